@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE config 2: 3840x2160 f16 RGBA, Rec.709 transfer LUT + RGB->Y'PbPr matrix on
+each of 2 layers, 2-layer alpha-over, f16 out; frames resident in HBM; Mpixels/s.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE).  Frames shard
+round-robin: global frame g belongs to rank g % N; no collective on the frame path.  RCCL carries
+only the parameter block (matrix + 128 KiB LUT) once at start and the timings at the end.
+
+A "step" = one batch of --batch frames per GPU through the fused chain kernel (one launch).
+The input ring (--ring frame sets, default 8 x 199 MB) is several times the 256 MiB Infinity
+Cache, so every launch streams from HBM.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 measured copy)
+BYTES_PER_PIXEL_PER_LAYER = 8  # one rgba_f16 read per layer pixel + one written per output pixel
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU (one kernel launch)")
+    ap.add_argument("--ring", type=int, default=8, help="distinct frame sets resident per GPU")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, seconds):
+    """The oracle (a scalar C port of the reference path) on the host cores, same workload, bounded."""
+    import oracle
+    from canvas_amd import REC709_RGB_TO_YPBPR, synth
+    so = None
+    try:
+        so = oracle.build(force=True, arch="-march=native -mtune=native", out="/tmp/canvas_oracle_native_%d.so" % os.getpid())
+        olib = oracle.lib(so)
+        flags = "gcc -std=c99 -O3 -march=native -fno-math-errno -ffp-contract=off"
+    except Exception:
+        olib = oracle.lib()
+        flags = "gcc -std=c99 -O3 -fno-math-errno -ffp-contract=off (generic x86-64)"
+    w, h, nl = args.width, args.height, args.layers
+    layers = [synth.layer_frame(w, h, k, 0) for k in range(nl)]
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    lut = oracle.transfer_table(0)
+    from canvas_amd.abi import HostFrame, rgba_frame_f16
+    arr = (C.POINTER(rgba_frame_f16) * nl)(*[C.pointer(l.c) for l in layers])
+
+    def one(out):
+        olib.orc_chain_color_over_f16(out.ref(), arr, nl, m.ctypes.data_as(C.POINTER(C.c_float)),
+                                      lut.ctypes.data_as(C.POINTER(C.c_uint16)), None)
+
+    out = HostFrame((0, 0, w - 1, h - 1), np.uint16)
+    one(out)                                            # warm: builds the half tables
+    t0, n = time.perf_counter(), 0
+    while n < 3 or time.perf_counter() - t0 < seconds:
+        one(out)
+        n += 1
+    dt1 = time.perf_counter() - t0
+    single = n * w * h / dt1 / 1e6
+
+    cores = os.cpu_count() or 1
+    cores = min(cores, 64)
+    from concurrent.futures import ThreadPoolExecutor
+    outs = [HostFrame((0, 0, w - 1, h - 1), np.uint16) for _ in range(cores)]
+
+    def worker(o):
+        c, t = 0, time.perf_counter()
+        while c < 2 or time.perf_counter() - t < seconds:
+            one(o)                                      # ctypes drops the GIL for the call
+            c += 1
+        return c
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        total = sum(ex.map(worker, outs))
+    dtn = time.perf_counter() - t0
+    if so and os.path.exists(so):
+        os.unlink(so)
+    cpu = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {
+        "value": round(single, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+        "sample": "%d x (%dx%d, %d layers) in %.1f s, 1 thread, %s" % (n, w, h, nl, dt1, flags),
+        "all_cores": {"value": round(total * w * h / dtn / 1e6, 2), "cores": cores,
+                      "sample": "%d frames in %.1f s, %d threads on independent frames" % (total, dtn, cores)},
+        "cpu": cpu,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from canvas_amd import REC709_RGB_TO_YPBPR, _lib, synth
+    from canvas_amd.device import DeviceFrame, chain_color_over
+    from canvas_amd.shard import broadcast_parameters, frames_of_rank
+
+    lib = _lib.load()
+    _lib.check(lib.cvs_init(local_rank), "cvs_init(%d)" % local_rank)
+    lib.init_half()
+    stream = lib.cvs_stream_create()
+
+    # parameter block: rank 0 owns it, everyone else receives it over RCCL
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    m = broadcast_parameters(lib, dist, rank, m, [_lib.LUT_REC709_TO_LINEAR_SCENE])
+
+    w, h, nl = args.width, args.height, args.layers
+    full = (0, 0, w - 1, h - 1)
+    ring = []
+    my_frames = frames_of_rank(rank, world, args.ring)          # global frame ids g with g % world == rank
+    for g in my_frames:
+        layers = []
+        for k in range(nl):
+            d = DeviceFrame(full, np.uint16)
+            d.upload(synth.layer_pixels(w, h, k, g))
+            layers.append(d)
+        ring.append((DeviceFrame(full, np.uint16), layers))
+
+    def step(i):
+        jobs = [ring[(i * args.batch + b) % len(ring)] for b in range(args.batch)]
+        chain_color_over(jobs, m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE, stream)
+
+    def barrier():
+        _lib.check(lib.cvs_stream_sync(stream), "sync")
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    assert lib.cvs_chain_last_was_fused() == 1, "the fused kernel did not run"
+
+    ev = [(lib.cvs_event_create(), lib.cvs_event_create()) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        lib.cvs_event_record(ev[i][0], stream)
+        step(args.warmup + i)
+        lib.cvs_event_record(ev[i][1], stream)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    launch_ms = [lib.cvs_event_elapsed_ms(a, b) for a, b in ev]
+    for a, b in ev:
+        lib.cvs_event_destroy(a), lib.cvs_event_destroy(b)
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # guard: the head of one output frame against the oracle
+    verified = None
+    if rank == 0:
+        try:
+            import oracle
+            rows = 4
+            from canvas_amd.abi import HostFrame
+            heads = [HostFrame((0, 0, w - 1, rows - 1), np.uint16, synth.layer_pixels(w, h, k, my_frames[0])[:rows]) for k in range(nl)]
+            want = oracle.chain_color_over(heads, m, oracle.transfer_table(0), None)
+            got = ring[0][0].download(stream).array[:rows]
+            verified = bool(np.array_equal(got, want.array))
+        except Exception as e:                                  # the oracle is only a checker here
+            verified = "unchecked: %s" % e
+
+    if rank == 0:
+        px_per_step = args.batch * w * h
+        total_px = px_per_step * args.steps * world
+        avg_ms = float(np.mean(launch_ms))
+        algo_bytes = px_per_step * BYTES_PER_PIXEL_PER_LAYER * (nl + 1)
+        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_chain_bytes_per_launch")
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "Mpixels/s through 4K f16 RGBA colour-matrix+alpha-over chain; % HBM roofline",
+            "value": round(total_px / elapsed / 1e6, 1),
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f16 storage, f32 arithmetic",
+            "data": "synthetic (Philox, seed 0xC0FFEE+1000*layer+frame), resident in HBM",
+            "config": {"workload": "%dx%d f16 RGBA, Rec.709->linear LUT + RGB->Y'PbPr 3x3 on %d layers + %d-layer alpha-over, f16 out" % (w, h, nl, nl),
+                       "frames_per_step_per_gpu": args.batch, "ring_frames_per_gpu": len(ring),
+                       "sharding": "frame g -> gpu g %% %d, no data-path collective" % world},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "k_chain<%d,pre-LUT>" % nl, "avg_launch_ms": round(avg_ms, 4),
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "achieved = %d B/px x %d px per launch / HIP-event launch time" % (BYTES_PER_PIXEL_PER_LAYER * (nl + 1), px_per_step)},
+            "verified_against_oracle": verified,
+            "device": lib.cvs_device_name().decode(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+            except Exception as e:
+                res["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %s" % e}
+        print(json.dumps(res), flush=True)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

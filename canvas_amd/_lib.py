@@ -1,0 +1,176 @@
+"""ctypes binding of libcanvas_hip.so (the C-ABI declared in include/canvas_hip.h).
+
+There is no fallback: if the shared library is missing or cannot be loaded, importing symbols
+from here raises, and every pixel entry point needs a HIP device at run time.
+"""
+import ctypes as C
+import os
+
+from .abi import (box2i, fir_filter, rational, rgba_frame_f16, rgba_frame_f32, v2f, video_frame_source_funcs,
+                  video_source)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcanvas_hip.so")
+
+CHAIN_MAX_LAYERS = 8
+LUT_NONE, LUT_REC709_TO_LINEAR_SCENE, LUT_REC709_TO_LINEAR_DISPLAY, LUT_LINEAR_TO_REC709, LUT_LINEAR_TO_SRGB = -1, 0, 1, 2, 3
+
+
+class rgba_f32(C.Structure):
+    _fields_ = [("r", C.c_float), ("g", C.c_float), ("b", C.c_float), ("a", C.c_float)]
+
+
+class rgba_frame_dev(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("format", C.c_int), ("full_window", box2i), ("current_window", box2i),
+                ("stream", C.c_void_p)]
+
+
+class chain_job(C.Structure):
+    _fields_ = [("out", C.POINTER(rgba_frame_f16)), ("layers", C.POINTER(rgba_frame_f16) * CHAIN_MAX_LAYERS),
+                ("nlayers", C.c_int)]
+
+
+P = C.POINTER
+_u16p, _f32p, _vp = P(C.c_uint16), P(C.c_float), C.c_void_p
+_F16, _F32 = P(rgba_frame_f16), P(rgba_frame_f32)
+
+# name -> (restype, argtypes); this table is also what tests use to check that every symbol the
+# header declares is exported.
+SIGNATURES = {
+    # (1) reference symbol set, host frames
+    "init_half": (None, []),
+    "get_frame_time": (C.c_int64, [P(rational), C.c_int]),
+    "get_time_frame": (C.c_int, [P(rational), C.c_int64]),
+    "gettime": (C.c_int64, []),
+    "video_get_frame_f16": (None, [P(video_source), C.c_int, _F16]),
+    "video_get_frame_f32": (None, [P(video_source), C.c_int, _F32]),
+    "video_get_frame_dev": (None, [P(video_source), C.c_int, P(rgba_frame_dev)]),
+    "video_copy_frame_f16": (None, [_F16, _F16]),
+    "video_copy_frame_alpha_f32": (None, [_F32, _F32, C.c_float]),
+    "video_mix_cross_f32": (None, [_F32, _F32, _F32, C.c_float]),
+    "video_mix_cross_f32_pull": (None, [_F32, P(video_source), C.c_int, P(video_source), C.c_int, C.c_float]),
+    "video_mix_over_f32": (None, [_F32, _F32, C.c_float]),
+    "video_scale_bilinear_f32": (None, [_F32, v2f, _F32, v2f, v2f]),
+    "video_scale_bilinear_f32_pull": (None, [_F32, v2f, P(video_source), C.c_int, P(box2i), v2f, v2f]),
+    "video_transfer_rec709_to_linear_scene": (None, [_u16p, _u16p, C.c_size_t]),
+    "video_transfer_rec709_to_linear_display": (None, [_u16p, _u16p, C.c_size_t]),
+    "video_transfer_linear_to_rec709": (None, [_u16p, _u16p, C.c_size_t]),
+    "video_transfer_linear_to_sRGB": (None, [_u16p, _u16p, C.c_size_t]),
+    "video_get_gamma45_ramp": (P(C.c_uint8), []),
+    "video_color_rgb_to_xyz_sdtv": (None, [_F16]),
+    "video_color_xyz_to_srgb": (None, [_F16]),
+    "filter_createTriangle": (None, [C.c_float, C.c_float, P(fir_filter)]),
+    "filter_createLanczos": (None, [C.c_float, C.c_int, C.c_float, P(fir_filter)]),
+    "filter_free": (None, [P(fir_filter)]),
+    "video_filter_gain_offset_f16": (None, [_F16, _F16, C.c_float, C.c_float]),
+    "video_fill_solid_f16": (None, [_F16, P(box2i), P(rgba_f32)]),
+    "video_fill_solid_f32": (None, [_F32, P(box2i), P(rgba_f32)]),
+    "workspace_create": (_vp, []),
+    "workspace_get_length": (C.c_int, [_vp]),
+    "workspace_add_item": (_vp, [_vp, _vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp]),
+    "workspace_get_item": (_vp, [_vp, C.c_int]),
+    "workspace_remove_item": (None, [_vp]),
+    "workspace_as_video_source": (None, [_vp, P(video_source)]),
+    "workspace_free": (None, [_vp]),
+    "workspace_get_item_pos": (None, [_vp, P(C.c_int64), P(C.c_int64), P(C.c_int64)]),
+    "workspace_get_item_offset": (C.c_int64, [_vp]),
+    "workspace_set_item_offset": (None, [_vp, C.c_int64]),
+    "workspace_get_item_source": (_vp, [_vp]),
+    "workspace_set_item_source": (None, [_vp, _vp]),
+    "workspace_get_item_tag": (_vp, [_vp]),
+    "workspace_set_item_tag": (None, [_vp, _vp]),
+    "workspace_update_item": (None, [_vp, P(C.c_int64), P(C.c_int64), P(C.c_int64), P(C.c_int64), P(_vp), P(_vp)]),
+    # (2) runtime + device twins
+    "cvs_init": (C.c_int, [C.c_int]),
+    "cvs_device_count": (C.c_int, []),
+    "cvs_current_device": (C.c_int, []),
+    "cvs_last_error": (C.c_char_p, []),
+    "cvs_device_name": (C.c_char_p, []),
+    "cvs_compute_units": (C.c_int, []),
+    "cvs_malloc": (_vp, [C.c_size_t]),
+    "cvs_free": (None, [_vp]),
+    "cvs_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "cvs_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "cvs_memcpy_d2d": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "cvs_memset": (C.c_int, [_vp, C.c_int, C.c_size_t, _vp]),
+    "cvs_stream_create": (_vp, []),
+    "cvs_stream_destroy": (None, [_vp]),
+    "cvs_stream_sync": (C.c_int, [_vp]),
+    "cvs_event_create": (_vp, []),
+    "cvs_event_destroy": (None, [_vp]),
+    "cvs_event_record": (C.c_int, [_vp, _vp]),
+    "cvs_event_sync": (C.c_int, [_vp]),
+    "cvs_event_elapsed_ms": (C.c_float, [_vp, _vp]),
+    "cvs_lut_device": (_vp, [C.c_int]),
+    "cvs_lut_host": (_u16p, [C.c_int]),
+    "cvs_lut_install": (C.c_int, [C.c_int, _u16p]),
+    "cvs_half_to_float_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "cvs_float_to_half_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "cvs_half_to_float_fast_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "cvs_float_to_half_fast_dev": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    "cvs_half_lookup_dev": (C.c_int, [_vp, _vp, _vp, C.c_size_t, _vp]),
+    "cvs_frame_f16_to_f32_dev": (C.c_int, [_F32, _F16, _vp]),
+    "cvs_frame_f32_to_f16_dev": (C.c_int, [_F16, _F32, _vp]),
+    "cvs_copy_frame_f16_dev": (C.c_int, [_F16, _F16, _vp]),
+    "cvs_copy_frame_alpha_f32_dev": (C.c_int, [_F32, _F32, C.c_float, _vp]),
+    "cvs_mix_cross_f32_dev": (C.c_int, [_F32, _F32, _F32, C.c_float, _vp]),
+    "cvs_mix_over_f32_dev": (C.c_int, [_F32, _F32, C.c_float, _vp]),
+    "cvs_color_matrix_f16_dev": (C.c_int, [_F16, _f32p, C.c_int, C.c_int, _vp]),
+    "cvs_gain_offset_f16_dev": (C.c_int, [_F16, _F16, C.c_float, C.c_float, _vp]),
+    "cvs_fill_solid_f16_dev": (C.c_int, [_F16, P(box2i), P(rgba_f32), _vp]),
+    "cvs_fill_solid_f32_dev": (C.c_int, [_F32, P(box2i), P(rgba_f32), _vp]),
+    "cvs_scale_bilinear_f32_dev": (C.c_int, [_F32, v2f, _F32, v2f, v2f, _vp]),
+    "cvs_fir_blur_f32_dev": (C.c_int, [_F32, _F32, _f32p, C.c_int, _vp]),
+    "cvs_resample_lanczos_f32_dev": (C.c_int, [_F32, _F32, C.c_float, C.c_float, C.c_int, _vp]),
+    # (3) fused chain
+    "cvs_chain_color_over_f16_dev": (C.c_int, [P(chain_job), C.c_int, _f32p, C.c_int, C.c_int, _vp]),
+    "cvs_chain_last_was_fused": (C.c_int, []),
+}
+
+# the five function-pointer globals of half.c:87-91
+HALF_POINTER_GLOBALS = {
+    "half_convert_to_float": C.CFUNCTYPE(None, _f32p, _u16p, C.c_int),
+    "half_convert_from_float": C.CFUNCTYPE(None, _u16p, _f32p, C.c_int),
+    "half_convert_to_float_fast": C.CFUNCTYPE(None, _f32p, _u16p, C.c_int),
+    "half_convert_from_float_fast": C.CFUNCTYPE(None, _u16p, _f32p, C.c_int),
+    "half_lookup": C.CFUNCTYPE(None, _u16p, _u16p, _u16p, C.c_int),
+}
+
+_lib = None
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load and bind the shared library.  Raises LibraryMissing when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or make -C canvas_amd/csrc).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def half_pointer(name):
+    """Read one of the half.c function-pointer globals (NULL before init_half())."""
+    lib = load()
+    addr = C.c_void_p.in_dll(lib, name).value
+    return HALF_POINTER_GLOBALS[name](addr) if addr else None
+
+
+def last_error():
+    return load().cvs_last_error().decode()
+
+
+def check(rc, what="call"):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, last_error()))

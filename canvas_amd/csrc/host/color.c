@@ -1,0 +1,140 @@
+/*
+ * color.c -- colour matrix entry points and the fused colour + alpha-over chain.
+ *
+ * Replaces src/cprocess/color.c:104-137 (video_color_rgb_to_xyz_sdtv) and :140-165
+ * (video_color_xyz_to_srgb); the general form behind both is cvs_color_matrix_f16_dev.
+ * The chain entry composes color.c + workspace.c:530-544 + main.c:43-71 into one kernel when every
+ * window involved covers the output's full window, and otherwise runs the same nodes one by one
+ * on the device (same arithmetic, f32 intermediates in HBM) so that ragged windows get the
+ * reference's window behaviour.
+ */
+#include "internal.h"
+
+CVS_EXPORT int cvs_color_matrix_f16_dev(rgba_frame_f16 *frame, const float m[9], int pre_lut, int post_lut, cvs_stream_t s) {
+    if (cvs_enter() != 0) return -1;
+    if (box2i_is_empty(&frame->current_window)) return 0;
+    if (!cvs_box_contains(&frame->full_window, &frame->current_window)) { cvs_set_error("colour matrix: current_window outside the buffer"); return -1; }
+    const half *pre = cvs_lut_dev_or_null(pre_lut), *post = cvs_lut_dev_or_null(post_lut);
+    if ((pre_lut != CVS_LUT_NONE && !pre) || (post_lut != CVS_LUT_NONE && !post)) return -1;
+    CVS_KERNEL(cvk_color_matrix(cvs_view(frame->data, &frame->full_window), cvs_rect(&frame->current_window), m, pre, post, cvs_cus(), cvs_pick_stream(s)));
+    return 0;
+}
+
+static void host_color(rgba_frame_f16 *frame, const float m[9], int pre, int post) {
+    if (box2i_is_empty(&frame->current_window) || cvs_enter() != 0) return;
+    hipStream_t s = cvs_pick_stream(NULL);
+    cvs_staged d = { 0 };
+    rgba_frame_f16 f = *frame;
+    int rc = cvs_stage_in(&d, frame->data, cvs_box_pixels(&frame->full_window) * sizeof(rgba_f16), 1, s);
+    f.data = d.dev;
+    if (rc == 0) rc = cvs_color_matrix_f16_dev(&f, m, pre, post, s);
+    if (rc == 0) cvs_stage_out(&d, frame->data, s);
+    cvs_stage_free(&d);
+}
+
+/* SMPTE-C RGB (Rec.709 transfer) -> linear XYZ; coefficients as color.c:115-118, column-major */
+CVS_EXPORT void video_color_rgb_to_xyz_sdtv(rgba_frame_f16 *frame) {
+    static const float m[9] = { 0.3936f, 0.2124f, 0.0187f, 0.3652f, 0.7010f, 0.1119f, 0.1916f, 0.0865f, 0.9582f };
+    host_color(frame, m, CVS_LUT_REC709_TO_LINEAR_SCENE, CVS_LUT_NONE);
+}
+
+/* linear XYZ -> sRGB; coefficients as color.c:143-146 */
+CVS_EXPORT void video_color_xyz_to_srgb(rgba_frame_f16 *frame) {
+    static const float m[9] = { 3.2410f, -0.9692f, 0.0556f, -1.5374f, 1.8760f, -0.2040f, -0.4986f, 0.0416f, 1.0570f };
+    host_color(frame, m, CVS_LUT_NONE, CVS_LUT_LINEAR_TO_SRGB);
+}
+
+/* ---------------------------------------------------------------- chain */
+
+static __thread int t_last_fused = -1;
+CVS_EXPORT int cvs_chain_last_was_fused(void) { return t_last_fused; }
+
+static bool same_box(const box2i *a, const box2i *b) {
+    return a->min.x == b->min.x && a->min.y == b->min.y && a->max.x == b->max.x && a->max.y == b->max.y;
+}
+
+static bool job_is_fusable(const cvs_chain_job *j) {
+    if (j->nlayers < 1 || j->nlayers > CVS_CHAIN_MAX_LAYERS) return false;
+    const box2i *fw = &j->out->full_window;
+    if (box2i_is_empty(fw)) return false;
+    if (((uintptr_t)j->out->data & 15u) != 0) return false;
+    for (int k = 0; k < j->nlayers; k++) {
+        const rgba_frame_f16 *l = j->layers[k];
+        if (!same_box(&l->full_window, fw) || !same_box(&l->current_window, fw)) return false;
+        if (((uintptr_t)l->data & 15u) != 0) return false;
+    }
+    return true;
+}
+
+/* the same graph, one device kernel per reference node; scratch frames are f32 like the reference's temps */
+static int chain_unfused(const cvs_chain_job *j, const float m[9], int pre_lut, int post_lut, hipStream_t s) {
+    const box2i *fw = &j->out->full_window;
+    size_t n = cvs_box_pixels(fw);
+    rgba_frame_f16 graded = { NULL, *fw, *fw };
+    rgba_frame_f32 acc = { NULL, *fw, *fw }, tmp = { NULL, *fw, *fw };
+    int rc = 0;
+    if (!n) { box2i_set_empty(&j->out->current_window); return 0; }
+    CVS_HIP(hipMalloc((void **)&graded.data, n * sizeof(rgba_f16)));
+    if (hipMalloc((void **)&acc.data, n * sizeof(rgba_f32)) != hipSuccess || hipMalloc((void **)&tmp.data, n * sizeof(rgba_f32)) != hipSuccess) {
+        cvs_set_error("chain: out of device memory for f32 intermediates");
+        rc = -1;
+    }
+    bool have_acc = false;
+    for (int k = 0; rc == 0 && k < j->nlayers; k++) {
+        /* the layer source: a graded copy of the input, clipped like video_copy_frame_f16 */
+        rc = cvs_copy_frame_f16_dev(&graded, j->layers[k], s);
+        if (rc == 0) rc = cvs_color_matrix_f16_dev(&graded, m, pre_lut, post_lut, s);
+        if (rc != 0) break;
+        if (!have_acc) {                       /* workspace.c:530: lowest item straight into the output */
+            rc = cvs_frame_f16_to_f32_dev(&acc, &graded, s);
+            have_acc = true;
+        } else {                               /* workspace.c:538-543 */
+            rc = cvs_frame_f16_to_f32_dev(&tmp, &graded, s);
+            if (rc == 0) rc = cvs_mix_over_f32_dev(&acc, &tmp, 1.0f, s);
+        }
+    }
+    if (rc == 0) rc = cvs_frame_f32_to_f16_dev(j->out, &acc, s);       /* main.c:43-71 */
+    if (rc == 0) rc = (int)hipStreamSynchronize(s);                    /* scratch is freed below */
+    hipFree(graded.data); hipFree(acc.data); hipFree(tmp.data);
+    if (rc != 0) box2i_set_empty(&j->out->current_window);
+    return rc;
+}
+
+CVS_EXPORT int cvs_chain_color_over_f16_dev(const cvs_chain_job *jobs, int njobs, const float m[9],
+                                            int pre_lut, int post_lut, cvs_stream_t stream) {
+    if (cvs_enter() != 0) return -1;
+    if (njobs <= 0) return 0;
+    hipStream_t s = cvs_pick_stream(stream);
+    const half *pre = cvs_lut_dev_or_null(pre_lut), *post = cvs_lut_dev_or_null(post_lut);
+    if ((pre_lut != CVS_LUT_NONE && !pre) || (post_lut != CVS_LUT_NONE && !post)) return -1;
+
+    bool all_fusable = true;
+    for (int i = 0; i < njobs; i++) all_fusable = all_fusable && job_is_fusable(&jobs[i]);
+    if (!all_fusable) {
+        t_last_fused = 0;
+        for (int i = 0; i < njobs; i++) {
+            int rc = chain_unfused(&jobs[i], m, pre_lut, post_lut, s);
+            if (rc != 0) return rc;
+        }
+        return 0;
+    }
+
+    cvk_chain_job *recs = calloc((size_t)njobs, sizeof *recs);
+    if (!recs) { cvs_set_error("chain: out of host memory"); return -1; }
+    int uniform = jobs[0].nlayers;
+    for (int i = 0; i < njobs; i++) {
+        cvk_chain_job *kj = &recs[i];
+        kj->out = jobs[i].out->data;
+        for (int k = 0; k < jobs[i].nlayers; k++) kj->layer[k] = jobs[i].layers[k]->data;
+        kj->nlayers = jobs[i].nlayers;
+        kj->npixels = cvs_box_pixels(&jobs[i].out->full_window);
+        if (jobs[i].nlayers != uniform) uniform = 0;
+        jobs[i].out->current_window = jobs[i].out->full_window;
+    }
+    if (uniform > 4) uniform = 0;
+    int rc = cvk_chain_color_over(recs, njobs, uniform, m, pre, post, cvs_cus(), s);
+    free(recs);
+    if (rc != 0) { cvs_set_error("chain kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
+    t_last_fused = 1;
+    return 0;
+}

@@ -1,0 +1,217 @@
+/*
+ * runtime.c -- device binding, streams, memory, error reporting, host<->HBM staging.
+ *
+ * The reference has no device layer (its frames are malloc'd host buffers).  What it does have is
+ * a threading contract this file has to keep: get_frame may be entered from any thread, with or
+ * without the GIL (SURVEY.md section 8b "threading").  HIP's current device is per thread, so every
+ * entry point goes through cvs_enter(), and each thread that does not bring its own stream gets one
+ * of its own -- no shared stream, no global lock on the pixel path.
+ */
+#define _GNU_SOURCE
+#include "internal.h"
+#include <pthread.h>
+#include <stdarg.h>
+#include <time.h>
+
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static int g_device = -1;
+static int g_cus = 256;
+static char g_name[640];
+
+static __thread char t_error[512];
+static __thread hipStream_t t_stream;
+static __thread int t_stream_device = -1;
+
+void cvs_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(t_error, sizeof t_error, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "canvas_hip: %s\n", t_error);
+}
+
+void cvs_clear_error(void) { t_error[0] = 0; }
+
+CVS_EXPORT const char *cvs_last_error(void) { return t_error; }
+
+CVS_EXPORT int cvs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+CVS_EXPORT int cvs_init(int device) {
+    pthread_mutex_lock(&g_lock);
+    if (g_device == device) { pthread_mutex_unlock(&g_lock); return hipSetDevice(device) == hipSuccess ? 0 : -1; }
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        pthread_mutex_unlock(&g_lock);
+        cvs_set_error("no HIP device available (%s); this library has no CPU path", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+        return -1;
+    }
+    if (device < 0 || device >= n) {
+        pthread_mutex_unlock(&g_lock);
+        cvs_set_error("device %d out of range (0..%d)", device, n - 1);
+        return -1;
+    }
+    if ((e = hipSetDevice(device)) != hipSuccess) {
+        pthread_mutex_unlock(&g_lock);
+        cvs_set_error("hipSetDevice(%d): %s", device, hipGetErrorString(e));
+        return -1;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        snprintf(g_name, sizeof g_name, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    g_device = device;
+    pthread_mutex_unlock(&g_lock);
+    return 0;
+}
+
+int cvs_enter(void) {
+    if (g_device < 0) {
+        const char *env = getenv("CVS_DEVICE");
+        if (cvs_init(env ? atoi(env) : 0) != 0) return -1;
+    }
+    if (hipSetDevice(g_device) != hipSuccess) { cvs_set_error("hipSetDevice(%d) failed", g_device); return -1; }
+    return 0;
+}
+
+CVS_EXPORT int cvs_current_device(void) { return g_device; }
+CVS_EXPORT const char *cvs_device_name(void) { return cvs_enter() == 0 ? g_name : ""; }
+CVS_EXPORT int cvs_compute_units(void) { return cvs_enter() == 0 ? g_cus : 0; }
+int cvs_cus(void) { return g_cus; }
+
+hipStream_t cvs_pick_stream(cvs_stream_t s) {
+    if (s) return (hipStream_t)s;
+    if (t_stream_device != g_device) {
+        if (hipStreamCreateWithFlags(&t_stream, hipStreamNonBlocking) != hipSuccess) t_stream = NULL;
+        t_stream_device = g_device;
+    }
+    return t_stream;
+}
+
+CVS_EXPORT void *cvs_malloc(size_t bytes) {
+    void *p = NULL;
+    if (cvs_enter() != 0) return NULL;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) { cvs_set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return NULL; }
+    return p;
+}
+
+CVS_EXPORT void cvs_free(void *dev) {
+    if (dev && cvs_enter() == 0) hipFree(dev);
+}
+
+CVS_EXPORT int cvs_memcpy_h2d(void *dev, const void *host, size_t bytes, cvs_stream_t s) {
+    if (cvs_enter() != 0) return -1;
+    CVS_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, cvs_pick_stream(s)));
+    if (!s) CVS_HIP(hipStreamSynchronize(cvs_pick_stream(s)));
+    return 0;
+}
+
+CVS_EXPORT int cvs_memcpy_d2h(void *host, const void *dev, size_t bytes, cvs_stream_t s) {
+    if (cvs_enter() != 0) return -1;
+    CVS_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, cvs_pick_stream(s)));
+    CVS_HIP(hipStreamSynchronize(cvs_pick_stream(s)));
+    return 0;
+}
+
+CVS_EXPORT int cvs_memcpy_d2d(void *dst, const void *src, size_t bytes, cvs_stream_t s) {
+    if (cvs_enter() != 0) return -1;
+    CVS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, cvs_pick_stream(s)));
+    return 0;
+}
+
+CVS_EXPORT int cvs_memset(void *dev, int value, size_t bytes, cvs_stream_t s) {
+    if (cvs_enter() != 0) return -1;
+    CVS_HIP(hipMemsetAsync(dev, value, bytes, cvs_pick_stream(s)));
+    return 0;
+}
+
+CVS_EXPORT cvs_stream_t cvs_stream_create(void) {
+    hipStream_t s = NULL;
+    if (cvs_enter() != 0) return NULL;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { cvs_set_error("hipStreamCreate failed"); return NULL; }
+    return s;
+}
+
+CVS_EXPORT void cvs_stream_destroy(cvs_stream_t s) {
+    if (s && cvs_enter() == 0) hipStreamDestroy((hipStream_t)s);
+}
+
+CVS_EXPORT int cvs_stream_sync(cvs_stream_t s) {
+    if (cvs_enter() != 0) return -1;
+    CVS_HIP(hipStreamSynchronize(cvs_pick_stream(s)));
+    return 0;
+}
+
+CVS_EXPORT cvs_event_t cvs_event_create(void) {
+    hipEvent_t e = NULL;
+    if (cvs_enter() != 0) return NULL;
+    if (hipEventCreate(&e) != hipSuccess) { cvs_set_error("hipEventCreate failed"); return NULL; }
+    return e;
+}
+
+CVS_EXPORT void cvs_event_destroy(cvs_event_t e) {
+    if (e && cvs_enter() == 0) hipEventDestroy((hipEvent_t)e);
+}
+
+CVS_EXPORT int cvs_event_record(cvs_event_t e, cvs_stream_t s) {
+    if (cvs_enter() != 0) return -1;
+    CVS_HIP(hipEventRecord((hipEvent_t)e, cvs_pick_stream(s)));
+    return 0;
+}
+
+CVS_EXPORT int cvs_event_sync(cvs_event_t e) {
+    if (cvs_enter() != 0) return -1;
+    CVS_HIP(hipEventSynchronize((hipEvent_t)e));
+    return 0;
+}
+
+CVS_EXPORT float cvs_event_elapsed_ms(cvs_event_t start, cvs_event_t stop) {
+    float ms = -1.0f;
+    if (cvs_enter() != 0) return -1.0f;
+    if (hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop) != hipSuccess) { cvs_set_error("hipEventElapsedTime failed"); return -1.0f; }
+    return ms;
+}
+
+/* ---- staging */
+
+int cvs_stage_in(cvs_staged *st, const void *host, size_t bytes, int upload, hipStream_t s) {
+    st->dev = NULL;
+    st->bytes = bytes;
+    if (!bytes) return 0;
+    CVS_HIP(hipMalloc(&st->dev, bytes));
+    if (upload) CVS_HIP(hipMemcpyAsync(st->dev, host, bytes, hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+int cvs_stage_out(cvs_staged *st, void *host, hipStream_t s) {
+    if (st->dev && st->bytes) CVS_HIP(hipMemcpyAsync(host, st->dev, st->bytes, hipMemcpyDeviceToHost, s));
+    CVS_HIP(hipStreamSynchronize(s));
+    return 0;
+}
+
+void cvs_stage_free(cvs_staged *st) {
+    if (st->dev) hipFree(st->dev);
+    st->dev = NULL;
+}
+
+/* ---- timing helpers of the reference's C-ABI */
+
+CVS_EXPORT int64_t gettime(void) {                                   /* src/cprocess/clock.c:28-52 */
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (int64_t)ts.tv_sec * NS_PER_SEC + (int64_t)ts.tv_nsec;
+}
+
+CVS_EXPORT int64_t get_frame_time(const rational *rate, int frame) { /* src/cprocess/main.c:23-26 */
+    return ((int64_t)frame * NS_PER_SEC * (int64_t)rate->d) / (int64_t)rate->n + INT64_C(1);
+}
+
+CVS_EXPORT int get_time_frame(const rational *rate, int64_t time) {  /* src/cprocess/main.c:28-31 */
+    return (int)((time * (int64_t)rate->n) / (NS_PER_SEC * (int64_t)rate->d));
+}

@@ -1,0 +1,325 @@
+/*
+ * scale.c -- separable resampling and blur: planning on the host, pixels in kernels/fir_ops.hip.
+ *
+ * video_scale_bilinear_f32 / _pull follow src/cprocess/video_scale.c:231-319 decision for
+ * decision: the identity shortcuts, smaller factor first (:252), the intermediate frame's window
+ * (:256-262, :271-277 -- derived with `* factor`, so a two-axis downscale only covers part of the
+ * target; kept, it is what the reference outputs), the zero fill, the window of lines actually
+ * touched (:124, :191, :225), the pull rectangle (:303-309).
+ *
+ * Per pass the reference regenerates a triangle filter per line with the fractional offset of
+ * that line's centre (:67-71, :97-101).  plan_pass() runs the same generator on the host and
+ * records, per target line, which source lines feed it and with what weight, in ascending source
+ * order; that table (a few KiB) is uploaded and the gather kernel does the rest.
+ *
+ * The FIR blur and the Lanczos resampler have no counterpart to follow (the reference has no blur,
+ * and filter_createLanczos has no caller): they are defined in DESIGN.md and reuse the same kernel.
+ */
+#define _GNU_SOURCE
+#include "internal.h"
+#include <limits.h>
+#include <math.h>
+
+typedef struct {
+    int t0, t1;            /* target lines covered by the table */
+    int stride;
+    int *ntaps, *tap_src;
+    float *taps;
+    int used_lo, used_hi;  /* target lines that received at least one tap */
+} tap_table;
+
+static void table_free(tap_table *tb) { free(tb->ntaps); free(tb->tap_src); free(tb->taps); memset(tb, 0, sizeof *tb); }
+
+static int table_alloc(tap_table *tb, int t0, int t1, int stride) {
+    memset(tb, 0, sizeof *tb);
+    tb->t0 = t0; tb->t1 = t1; tb->stride = stride > 0 ? stride : 1;
+    tb->used_lo = INT_MAX; tb->used_hi = INT_MIN;
+    size_t lines = t1 >= t0 ? (size_t)(t1 - t0 + 1) : 0;
+    tb->ntaps = calloc(lines ? lines : 1, sizeof(int));
+    tb->tap_src = calloc((lines ? lines : 1) * (size_t)tb->stride, sizeof(int));
+    tb->taps = calloc((lines ? lines : 1) * (size_t)tb->stride, sizeof(float));
+    if (!tb->ntaps || !tb->tap_src || !tb->taps) { table_free(tb); return -1; }
+    return 0;
+}
+
+static inline void table_add(tap_table *tb, int t, int s, float c) {
+    int row = t - tb->t0, k = tb->ntaps[row];
+    if (k < tb->stride) { tb->tap_src[(size_t)row * tb->stride + k] = s; tb->taps[(size_t)row * tb->stride + k] = c; }
+    tb->ntaps[row] = k + 1;
+}
+
+/* widest triangle the per-line generator can return (video_scale.c:52-57) */
+static int triangle_cap(float factor) {
+    float dummy = factor;
+    fir_filter probe = { &dummy, 0, 0 };
+    filter_createTriangle(factor, 0.0f, &probe);
+    return probe.width + 3;
+}
+
+/* Tap table of one triangle pass.  count_touch: whether an in-range tap marks its target line as
+ * used even when the other axis is empty (true for the vertical pass, :88-89; the horizontal pass
+ * only marks inside its row loop, :186-187). */
+static int plan_triangle(tap_table *tb, float tmin, float smin, float factor, int s0, int s1, int t0, int t1, bool count_touch) {
+    const int cap = triangle_cap(factor);
+    float *buf = malloc(sizeof(float) * (size_t)cap);
+    if (!buf) return -1;
+    fir_filter f = { buf, 0, 0 };
+    int rc = 0;
+    if (factor > 1.0f) {
+        /* scatter form: how many source lines can land on one target line?  count first */
+        int lines = t1 >= t0 ? t1 - t0 + 1 : 0;
+        int *count = calloc((size_t)(lines ? lines : 1), sizeof(int));
+        if (!count) { free(buf); return -1; }
+        for (int pass = 0; pass < 2 && rc == 0; pass++) {
+            if (pass == 1) {
+                int most = 1;
+                for (int i = 0; i < lines; i++) if (count[i] > most) most = count[i];
+                rc = table_alloc(tb, t0, t1, most);
+                if (rc != 0) break;
+            }
+            for (int s = s0; s <= s1; s++) {
+                float centre_f = (s - smin) * factor + tmin;
+                int centre = (int)floor(centre_f);
+                f.width = cap;
+                filter_createTriangle(factor, centre_f - centre, &f);
+                for (int k = 0; k < f.width; k++) {
+                    int t = centre - f.center + k;
+                    if (t < t0 || t > t1) continue;
+                    if (pass == 0) count[t - t0]++;
+                    else {
+                        table_add(tb, t, s, buf[k]);
+                        if (count_touch) { if (t < tb->used_lo) tb->used_lo = t; if (t > tb->used_hi) tb->used_hi = t; }
+                    }
+                }
+            }
+        }
+        free(count);
+    } else {
+        rc = table_alloc(tb, t0, t1, cap);
+        for (int t = t0; rc == 0 && t <= t1; t++) {
+            float centre_f = (t - tmin) / factor + smin;
+            int centre = (int)floor(centre_f);
+            f.width = cap;
+            filter_createTriangle(factor, centre_f - centre, &f);
+            for (int k = 0; k < f.width; k++) {
+                int s = centre - f.center + k;
+                if (s < s0 || s > s1) continue;
+                table_add(tb, t, s, buf[k]);
+                if (count_touch) { if (t < tb->used_lo) tb->used_lo = t; if (t > tb->used_hi) tb->used_hi = t; }
+            }
+        }
+    }
+    free(buf);
+    return rc;
+}
+
+/* upload a table and run the gather over [used_lo, used_hi] x [lo, hi] */
+static int run_table(const tap_table *tb, cvk_view target, cvk_view source, int axis, int lo, int hi, hipStream_t s) {
+    if (tb->used_hi < tb->used_lo || hi < lo) return 0;
+    const int first = tb->used_lo - tb->t0, lines = tb->used_hi - tb->used_lo + 1;
+    size_t n_i = (size_t)lines, n_t = (size_t)lines * (size_t)tb->stride;
+    char *dev = NULL;
+    size_t off_src = (n_i * sizeof(int) + 255) & ~(size_t)255;
+    size_t off_tap = off_src + ((n_t * sizeof(int) + 255) & ~(size_t)255);
+    size_t total = off_tap + n_t * sizeof(float);
+    CVS_HIP(hipMalloc((void **)&dev, total));
+    hipError_t e = hipMemcpyAsync(dev, tb->ntaps + first, n_i * sizeof(int), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dev + off_src, tb->tap_src + (size_t)first * tb->stride, n_t * sizeof(int), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(dev + off_tap, tb->taps + (size_t)first * tb->stride, n_t * sizeof(float), hipMemcpyHostToDevice, s);
+    int rc = (int)e;
+    if (rc == 0) {
+        cvk_fir_params fp;
+        memset(&fp, 0, sizeof fp);
+        fp.target = target; fp.source = source; fp.axis = axis;
+        fp.t0 = tb->used_lo; fp.t1 = tb->used_hi; fp.lo = lo; fp.hi = hi;
+        fp.ntaps = (const int *)dev; fp.tap_src = (const int *)(dev + off_src); fp.taps = (const float *)(dev + off_tap);
+        fp.stride = tb->stride;
+        rc = cvk_fir_gather(&fp, s);
+    }
+    if (rc == 0) rc = (int)hipStreamSynchronize(s);     /* the host table and `dev` go away now */
+    hipFree(dev);
+    if (rc != 0) cvs_set_error("FIR pass failed: %s", hipGetErrorString((hipError_t)rc));
+    return rc;
+}
+
+/* one pass of video_scale.c:34-127 (axis 0) or :129-229 (axis 1) on device frames */
+static int triangle_pass(rgba_frame_f32 *target, float tmin, const rgba_frame_f32 *source, float smin, float factor, int axis, hipStream_t s) {
+    const box2i srect = source->current_window, trect = target->full_window;
+    const int lo = axis ? (srect.min.y > trect.min.y ? srect.min.y : trect.min.y) : (srect.min.x > trect.min.x ? srect.min.x : trect.min.x);
+    const int hi = axis ? (srect.max.y < trect.max.y ? srect.max.y : trect.max.y) : (srect.max.x < trect.max.x ? srect.max.x : trect.max.x);
+    const int s0 = axis ? srect.min.x : srect.min.y, s1 = axis ? srect.max.x : srect.max.y;
+    const int t0 = axis ? trect.min.x : trect.min.y, t1 = axis ? trect.max.x : trect.max.y;
+    cvk_view tv = cvs_view(target->data, &target->full_window), sv = cvs_view(source->data, &source->full_window);
+
+    CVS_KERNEL(cvk_zero_f32(tv, s));
+    if (factor == 1.0f && tmin == smin) return cvs_copy_frame_alpha_f32_dev(target, source, 1.0f, s);
+
+    tap_table tb;
+    int rc = plan_triangle(&tb, tmin, smin, factor, s0, s1, t0, t1, axis == 0 || lo <= hi);
+    if (rc != 0) { cvs_set_error("scale: out of memory planning taps"); return rc; }
+    /* the gather reads source lines named in the table; they must be inside the source buffer */
+    rc = run_table(&tb, tv, sv, axis, lo, hi, s);
+    if (axis) box2i_set(&target->current_window, tb.used_lo, lo, tb.used_hi, hi);
+    else      box2i_set(&target->current_window, lo, tb.used_lo, hi, tb.used_hi);
+    table_free(&tb);
+    return rc;
+}
+
+CVS_EXPORT int cvs_scale_bilinear_f32_dev(rgba_frame_f32 *target, v2f tp, const rgba_frame_f32 *source, v2f sp, v2f fac, cvs_stream_t stream) {
+    if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
+    hipStream_t s = cvs_pick_stream(stream);
+    if (fac.x == 1.0f && tp.x == sp.x) {
+        if (fac.y == 1.0f && tp.y == sp.y) return cvs_copy_frame_alpha_f32_dev(target, source, 1.0f, s);
+        return triangle_pass(target, tp.y, source, sp.y, fac.y, 0, s);
+    }
+    if (fac.y == 1.0f && tp.y == sp.y) return triangle_pass(target, tp.x, source, sp.x, fac.x, 1, s);
+
+    rgba_frame_f32 mid;
+    const box2i *tf = &target->full_window, *sc = &source->current_window;
+    const bool x_first = fac.x < fac.y;
+    if (x_first)
+        box2i_set(&mid.full_window, (int)(sp.x - (tp.x - tf->min.x) * fac.x), sc->min.y,
+                  (int)(sp.x + (tf->max.x - tp.x) * fac.x), sc->max.y);
+    else
+        box2i_set(&mid.full_window, sc->min.x, (int)(sp.y - (tp.y - tf->min.y) * fac.y),
+                  sc->max.x, (int)(sp.y + (tf->max.y - tp.y) * fac.y));
+    box2i_intersect(&mid.full_window, &mid.full_window, tf);
+    mid.current_window = mid.full_window;
+    size_t n = cvs_box_pixels(&mid.full_window);
+    mid.data = cvs_malloc(sizeof(rgba_f32) * (n ? n : 1));
+    if (!mid.data) { box2i_set_empty(&target->current_window); return -1; }
+    int rc;
+    if (x_first) { rc = triangle_pass(&mid, tp.x, source, sp.x, fac.x, 1, s); if (rc == 0) rc = triangle_pass(target, tp.y, &mid, sp.y, fac.y, 0, s); }
+    else         { rc = triangle_pass(&mid, tp.y, source, sp.y, fac.y, 0, s); if (rc == 0) rc = triangle_pass(target, tp.x, &mid, sp.x, fac.x, 1, s); }
+    if (rc == 0) rc = cvs_stream_sync(s);
+    cvs_free(mid.data);
+    if (rc != 0) box2i_set_empty(&target->current_window);
+    return rc;
+}
+
+CVS_EXPORT void video_scale_bilinear_f32(rgba_frame_f32 *target, v2f tp, rgba_frame_f32 *source, v2f sp, v2f fac) {
+    if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return; }
+    hipStream_t s = cvs_pick_stream(NULL);
+    cvs_staged d_t = { 0 }, d_s = { 0 };
+    rgba_frame_f32 ft = *target, fs = *source;
+    int rc = cvs_stage_in(&d_t, target->data, cvs_box_pixels(&target->full_window) * sizeof(rgba_f32), 1, s);
+    if (rc == 0) rc = cvs_stage_in(&d_s, source->data, cvs_box_pixels(&source->full_window) * sizeof(rgba_f32), !box2i_is_empty(&source->current_window), s);
+    ft.data = d_t.dev; fs.data = d_s.dev;
+    if (rc == 0) rc = cvs_scale_bilinear_f32_dev(&ft, tp, &fs, sp, fac, s);
+    if (rc == 0) rc = cvs_stage_out(&d_t, target->data, s);
+    target->current_window = ft.current_window;
+    if (rc != 0) box2i_set_empty(&target->current_window);
+    cvs_stage_free(&d_t); cvs_stage_free(&d_s);
+}
+
+CVS_EXPORT void video_scale_bilinear_f32_pull(rgba_frame_f32 *target, v2f tp, video_source *source, int frame,
+                                              box2i *source_rect, v2f sp, v2f fac) {
+    if (fac.x == 0.0f || fac.y == 0.0f) { box2i_set_empty(&target->current_window); return; }   /* video_scale.c:290-293 */
+    if (fac.x == 1.0f && fac.y == 1.0f && tp.x == sp.x && tp.y == sp.y) { video_get_frame_f32(source, frame, target); return; }
+    const box2i *tf = &target->full_window;
+    rgba_frame_f32 tmp;
+    box2i_set(&tmp.full_window,
+              (int)(sp.x - (tp.x - tf->min.x) / fac.x) - 1, (int)(sp.y - (tp.y - tf->min.y) / fac.y) - 1,
+              (int)(sp.x + (tf->max.x - tp.x) / fac.x) + 1, (int)(sp.y + (tf->max.y - tp.y) / fac.y) + 1);
+    box2i_intersect(&tmp.full_window, &tmp.full_window, source_rect);
+    tmp.current_window = tmp.full_window;
+    size_t n = cvs_box_pixels(&tmp.full_window);
+    tmp.data = malloc(sizeof(rgba_f32) * (n ? n : 1));
+    if (!tmp.data) { box2i_set_empty(&target->current_window); return; }
+    video_get_frame_f32(source, frame, &tmp);
+    video_scale_bilinear_f32(target, tp, &tmp, sp, fac);
+    free(tmp.data);
+}
+
+/* ---------------------------------------------------------------- FIR blur (repo-defined, DESIGN.md "A11")
+ * Odd or even tap count, centre = ntaps/2; horizontal then vertical; accumulate from 0.0f in
+ * ascending tap order; taps falling outside the source's current_window are skipped; output window =
+ * source.current ∩ target.full. */
+static int plan_blur(tap_table *tb, int t0, int t1, int s0, int s1, const float *taps, int ntaps) {
+    int rc = table_alloc(tb, t0, t1, ntaps);
+    const int c = ntaps / 2;
+    for (int t = t0; rc == 0 && t <= t1; t++)
+        for (int k = 0; k < ntaps; k++) {
+            int sidx = t - c + k;
+            if (sidx < s0 || sidx > s1) continue;
+            table_add(tb, t, sidx, taps[k]);
+        }
+    tb->used_lo = t0; tb->used_hi = t1;
+    return rc;
+}
+
+CVS_EXPORT int cvs_fir_blur_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, const float *taps, int ntaps, cvs_stream_t stream) {
+    if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
+    if (ntaps < 1 || !taps) { cvs_set_error("blur: need at least one tap"); box2i_set_empty(&target->current_window); return -1; }
+    hipStream_t s = cvs_pick_stream(stream);
+    box2i win;
+    box2i_intersect(&win, &source->current_window, &target->full_window);
+    target->current_window = win;
+    if (box2i_is_empty(&win)) return 0;
+    const box2i *sw = &source->current_window;
+    rgba_frame_f32 mid = { NULL, *sw, *sw };
+    mid.data = cvs_malloc(cvs_box_pixels(sw) * sizeof(rgba_f32));
+    if (!mid.data) { box2i_set_empty(&target->current_window); return -1; }
+    tap_table tb;
+    int rc = plan_blur(&tb, sw->min.x, sw->max.x, sw->min.x, sw->max.x, taps, ntaps);
+    if (rc == 0) rc = run_table(&tb, cvs_view(mid.data, &mid.full_window), cvs_view(source->data, &source->full_window), 1, sw->min.y, sw->max.y, s);
+    table_free(&tb);
+    if (rc == 0) rc = plan_blur(&tb, win.min.y, win.max.y, sw->min.y, sw->max.y, taps, ntaps);
+    if (rc == 0) { rc = run_table(&tb, cvs_view(target->data, &target->full_window), cvs_view(mid.data, &mid.full_window), 0, win.min.x, win.max.x, s); table_free(&tb); }
+    cvs_free(mid.data);
+    if (rc != 0) box2i_set_empty(&target->current_window);
+    return rc;
+}
+
+/* ---------------------------------------------------------------- Lanczos gather resample (repo-defined)
+ * Per target line the taps come from filter_createLanczos(factor, kernel_size, frac(centre)) with
+ * centre = t / factor (origin 0 on both sides); x pass then y pass; f32 accumulate from 0. */
+static int plan_lanczos(tap_table *tb, int t0, int t1, int s0, int s1, float factor, int ksize) {
+    fir_filter probe = { NULL, 0, 0 };
+    filter_createLanczos(factor, ksize, 0.0f, &probe);
+    int cap = probe.width + 3;
+    filter_free(&probe);
+    int rc = table_alloc(tb, t0, t1, cap);
+    for (int t = t0; rc == 0 && t <= t1; t++) {
+        float centre_f = (float)t / factor;
+        int centre = (int)floor(centre_f);
+        fir_filter f = { NULL, 0, 0 };
+        filter_createLanczos(factor, ksize, centre_f - centre, &f);
+        if (!f.coeff) { rc = -1; break; }
+        for (int k = 0; k < f.width; k++) {
+            int sidx = centre - f.center + k;
+            if (sidx < s0 || sidx > s1) continue;
+            table_add(tb, t, sidx, f.coeff[k]);
+        }
+        filter_free(&f);
+    }
+    tb->used_lo = t0; tb->used_hi = t1;
+    return rc;
+}
+
+CVS_EXPORT int cvs_resample_lanczos_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, float fx, float fy, int ksize, cvs_stream_t stream) {
+    if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
+    if (!(fx > 0.0f) || !(fy > 0.0f) || ksize < 1 || box2i_is_empty(&source->current_window) || box2i_is_empty(&target->full_window)) {
+        box2i_set_empty(&target->current_window);
+        return 0;
+    }
+    hipStream_t s = cvs_pick_stream(stream);
+    const box2i *sw = &source->current_window, *tf = &target->full_window;
+    rgba_frame_f32 mid;
+    box2i_set(&mid.full_window, tf->min.x, sw->min.y, tf->max.x, sw->max.y);
+    mid.current_window = mid.full_window;
+    mid.data = cvs_malloc(cvs_box_pixels(&mid.full_window) * sizeof(rgba_f32));
+    if (!mid.data) { box2i_set_empty(&target->current_window); return -1; }
+    const int lo_y = sw->min.y, hi_y = sw->max.y;
+    tap_table tb;
+    int rc = plan_lanczos(&tb, tf->min.x, tf->max.x, sw->min.x, sw->max.x, fx, ksize);
+    if (rc == 0) rc = run_table(&tb, cvs_view(mid.data, &mid.full_window), cvs_view(source->data, &source->full_window), 1, lo_y, hi_y, s);
+    table_free(&tb);
+    const int lo_x = tf->min.x, hi_x = tf->max.x;
+    if (rc == 0) rc = plan_lanczos(&tb, tf->min.y, tf->max.y, sw->min.y, sw->max.y, fy, ksize);
+    if (rc == 0) { rc = run_table(&tb, cvs_view(target->data, &target->full_window), cvs_view(mid.data, &mid.full_window), 0, lo_x, hi_x, s); table_free(&tb); }
+    cvs_free(mid.data);
+    if (rc == 0) target->current_window = *tf;
+    else box2i_set_empty(&target->current_window);
+    return rc;
+}

@@ -1,0 +1,89 @@
+/*
+ * kernels.h -- internal seam between the host C code (csrc/host) and the HIP kernels
+ * (the .hip files next to this header).  Plain C types only; every launcher enqueues on `stream` and returns a
+ * hipError_t as int (0 = ok).  Host code has already done all window arithmetic: the kernels
+ * get explicit rectangles and never look at box2i / current_window.
+ */
+#ifndef CVS_KERNELS_H
+#define CVS_KERNELS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* a frame buffer as the kernels see it: base pointer + the full window it covers */
+typedef struct {
+    void *data;          /* device pointer to pixel (fx0, fy0) */
+    int pitch;           /* pixels per row = fx1 - fx0 + 1 */
+    int fx0, fy0, fx1, fy1;
+} cvk_view;
+
+typedef struct { int x0, y0, x1, y1; } cvk_rect;     /* inclusive */
+
+/* flat arrays */
+int cvk_half_to_float(float *out, const uint16_t *in, size_t count, int fast, void *stream);
+int cvk_float_to_half(uint16_t *out, const float *in, size_t count, int fast, void *stream);
+int cvk_half_lookup(const uint16_t *table, uint16_t *out, const uint16_t *in, size_t count, int cus, void *stream);
+
+/* windowed frame ops; rect must lie inside every view involved */
+int cvk_copy_f16(cvk_view out, cvk_view in, cvk_rect r, void *stream);
+int cvk_copy_alpha_f32(cvk_view out, cvk_view in, cvk_rect r, float alpha, void *stream);
+int cvk_widen(cvk_view out32, cvk_view in16, cvk_rect r, void *stream);
+int cvk_narrow(cvk_view out16, cvk_view in32, cvk_rect r, void *stream);
+int cvk_fill_f16(cvk_view out, cvk_rect r, uint64_t pixel_bits, void *stream);
+int cvk_fill_f32(cvk_view out, cvk_rect r, const float rgba[4], void *stream);
+int cvk_gain_offset_f16(cvk_view out, cvk_view in, cvk_rect r, float gain, float offset, void *stream);
+
+/* two-input mixers (video_mix.c region walk, decided on the host) */
+enum { CVK_MIX_CROSS = 0, CVK_MIX_OVER = 1 };
+typedef struct {
+    cvk_view out, p, q;            /* for OVER p aliases out */
+    cvk_rect outer, inner;         /* inner already normalised (gap form when empty) */
+    cvk_rect pw, qw;               /* current windows of p and q */
+    int gap_x, gap_y;
+    int top_is_p, bottom_is_p, left_is_p, right_is_p;
+    float wp, wq;                  /* alpha weights of lone pixels / blend mixes */
+    int mode;                      /* CVK_MIX_* */
+    int p_in_place;                /* p's own pixels are already in out: leave them */
+} cvk_mix_params;
+int cvk_mix(const cvk_mix_params *mp, void *stream);
+
+/* colour matrix on an f16 frame, in place, color.c structure; LUT pointers are device tables or NULL */
+int cvk_color_matrix(cvk_view frame, cvk_rect r, const float m[9], const uint16_t *pre_lut,
+                     const uint16_t *post_lut, int cus, void *stream);
+
+/* fused colour + over chain; `jobs` is a HOST array (records are passed as kernel arguments,
+ * 32 per launch); the buffers they point to are in HBM */
+#define CVK_CHAIN_MAX_LAYERS 8
+typedef struct {
+    void *out;                               /* rgba_f16 device buffer, npixels long */
+    const void *layer[CVK_CHAIN_MAX_LAYERS]; /* rgba_f16 device buffers, bottom first */
+    int nlayers;
+    int pad;
+    uint64_t npixels;
+} cvk_chain_job;
+int cvk_chain_color_over(const cvk_chain_job *jobs, int njobs, int uniform_layers, const float m[9],
+                         const uint16_t *pre_lut, const uint16_t *post_lut, int cus, void *stream);
+
+/* separable FIR passes (video_scale.c structure) */
+typedef struct {
+    cvk_view target, source;
+    int axis;                 /* 0: resample along y, 1: along x */
+    int t0, t1;               /* target lines to produce along the axis */
+    int lo, hi;               /* span on the other axis */
+    int s0, s1;               /* valid source lines along the axis (taps outside are skipped) */
+    const int *ntaps;         /* device: per target line, tap count */
+    const int *tap_src;       /* device: per target line, `stride` source line indices, ascending */
+    const float *taps;        /* device: per target line, `stride` coefficients */
+    int stride;
+} cvk_fir_params;
+int cvk_fir_gather(const cvk_fir_params *fp, void *stream);
+int cvk_zero_f32(cvk_view v, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,98 @@
+// pixel_math.hpp -- per-channel arithmetic shared by every kernel of the path (gfx950 only).
+//
+// The reference converts through lookup tables (src/cprocess/half.c:31-51, genhalf.py); here the
+// same mappings come from two CDNA4 instructions plus one fix-up:
+//   h2f : v_cvt_f32_f16          -- exact for all 65536 codes (signalling NaNs come out quiet)
+//   f2h : v_cvt_pkrtz_f16_f32    -- round toward zero, subnormals included, which is what
+//                                   `base + (mantissa >> shift)` computes; the one difference is
+//                                   finite overflow: RTZ saturates at 65504 where the table gives
+//                                   +-Inf for |x| >= 65536 (genhalf.py:36-37), fixed below.
+// All f32 arithmetic is written as separate mul / add / div (the translation unit is built with
+// -ffp-contract=off) to match the reference's gcc -std=c99 build, which does not fuse.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cvs {
+
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float h2f(uint32_t code) {
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)code);
+}
+
+// |x| >= 65536 must become +-Inf.  (x * 2^112) overflows to Inf exactly for those x and is an
+// exact scaling otherwise; multiplying back by 2^-112 restores every other value bit for bit
+// (f32 denormals are kept on gfx950), and NaN stays NaN.
+__device__ __forceinline__ float saturate_to_inf(float x) {
+    return (x * 0x1p112f) * 0x1p-112f;
+}
+
+// two channels -> one dword of two truncated halfs (lo = a, hi = b)
+__device__ __forceinline__ uint32_t f2h_rz2(float a, float b) {
+    auto v = __builtin_amdgcn_cvt_pkrtz(saturate_to_inf(a), saturate_to_inf(b));
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ __forceinline__ uint32_t f2h_rz(float a) { return f2h_rz2(a, 0.0f) & 0xFFFFu; }
+
+// bit-twiddled variants the reference also exports (half.c:39-45, 53-59); only exact for normals
+__device__ __forceinline__ float h2f_fast(uint32_t v) {
+    return __uint_as_float(((v & 0x8000u) << 16) | (((v & 0x7c00u) + 0x1C000u) << 13) | ((v & 0x03FFu) << 13));
+}
+__device__ __forceinline__ uint32_t f2h_fast(float f) {
+    uint32_t u = __float_as_uint(f);
+    return ((u >> 16) & 0x8000u) | ((((u & 0x7f800000u) - 0x38000000u) >> 13) & 0x7c00u) | ((u >> 13) & 0x03ffu);
+}
+
+struct px32 { float r, g, b, a; };
+
+// one rgba_f16 pixel = two dwords: lo = g:r, hi = a:b
+__device__ __forceinline__ px32 widen(uint2 p) {
+    return { h2f(p.x & 0xFFFFu), h2f(p.x >> 16), h2f(p.y & 0xFFFFu), h2f(p.y >> 16) };
+}
+__device__ __forceinline__ uint2 narrow(px32 v) {
+    return make_uint2(f2h_rz2(v.r, v.g), f2h_rz2(v.b, v.a));
+}
+
+// color.c:34-42 -- left-to-right, alpha copied.  m is column-major (see canvas_hip.h).
+__device__ __forceinline__ px32 mat3(px32 v, const float *m) {
+    px32 o;
+    o.r = v.r * m[0] + v.g * m[3] + v.b * m[6];
+    o.g = v.r * m[1] + v.g * m[4] + v.b * m[7];
+    o.b = v.r * m[2] + v.g * m[5] + v.b * m[8];
+    o.a = v.a;
+    return o;
+}
+
+// video_mix.c:323-337
+__device__ __forceinline__ px32 blend_over(px32 lo, px32 b, float mix_b) {
+    float alpha_b = b.a * mix_b;
+    float alpha_a = lo.a * (1.0f - b.a * mix_b);
+    float a = alpha_a + alpha_b;
+    px32 o = { 0.0f, 0.0f, 0.0f, 0.0f };
+    if (a != 0.0f) {
+        o.r = (lo.r * alpha_a + b.r * alpha_b) / a;
+        o.g = (lo.g * alpha_a + b.g * alpha_b) / a;
+        o.b = (lo.b * alpha_a + b.b * alpha_b) / a;
+        o.a = a;
+    }
+    return o;
+}
+
+// video_mix.c:193-205
+__device__ __forceinline__ px32 blend_cross(px32 a, px32 b, float mix_a, float mix_b) {
+    float alpha_a = a.a * mix_a;
+    float alpha_b = b.a * mix_b;
+    float oa = alpha_a + alpha_b;
+    px32 o = { 0.0f, 0.0f, 0.0f, 0.0f };
+    if (oa != 0.0f) {
+        o.r = (a.r * alpha_a + b.r * alpha_b) / oa;
+        o.g = (a.g * alpha_a + b.g * alpha_b) / oa;
+        o.b = (a.b * alpha_a + b.b * alpha_b) / oa;
+        o.a = oa;
+    }
+    return o;
+}
+
+}  // namespace cvs

@@ -1,0 +1,296 @@
+/*
+ * canvas_hip.h -- C-ABI of the MI355X (gfx950) implementation of Canvas's per-pixel video path.
+ *
+ * One shared library, libcanvas_hip.so, exports
+ *   (1) the symbol set of the reference's src/cprocess for this path, with the same names,
+ *       argument meaning and error behaviour, working on HOST frames (each call stages the
+ *       frames to HBM, runs the HIP kernels, and copies the result back: drop-in, PCIe-bound);
+ *   (2) `cvs_*_dev` twins of the same operations on frames that already live in HBM
+ *       (frame->data is a device pointer), taking a stream: zero-copy, what bench.py measures;
+ *   (3) the fused colour-matrix + alpha-over chain, single and batched.
+ * There is no CPU implementation behind any of these: without a HIP device every pixel entry
+ * point fails (empty current_window / non-zero status, message in cvs_last_error()).
+ *
+ * Struct layouts, field order and names are those of the reference's include/framework.h so
+ * that code compiled against it keeps working:
+ *   rational, v2i, box2i, v2f, box2f ........ framework.h:46-75
+ *   box2i_* / min / max / clamp helpers ..... framework.h:77-149
+ *   rgba_f16, rgba_u8, rgba_f32, frames ..... framework.h:155-177
+ *   video_frame_source_funcs, video_source .. framework.h:185-194, 210-213
+ *   fir_filter .............................. framework.h:618-627
+ * GL types are gone: slot 3 of the vtable (get_frame_gl, framework.h:193) keeps its position
+ * and becomes the device-frame entry, announced by VIDEO_SOURCE_FLAG_DEVICE in `flags`
+ * (framework.h:190 reserves that word).
+ */
+#ifndef CANVAS_HIP_H
+#define CANVAS_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdbool.h>
+
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+#define CVS_EXPORT __attribute__((visibility("default")))
+#define NS_PER_SEC INT64_C(1000000000)
+
+/* ------------------------------------------------------------------ value types */
+
+typedef uint16_t half;                 /* include/half.h:26 */
+#define HALF_COUNT 65536
+
+typedef struct { int32_t n; uint32_t d; } rational;
+typedef struct { int32_t x, y; } v2i;
+typedef struct { v2i min, max; } box2i;        /* inclusive; empty when max < min on either axis */
+typedef struct { float x, y; } v2f;
+typedef struct { v2f min, max; } box2f;
+
+typedef struct { half r, g, b, a; } rgba_f16;  /* 8 bytes, channel order r,g,b,a */
+typedef struct { uint8_t r, g, b, a; } rgba_u8;
+typedef struct { float r, g, b, a; } rgba_f32; /* 16 bytes */
+
+/* A frame is a caller-owned buffer covering full_window (rows packed, stride = its width);
+ * the callee fills some sub-rectangle and reports it in current_window.  Pixels outside
+ * current_window are undefined. */
+typedef struct { rgba_f16 *data; box2i full_window; box2i current_window; } rgba_frame_f16;
+typedef struct { rgba_f32 *data; box2i full_window; box2i current_window; } rgba_frame_f32;
+
+/* Device-resident frame handed through vtable slot 3. */
+enum { CVS_FORMAT_F16 = 1, CVS_FORMAT_F32 = 2 };
+typedef struct {
+    void *data;            /* device pointer, layout as the host frame of `format` */
+    int format;            /* set by the caller: which layout `data` has room for */
+    box2i full_window;
+    box2i current_window;
+    void *stream;          /* hipStream_t the callee must enqueue on (NULL = the library's stream) */
+} rgba_frame_dev;
+
+typedef void (*video_get_frame_func)(void *self, int frame_index, rgba_frame_f16 *frame);
+typedef void (*video_get_frame_32_func)(void *self, int frame_index, rgba_frame_f32 *frame);
+typedef void (*video_get_frame_dev_func)(void *self, int frame_index, rgba_frame_dev *frame);
+
+#define VIDEO_SOURCE_FLAG_DEVICE 0x1   /* slot 3 is a device-frame entry */
+
+typedef struct {
+    int flags;
+    video_get_frame_func get_frame;
+    video_get_frame_32_func get_frame_32;
+    video_get_frame_dev_func get_frame_dev;     /* was get_frame_gl */
+} video_frame_source_funcs;
+
+typedef struct { void *obj; video_frame_source_funcs *funcs; } video_source;
+
+typedef struct { float *coeff; int width; int center; } fir_filter;
+
+/* ------------------------------------------------------------------ inline helpers (framework.h:55-149,196-208) */
+
+static inline void v2i_add(v2i *r, const v2i *a, const v2i *b) { r->x = a->x + b->x; r->y = a->y + b->y; }
+static inline void v2i_subtract(v2i *r, const v2i *a, const v2i *b) { r->x = a->x - b->x; r->y = a->y - b->y; }
+
+#if !defined(__cplusplus)
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
+static inline int clamp(int v, int lo, int hi) { return min(max(v, lo), hi); }
+#endif
+static inline float minf(float a, float b) { return a < b ? a : b; }
+static inline float maxf(float a, float b) { return a > b ? a : b; }
+static inline float clampf(float v, float lo, float hi) { return minf(maxf(v, lo), hi); }
+
+static inline void box2i_set(box2i *b, int x0, int y0, int x1, int y1) { b->min.x = x0; b->min.y = y0; b->max.x = x1; b->max.y = y1; }
+static inline void box2i_set_empty(box2i *b) { box2i_set(b, 0, 0, -1, -1); }
+static inline bool box2i_is_empty(const box2i *b) { return b->max.x < b->min.x || b->max.y < b->min.y; }
+static inline void box2i_intersect(box2i *r, const box2i *a, const box2i *b) {
+    int x0 = a->min.x > b->min.x ? a->min.x : b->min.x, y0 = a->min.y > b->min.y ? a->min.y : b->min.y;
+    int x1 = a->max.x < b->max.x ? a->max.x : b->max.x, y1 = a->max.y < b->max.y ? a->max.y : b->max.y;
+    box2i_set(r, x0, y0, x1, y1);
+}
+static inline void box2i_union(box2i *r, const box2i *a, const box2i *b) {
+    int x0 = a->min.x < b->min.x ? a->min.x : b->min.x, y0 = a->min.y < b->min.y ? a->min.y : b->min.y;
+    int x1 = a->max.x > b->max.x ? a->max.x : b->max.x, y1 = a->max.y > b->max.y ? a->max.y : b->max.y;
+    box2i_set(r, x0, y0, x1, y1);
+}
+/* an inverted axis is turned into the gap between the two spans it came from */
+static inline void box2i_normalize(box2i *b) {
+    if (b->min.x > b->max.x) { int32_t t = b->min.x - 1; b->min.x = b->max.x + 1; b->max.x = t; }
+    if (b->min.y > b->max.y) { int32_t t = b->min.y - 1; b->min.y = b->max.y + 1; b->max.y = t; }
+}
+static inline void box2i_get_size(const box2i *b, v2i *r) {
+    r->x = b->max.x < b->min.x ? 0 : b->max.x - b->min.x + 1;
+    r->y = b->max.y < b->min.y ? 0 : b->max.y - b->min.y + 1;
+}
+static inline rgba_f16 *video_get_pixel_f16(rgba_frame_f16 *f, int x, int y) {
+    return &f->data[(ptrdiff_t)(y - f->full_window.min.y) * (f->full_window.max.x - f->full_window.min.x + 1) + x - f->full_window.min.x];
+}
+static inline rgba_f32 *video_get_pixel_f32(rgba_frame_f32 *f, int x, int y) {
+    return &f->data[(ptrdiff_t)(y - f->full_window.min.y) * (f->full_window.max.x - f->full_window.min.x + 1) + x - f->full_window.min.x];
+}
+
+/* ------------------------------------------------------------------ (1) reference symbol set, HOST frames
+ * Each entry names the reference definition it replaces. */
+
+/* src/cprocess/half.c:87-105 -- function-pointer globals, valid after init_half() */
+CVS_EXPORT void init_half(void);
+CVS_EXPORT extern void (*half_convert_from_float)(half *out, const float *in, int count);       /* truncating, half.c:47-51 */
+CVS_EXPORT extern void (*half_convert_to_float)(float *out, const half *in, int count);         /* exact, half.c:31-37 */
+CVS_EXPORT extern void (*half_convert_from_float_fast)(half *out, const float *in, int count);  /* half.c:53-59 */
+CVS_EXPORT extern void (*half_convert_to_float_fast)(float *out, const half *in, int count);    /* half.c:39-45 */
+CVS_EXPORT extern void (*half_lookup)(const half *table, half *out, const half *in, int count); /* half.c:82-85 */
+
+static inline void rgba_f32_to_f16(rgba_f16 *out, const rgba_f32 *in, int count) { half_convert_from_float(&out->r, &in->r, count * 4); }
+static inline void rgba_f16_to_f32(rgba_f32 *out, const rgba_f16 *in, int count) { half_convert_to_float(&out->r, &in->r, count * 4); }
+
+/* src/cprocess/main.c:23-31 */
+CVS_EXPORT int64_t get_frame_time(const rational *frame_rate, int frame);
+CVS_EXPORT int get_time_frame(const rational *frame_rate, int64_t time);
+/* src/cprocess/clock.c:28-52 */
+CVS_EXPORT int64_t gettime(void);
+
+/* src/cprocess/main.c:33-76,105-144 -- vtable dispatch + format conversion; NULL source => empty window */
+CVS_EXPORT void video_get_frame_f16(video_source *source, int frame_index, rgba_frame_f16 *frame);
+CVS_EXPORT void video_get_frame_f32(video_source *source, int frame_index, rgba_frame_f32 *frame);
+/* device twin: fills a device frame through slot 3 when the source has one, else pulls a host
+ * frame and uploads it */
+CVS_EXPORT void video_get_frame_dev(video_source *source, int frame_index, rgba_frame_dev *frame);
+
+/* src/cprocess/video_mix.c:27-44, 73-105, 107-235, 46-71, 237-370 */
+CVS_EXPORT void video_copy_frame_f16(rgba_frame_f16 *out, rgba_frame_f16 *in);
+CVS_EXPORT void video_copy_frame_alpha_f32(rgba_frame_f32 *out, rgba_frame_f32 *in, float alpha);
+CVS_EXPORT void video_mix_cross_f32(rgba_frame_f32 *out, rgba_frame_f32 *a, rgba_frame_f32 *b, float mix_b);
+CVS_EXPORT void video_mix_cross_f32_pull(rgba_frame_f32 *out, video_source *a, int frame_a, video_source *b, int frame_b, float mix_b);
+CVS_EXPORT void video_mix_over_f32(rgba_frame_f32 *out, rgba_frame_f32 *b, float mix_b);
+
+/* src/cprocess/video_scale.c:231-286, 288-319 */
+CVS_EXPORT void video_scale_bilinear_f32(rgba_frame_f32 *target, v2f target_point, rgba_frame_f32 *source, v2f source_point, v2f factors);
+CVS_EXPORT void video_scale_bilinear_f32_pull(rgba_frame_f32 *target, v2f target_point, video_source *source, int frame,
+                                              box2i *source_rect, v2f source_point, v2f factors);
+
+/* src/cprocess/gammatab.c:83-110, 128-159, 171-198, 223-250, 13-38 */
+CVS_EXPORT void video_transfer_rec709_to_linear_scene(half *out, const half *in, size_t count);
+CVS_EXPORT void video_transfer_rec709_to_linear_display(half *out, const half *in, size_t count);
+CVS_EXPORT void video_transfer_linear_to_rec709(half *out, const half *in, size_t count);
+CVS_EXPORT void video_transfer_linear_to_sRGB(half *out, const half *in, size_t count);
+CVS_EXPORT const uint8_t *video_get_gamma45_ramp(void);
+
+/* src/cprocess/color.c:104-137, 140-165 (exported there, missing from framework.h) */
+CVS_EXPORT void video_color_rgb_to_xyz_sdtv(rgba_frame_f16 *frame);
+CVS_EXPORT void video_color_xyz_to_srgb(rgba_frame_f16 *frame);
+
+/* src/cprocess/filter.c:24-76, 78-148, 150-153 */
+CVS_EXPORT void filter_createTriangle(float sub, float offset, fir_filter *filter);
+CVS_EXPORT void filter_createLanczos(float sub, int kernel_size, float offset, fir_filter *filter);
+CVS_EXPORT void filter_free(fir_filter *filter);
+
+/* src/cprocess/video_filter.c:27-39 + src/cprocess/gl.c:584 -- the reference only has this as a
+ * GLSL program (video_filter_gain_offset_gl); same formula and window rule, f16 frames */
+CVS_EXPORT void video_filter_gain_offset_f16(rgba_frame_f16 *out, rgba_frame_f16 *in, float gain, float offset);
+
+/* src/process/SolidColorVideoSource.c:52-101 (the fill loops; parameter fetch stays with the caller) */
+CVS_EXPORT void video_fill_solid_f16(rgba_frame_f16 *frame, const box2i *window, const rgba_f32 *color);
+CVS_EXPORT void video_fill_solid_f32(rgba_frame_f32 *frame, const box2i *window, const rgba_f32 *color);
+
+/* src/cprocess/workspace.c (video half): item bookkeeping :107-492, stack :494-550, source :604-613 */
+typedef struct workspace_t_tag workspace_t;
+typedef struct workspace_item_t_tag workspace_item_t;
+CVS_EXPORT workspace_t *workspace_create(void);
+CVS_EXPORT int workspace_get_length(workspace_t *workspace);
+CVS_EXPORT workspace_item_t *workspace_add_item(workspace_t *self, void *source, int64_t x, int64_t width, int64_t offset, int64_t z, void *tag);
+CVS_EXPORT workspace_item_t *workspace_get_item(workspace_t *self, int index);
+CVS_EXPORT void workspace_remove_item(workspace_item_t *item);
+CVS_EXPORT void workspace_as_video_source(workspace_t *workspace, video_source *source);
+CVS_EXPORT void workspace_free(workspace_t *workspace);
+CVS_EXPORT void workspace_get_item_pos(workspace_item_t *item, int64_t *x, int64_t *width, int64_t *z);
+CVS_EXPORT int64_t workspace_get_item_offset(workspace_item_t *item);
+CVS_EXPORT void workspace_set_item_offset(workspace_item_t *item, int64_t offset);
+CVS_EXPORT void *workspace_get_item_source(workspace_item_t *item);
+CVS_EXPORT void workspace_set_item_source(workspace_item_t *item, void *source);
+CVS_EXPORT void *workspace_get_item_tag(workspace_item_t *item);
+CVS_EXPORT void workspace_set_item_tag(workspace_item_t *item, void *tag);
+CVS_EXPORT void workspace_update_item(workspace_item_t *item, int64_t *x, int64_t *width, int64_t *z, int64_t *offset, void **source, void **tag);
+
+/* ------------------------------------------------------------------ (2) device runtime + device-frame twins */
+
+typedef void *cvs_stream_t;            /* hipStream_t */
+
+enum { CVS_LUT_NONE = -1, CVS_LUT_REC709_TO_LINEAR_SCENE = 0, CVS_LUT_REC709_TO_LINEAR_DISPLAY = 1,
+       CVS_LUT_LINEAR_TO_REC709 = 2, CVS_LUT_LINEAR_TO_SRGB = 3, CVS_LUT_COUNT = 4 };
+
+CVS_EXPORT int cvs_init(int device);                   /* 0 on success; idempotent per device */
+CVS_EXPORT int cvs_device_count(void);
+CVS_EXPORT int cvs_current_device(void);
+CVS_EXPORT const char *cvs_last_error(void);           /* thread-local, "" when none */
+CVS_EXPORT const char *cvs_device_name(void);
+CVS_EXPORT int cvs_compute_units(void);
+
+CVS_EXPORT void *cvs_malloc(size_t bytes);
+CVS_EXPORT void cvs_free(void *dev);
+CVS_EXPORT int cvs_memcpy_h2d(void *dev, const void *host, size_t bytes, cvs_stream_t s);
+CVS_EXPORT int cvs_memcpy_d2h(void *host, const void *dev, size_t bytes, cvs_stream_t s);
+CVS_EXPORT int cvs_memcpy_d2d(void *dst, const void *src, size_t bytes, cvs_stream_t s);
+CVS_EXPORT int cvs_memset(void *dev, int value, size_t bytes, cvs_stream_t s);
+CVS_EXPORT cvs_stream_t cvs_stream_create(void);
+CVS_EXPORT void cvs_stream_destroy(cvs_stream_t s);
+CVS_EXPORT int cvs_stream_sync(cvs_stream_t s);
+/* HIP events on a stream, for callers that time kernels without linking HIP themselves */
+typedef void *cvs_event_t;
+CVS_EXPORT cvs_event_t cvs_event_create(void);
+CVS_EXPORT void cvs_event_destroy(cvs_event_t e);
+CVS_EXPORT int cvs_event_record(cvs_event_t e, cvs_stream_t s);
+CVS_EXPORT int cvs_event_sync(cvs_event_t e);
+CVS_EXPORT float cvs_event_elapsed_ms(cvs_event_t start, cvs_event_t stop);   /* < 0 on error */
+
+/* the four transfer tables, resident in HBM after first use (128 KiB each); host copy for callers
+ * that want to ship them elsewhere (multi-GPU parameter broadcast) */
+CVS_EXPORT const half *cvs_lut_device(int which);
+CVS_EXPORT const half *cvs_lut_host(int which);
+/* install a table built elsewhere (rank 0 broadcasts, the others install); 65536 entries */
+CVS_EXPORT int cvs_lut_install(int which, const half *table_host);
+
+/* flat arrays in HBM */
+CVS_EXPORT int cvs_half_to_float_dev(float *out, const half *in, size_t count, cvs_stream_t s);
+CVS_EXPORT int cvs_float_to_half_dev(half *out, const float *in, size_t count, cvs_stream_t s);
+CVS_EXPORT int cvs_half_to_float_fast_dev(float *out, const half *in, size_t count, cvs_stream_t s);
+CVS_EXPORT int cvs_float_to_half_fast_dev(half *out, const float *in, size_t count, cvs_stream_t s);
+CVS_EXPORT int cvs_half_lookup_dev(const half *table_dev, half *out, const half *in, size_t count, cvs_stream_t s);
+
+/* frames in HBM (frame->data is a device pointer); window logic runs on the host exactly as in
+ * the reference and the structs are updated before the call returns; pixels are enqueued on `s` */
+CVS_EXPORT int cvs_frame_f16_to_f32_dev(rgba_frame_f32 *out, const rgba_frame_f16 *in, cvs_stream_t s);   /* main.c:115-139 */
+CVS_EXPORT int cvs_frame_f32_to_f16_dev(rgba_frame_f16 *out, const rgba_frame_f32 *in, cvs_stream_t s);   /* main.c:43-71 */
+CVS_EXPORT int cvs_copy_frame_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *in, cvs_stream_t s);
+CVS_EXPORT int cvs_copy_frame_alpha_f32_dev(rgba_frame_f32 *out, const rgba_frame_f32 *in, float alpha, cvs_stream_t s);
+CVS_EXPORT int cvs_mix_cross_f32_dev(rgba_frame_f32 *out, const rgba_frame_f32 *a, const rgba_frame_f32 *b, float mix_b, cvs_stream_t s);
+CVS_EXPORT int cvs_mix_over_f32_dev(rgba_frame_f32 *out, const rgba_frame_f32 *b, float mix_b, cvs_stream_t s);
+/* colour matrix with the color.c structure; m is column-major as color.c passes it:
+ * m[0..2] = coefficients multiplying r (a.x a.y a.z), m[3..5] those of g, m[6..8] those of b */
+CVS_EXPORT int cvs_color_matrix_f16_dev(rgba_frame_f16 *frame, const float m[9], int pre_lut, int post_lut, cvs_stream_t s);
+CVS_EXPORT int cvs_gain_offset_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *in, float gain, float offset, cvs_stream_t s);
+CVS_EXPORT int cvs_fill_solid_f16_dev(rgba_frame_f16 *frame, const box2i *window, const rgba_f32 *color, cvs_stream_t s);
+CVS_EXPORT int cvs_fill_solid_f32_dev(rgba_frame_f32 *frame, const box2i *window, const rgba_f32 *color, cvs_stream_t s);
+CVS_EXPORT int cvs_scale_bilinear_f32_dev(rgba_frame_f32 *target, v2f target_point, const rgba_frame_f32 *source, v2f source_point, v2f factors, cvs_stream_t s);
+/* separable FIR blur at factor 1 (absent from the reference; defined in DESIGN.md) and the Lanczos
+ * gather resampler built on filter_createLanczos */
+CVS_EXPORT int cvs_fir_blur_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, const float *taps_host, int ntaps, cvs_stream_t s);
+CVS_EXPORT int cvs_resample_lanczos_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, float factor_x, float factor_y, int kernel_size, cvs_stream_t s);
+
+/* ------------------------------------------------------------------ (3) fused chain: BASELINE config 2
+ * out = f16( over-stack_{k=0..n-1}( f32( colour(layer_k) ) ) ), i.e. what the reference computes with
+ * color.c on every layer, workspace.c:530-544 over the layers bottom-to-top and main.c:43-71 on the
+ * result -- in ONE kernel: 8 B read per layer pixel, 8 B written per output pixel. */
+#define CVS_CHAIN_MAX_LAYERS 8
+typedef struct {
+    rgba_frame_f16 *out;                               /* device frame; current_window is set */
+    const rgba_frame_f16 *layers[CVS_CHAIN_MAX_LAYERS];/* device frames, bottom first */
+    int nlayers;
+} cvs_chain_job;
+CVS_EXPORT int cvs_chain_color_over_f16_dev(const cvs_chain_job *jobs, int njobs, const float m[9],
+                                            int pre_lut, int post_lut, cvs_stream_t s);
+/* how the last chain call ran: 1 = single fused kernel, 0 = node-by-node device kernels
+ * (windows did not all cover the output's full window) */
+CVS_EXPORT int cvs_chain_last_was_fused(void);
+
+#if defined(__cplusplus)
+}
+#endif
+#endif

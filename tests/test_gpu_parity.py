@@ -1,0 +1,658 @@
+"""GPU parity: every entry point of libcanvas_hip.so, called through the C-ABI, against the CPU
+oracle on the same seeded inputs.  Bar: bit-exact (sign of zero and NaN payload aside, see
+tests/util.py) -- tighter than the 1-ulp-in-half bar BASELINE.md allows.
+
+Run on the GPU box with `pytest -m gpu`.  Nothing here reads /root/reference.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from canvas_amd import REC709_RGB_TO_YPBPR, _lib, synth
+from canvas_amd.abi import (GET_FRAME_F16, GET_FRAME_F32, HostFrame, box2i, fir_filter, v2f,
+                            video_frame_source_funcs, video_source)
+from canvas_amd.device import DeviceFrame, chain_color_over
+from tests.util import (assert_same_f16, assert_same_f32, f32p, rand_f16_frame, rand_f32_frame, same_window, u16p)
+
+pytestmark = pytest.mark.gpu
+
+ALL_CODES = np.arange(65536, dtype=np.uint16)
+
+
+@pytest.fixture(scope="module")
+def cvs():
+    lib = _lib.load()
+    assert lib.cvs_init(0) == 0, _lib.last_error()
+    lib.init_half()
+    return lib
+
+
+# ------------------------------------------------------------------ A1-A3 half.c
+
+def _host_h2f(codes, name="half_convert_to_float"):
+    out = np.empty(codes.shape, np.float32)
+    _lib.half_pointer(name)(f32p(out), u16p(codes), codes.size)
+    return out
+
+
+def _host_f2h(values, name="half_convert_from_float"):
+    out = np.empty(values.shape, np.uint16)
+    _lib.half_pointer(name)(u16p(out), f32p(values), values.size)
+    return out
+
+
+def test_half_pointers_null_until_init():
+    # half.c:87-91: the globals are plain pointers that init_half() fills in
+    lib = _lib.load()
+    lib.init_half()
+    for name in _lib.HALF_POINTER_GLOBALS:
+        assert _lib.half_pointer(name) is not None
+
+
+def test_h2f_every_code(cvs, orc):
+    got, want = _host_h2f(ALL_CODES), orc.half_to_float(ALL_CODES)
+    assert_same_f32(got, want, "h2f")
+    # values, not just canonical form: everything that is not a NaN must match bit for bit
+    nn = ~np.isnan(want)
+    assert np.array_equal(got[nn].view(np.uint32), want[nn].view(np.uint32))
+
+
+def test_f2h_probe_set(cvs, orc):
+    rng = np.random.default_rng(7)
+    probes = [
+        rng.uniform(-4, 4, 300001).astype(np.float32),                     # ragged length: vector body + tail
+        rng.uniform(-70000, 70000, 50000).astype(np.float32),
+        (rng.uniform(-1, 1, 50000) * 2.0 ** rng.integers(-30, -10, 50000)).astype(np.float32),
+        orc.half_to_float(ALL_CODES[(ALL_CODES & 0x7C00) != 0x7C00]),      # every finite half is a fixed point
+        np.array([0.0, -0.0, 65504.0, 65519.9, 65520.0, 65535.9, 65536.0, -65536.0, 1e30, -1e30, np.inf, -np.inf,
+                  2.0 ** -24, 2.0 ** -25, 1.5 * 2.0 ** -24, 2.0 ** -14, 2.0 ** -14 * (1 - 2.0 ** -11), 1e-45, -1e-45], np.float32),
+    ]
+    bits = rng.integers(0, 2 ** 32, 400000, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    probes.append(bits[~np.isnan(bits)])                                   # every exponent class, both signs
+    for i, p in enumerate(probes):
+        got, want = _host_f2h(p), orc.float_to_half(p)
+        assert np.array_equal(got, want), "probe set %d" % i
+
+
+def test_f2h_nan_stays_nan_or_matches(cvs, orc):
+    # NaN payload/sign is not pinned (x86 vs gfx950 default NaN); the table turns low-payload NaNs into Inf
+    p = np.array([0x7FC00000, 0xFFC00000, 0x7F800001, 0x7F802000, 0x7FFFFFFF], np.uint32).view(np.float32)
+    got, want = _host_f2h(p), orc.float_to_half(p)
+    for g, w in zip(got, want):
+        assert g == w or (g & 0x7FFF) > 0x7C00
+
+
+def test_round_trip_is_identity_on_all_finite_codes(cvs):
+    finite = ALL_CODES[(ALL_CODES & 0x7C00) != 0x7C00]
+    assert np.array_equal(_host_f2h(_host_h2f(finite)), finite)
+
+
+def test_fast_variants(cvs, orc):
+    normal = ALL_CODES[((ALL_CODES >> 10) & 0x1F != 0) & ((ALL_CODES >> 10) & 0x1F != 31)]
+    f = _host_h2f(normal, "half_convert_to_float_fast")
+    assert np.array_equal(f.view(np.uint32), orc.half_to_float(normal).view(np.uint32))
+    assert np.array_equal(_host_f2h(f, "half_convert_from_float_fast"), normal)
+
+
+@pytest.mark.parametrize("count", [1, 7, 8, 1000, 65536 * 3 + 5])
+def test_half_lookup(cvs, orc, count):
+    rng = np.random.default_rng(count)
+    table = rng.integers(0, 65536, 65536).astype(np.uint16)
+    codes = rng.integers(0, 65536, count).astype(np.uint16)
+    out = np.empty_like(codes)
+    _lib.half_pointer("half_lookup")(u16p(table), u16p(out), u16p(codes), count)
+    assert np.array_equal(out, table[codes])
+
+
+def test_flat_dev_entry_points_with_unaligned_buffers(cvs, orc):
+    rng = np.random.default_rng(3)
+    n = 4099
+    codes = rng.integers(0, 0x7C00, n + 3).astype(np.uint16)
+    d_in, d_out = cvs.cvs_malloc(2 * (n + 3)), cvs.cvs_malloc(4 * (n + 4))
+    _lib.check(cvs.cvs_memcpy_h2d(d_in, codes.ctypes.data, codes.nbytes, None))
+    _lib.check(cvs.cvs_half_to_float_dev(d_out + 4, d_in + 6, n, None))      # both 16-byte misaligned
+    out = np.empty(n, np.float32)
+    _lib.check(cvs.cvs_memcpy_d2h(out.ctypes.data, d_out + 4, 4 * n, None))
+    assert np.array_equal(out.view(np.uint32), orc.half_to_float(codes[3:3 + n]).view(np.uint32))
+    cvs.cvs_free(d_in), cvs.cvs_free(d_out)
+
+
+# ------------------------------------------------------------------ A13 gammatab.c
+
+@pytest.mark.parametrize("which", [0, 1, 2, 3])
+def test_transfer_tables_equal_oracle(cvs, orc, which):
+    tab = np.ctypeslib.as_array(cvs.cvs_lut_host(which), shape=(65536,)).copy()
+    assert_same_f16(tab, orc.transfer_table(which), "table %d" % which)
+    d = np.empty(65536, np.uint16)
+    _lib.check(cvs.cvs_memcpy_d2h(d.ctypes.data, cvs.cvs_lut_device(which), 131072, None))
+    assert np.array_equal(d, tab)
+
+
+def test_transfer_functions_on_host_buffers(cvs, orc):
+    rng = np.random.default_rng(9)
+    codes = rng.integers(0, 0x7C00, 12345).astype(np.uint16)
+    for which, name in enumerate(["video_transfer_rec709_to_linear_scene", "video_transfer_rec709_to_linear_display",
+                                  "video_transfer_linear_to_rec709", "video_transfer_linear_to_sRGB"]):
+        out = np.empty_like(codes)
+        getattr(cvs, name)(u16p(out), u16p(codes), codes.size)
+        assert np.array_equal(out, orc.transfer_table(which)[codes]), name
+
+
+def test_gamma45_ramp(cvs, orc):
+    ramp = np.ctypeslib.as_array(cvs.video_get_gamma45_ramp(), shape=(65536,))
+    not_nan = (ALL_CODES & 0x7FFF) <= 0x7C00
+    nonneg = not_nan & (ALL_CODES < 0x8000)               # powf of a negative is NaN; its uint8 cast is unpinned
+    assert np.array_equal(ramp[nonneg], orc.gamma45_ramp()[nonneg])
+
+
+# ------------------------------------------------------------------ A10 filter.c
+
+def _taps(cvs, kind, *args):
+    f = fir_filter(None, 0, 0)
+    if kind == "tri":
+        cvs.filter_createTriangle(C.c_float(args[0]), C.c_float(args[1]), C.byref(f))
+    else:
+        cvs.filter_createLanczos(C.c_float(args[0]), args[1], C.c_float(args[2]), C.byref(f))
+    taps = np.ctypeslib.as_array(f.coeff, shape=(f.width,)).copy()
+    centre = f.center
+    cvs.filter_free(C.byref(f))
+    return taps, centre
+
+
+@pytest.mark.parametrize("sub", [0.25, 0.5, 0.75, 1.0, 2.0, 3.5, 4.0])
+@pytest.mark.parametrize("offset", [0.0, 0.25, 0.5, 0.999])
+def test_fir_taps(cvs, orc, sub, offset):
+    for kind, mine, theirs in [("tri", (sub, offset), orc.fir_triangle(sub, offset)),
+                               ("lan", (sub, 3, offset), orc.fir_lanczos(sub, 3, offset))]:
+        taps, centre = _taps(cvs, kind, *mine)
+        assert centre == theirs[1] and len(taps) == len(theirs[0])
+        assert np.array_equal(taps.view(np.uint32), theirs[0].view(np.uint32)), (kind, sub, offset)
+
+
+def test_fir_small_buffer_protocol(cvs):
+    buf = (C.c_float * 2)(7.0, 7.0)
+    f = fir_filter(C.cast(buf, C.POINTER(C.c_float)), 2, 0)
+    cvs.filter_createTriangle(C.c_float(0.25), C.c_float(0.0), C.byref(f))
+    assert f.center == -1 and f.width == 7 and buf[0] == 7.0
+
+
+# ------------------------------------------------------------------ A5 copies
+
+WINDOW_CASES = [
+    ((0, 0, 15, 8), (0, 0, 15, 8), (0, 0, 15, 8)),      # out.full, in.full, in.current
+    ((0, 0, 15, 8), (0, 0, 15, 8), (3, 2, 10, 6)),
+    ((-1, -1, 1, 1), (0, 0, 3, 3), (0, 0, 2, 2)),       # the RgbaFrameF16.py re-window
+    ((0, 0, 15, 8), (-4, -4, 20, 12), (-2, -3, 18, 11)),
+    ((0, 0, 15, 8), (0, 0, 15, 8), (0, 0, -1, -1)),     # empty input
+    ((0, 0, 15, 8), (20, 20, 30, 30), (21, 21, 29, 29)),  # disjoint
+]
+
+
+@pytest.mark.parametrize("out_full,in_full,in_cur", WINDOW_CASES)
+def test_copy_frame_f16(cvs, orc, out_full, in_full, in_cur):
+    rng = np.random.default_rng(1)
+    src = rand_f16_frame(rng, in_full, in_cur)
+    a, b = rand_f16_frame(rng, out_full), None
+    b = a.copy()
+    cvs.video_copy_frame_f16(a.ref(), src.ref())
+    orc.lib().orc_copy_frame_f16(b.ref(), src.ref())
+    assert same_window(a.current_window, b.current_window)
+    assert np.array_equal(a.array, b.array)
+
+
+@pytest.mark.parametrize("out_full,in_full,in_cur", WINDOW_CASES)
+@pytest.mark.parametrize("alpha", [1.0, 0.4, 0.0, 1.5, -2.0])
+def test_copy_frame_alpha_f32(cvs, orc, out_full, in_full, in_cur, alpha):
+    rng = np.random.default_rng(2)
+    src = rand_f32_frame(rng, in_full, in_cur)
+    a = rand_f32_frame(rng, out_full)
+    b = a.copy()
+    cvs.video_copy_frame_alpha_f32(a.ref(), src.ref(), C.c_float(alpha))
+    orc.lib().orc_copy_frame_alpha_f32(b.ref(), src.ref(), C.c_float(alpha))
+    assert same_window(a.current_window, b.current_window)
+    assert_same_f32(a.array, b.array, "copy_alpha")
+
+
+# ------------------------------------------------------------------ A6 / A7 mixers
+
+FULL = (0, 0, 23, 11)
+MIX_WINDOWS = [
+    (FULL, FULL),                               # full overlap
+    (FULL, (3, 2, 10, 6)),                      # nested
+    ((3, 2, 10, 6), FULL),
+    (FULL, (0, 0, -1, -1)),                     # empty either
+    ((0, 0, -1, -1), (2, 1, 9, 7)),
+    ((0, 0, 11, 11), (0, 0, 23, 11)),           # shared origin
+    ((1, 1, 6, 3), (1, 5, 6, 8)),               # disjoint in y, same x span
+    ((1, 1, 6, 3), (9, 1, 14, 3)),              # disjoint in x
+    ((1, 1, 6, 3), (9, 6, 14, 9)),              # disjoint in both
+    ((2, 1, 12, 7), (6, 4, 20, 10)),            # partial overlap, p upper-left
+    ((6, 4, 20, 10), (2, 1, 12, 7)),            # partial overlap, p lower-right (exercises the `left` selector quirk)
+    ((0, 5, 12, 9), (5, 0, 20, 7)),             # min.x vs min.y comparison picks the other frame
+    ((4, 0, 9, 11), (0, 3, 23, 8)),             # cross shape
+]
+
+
+@pytest.mark.parametrize("pw,qw", MIX_WINDOWS)
+@pytest.mark.parametrize("mix", [1.0, 0.35, 0.0, 2.0])
+def test_mix_over(cvs, orc, pw, qw, mix):
+    rng = np.random.default_rng(abs(hash((pw, qw))) % 9973)
+    out = rand_f32_frame(rng, FULL, pw, "mixed")
+    upper = rand_f32_frame(rng, FULL, qw, "mixed")
+    want = out.copy()
+    cvs.video_mix_over_f32(out.ref(), upper.ref(), C.c_float(mix))
+    orc.lib().orc_mix_over_f32(want.ref(), upper.ref(), C.c_float(mix))
+    assert same_window(out.current_window, want.current_window)
+    assert_same_f32(out.array, want.array, "over")      # the WHOLE buffer: untouched junk must stay untouched
+
+
+@pytest.mark.parametrize("pw,qw", MIX_WINDOWS)
+@pytest.mark.parametrize("mix", [0.5, 0.2, 0.0, 1.0])
+@pytest.mark.parametrize("in_place", [False, True])
+def test_mix_cross(cvs, orc, pw, qw, mix, in_place):
+    rng = np.random.default_rng(abs(hash((pw, qw, in_place))) % 9973)
+    a = rand_f32_frame(rng, FULL, pw, "mixed")
+    b = rand_f32_frame(rng, FULL, qw, "mixed")
+    if in_place:
+        want = a.copy()
+        cvs.video_mix_cross_f32(a.ref(), a.ref(), b.ref(), C.c_float(mix))
+        orc.lib().orc_mix_cross_f32(want.ref(), want.ref(), b.ref(), C.c_float(mix))
+        got = a
+    else:
+        got = rand_f32_frame(rng, FULL)
+        want = got.copy()
+        cvs.video_mix_cross_f32(got.ref(), a.ref(), b.ref(), C.c_float(mix))
+        orc.lib().orc_mix_cross_f32(want.ref(), a.ref(), b.ref(), C.c_float(mix))
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f32(got.array, want.array, "cross")
+
+
+def test_mix_over_clipped_by_smaller_output(cvs, orc):
+    rng = np.random.default_rng(77)
+    out = rand_f32_frame(rng, (4, 2, 19, 9), (5, 3, 15, 8), "mixed")
+    upper = rand_f32_frame(rng, (4, 2, 19, 9), (8, 2, 19, 6), "mixed")
+    want = out.copy()
+    cvs.video_mix_over_f32(out.ref(), upper.ref(), C.c_float(0.8))
+    orc.lib().orc_mix_over_f32(want.ref(), upper.ref(), C.c_float(0.8))
+    assert same_window(out.current_window, want.current_window)
+    assert_same_f32(out.array, want.array, "over (offset origin)")
+
+
+def test_crossfade_kat_through_the_library(cvs):
+    """The reference's own mixing KAT (tests/canvas/sequence.py:58-100, frames 15-19)."""
+    for i in range(15, 20):
+        mix = float(i - 15) / 5.0
+        a = HostFrame((0, 0, 0, 0), np.float32, np.array([[[0, i - 9, 0, 1]]], np.float32))
+        b = HostFrame((0, 0, 0, 0), np.float32, np.array([[[0, 0, i - 14, 1]]], np.float32))
+        out = HostFrame((0, 0, 0, 0), np.float32)
+        cvs.video_mix_cross_f32(out.ref(), a.ref(), b.ref(), C.c_float(mix))
+        r, g, bl, al = [float(v) for v in out.array[0, 0]]
+        assert round(r, 6) == 0 and round(al - 1.0, 6) == 0
+        assert round(g - (i - 9) * (1.0 - mix), 6) == 0 and round(bl - (i - 14) * mix, 6) == 0
+
+
+# ------------------------------------------------------------------ A12 colour matrix
+
+@pytest.mark.parametrize("cur", [(0, 0, 40, 20), (3, 2, 30, 17), (5, 5, 5, 5), (0, 0, -1, -1)])
+def test_named_colour_functions(cvs, orc, cur):
+    rng = np.random.default_rng(5)
+    for mine, theirs in [(cvs.video_color_rgb_to_xyz_sdtv, orc.lib().orc_color_rgb_to_xyz_sdtv),
+                         (cvs.video_color_xyz_to_srgb, orc.lib().orc_color_xyz_to_srgb)]:
+        a = rand_f16_frame(rng, (0, 0, 40, 20), cur)
+        b = a.copy()
+        mine(a.ref())
+        theirs(b.ref())
+        assert_same_f16(a.array, b.array, "colour")
+
+
+@pytest.mark.parametrize("pre,post", [(-1, -1), (0, -1), (-1, 3), (0, 2)])
+def test_colour_matrix_general(cvs, orc, pre, post):
+    rng = np.random.default_rng(6)
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    h = rand_f16_frame(rng, (-3, -2, 60, 33), (0, 0, 57, 30))
+    # a few wild codes: negatives, subnormals, large values
+    h.array[5, 5] = [0x8400, 0x0001, 0x7BFF, 0xC000]
+    want = h.copy()
+    dev = DeviceFrame.from_host(h)
+    _lib.check(cvs.cvs_color_matrix_f16_dev(dev.ref(), f32p(m), pre, post, None))
+    _lib.check(cvs.cvs_stream_sync(None))
+    got = dev.download()
+    orc.lib().orc_color_matrix_f16(want.ref(), f32p(m),
+                                   None if pre < 0 else u16p(orc.transfer_table(pre)),
+                                   None if post < 0 else u16p(orc.transfer_table(post)))
+    assert_same_f16(got.array, want.array, "colour matrix pre=%d post=%d" % (pre, post))
+
+
+# ------------------------------------------------------------------ A15 / A16
+
+def test_gain_offset(cvs, orc):
+    rng = np.random.default_rng(8)
+    for out_full, in_full, in_cur in WINDOW_CASES:
+        src = rand_f16_frame(rng, in_full, in_cur)
+        a = rand_f16_frame(rng, out_full)
+        b = a.copy()
+        cvs.video_filter_gain_offset_f16(a.ref(), src.ref(), C.c_float(1.5), C.c_float(0.0625))
+        orc.lib().orc_gain_offset_f16(b.ref(), src.ref(), C.c_float(1.5), C.c_float(0.0625))
+        assert same_window(a.current_window, b.current_window)
+        assert_same_f16(a.array, b.array, "gain/offset")
+
+
+def test_solid_fill_and_reference_kats(cvs, orc):
+    color = _lib.rgba_f32(1.0, 0.5, 0.333333, 0.2)
+    carr = np.array([1.0, 0.5, 0.333333, 0.2], np.float32)
+    # RgbaFrameF16.py:6-23
+    frame = HostFrame((0, 0, 3, 3), np.uint16, fill=0x1234)
+    want = frame.copy()
+    win = box2i.of(0, 0, 2, 2)
+    cvs.video_fill_solid_f16(frame.ref(), C.byref(win), C.byref(color))
+    orc.lib().orc_solid_f16(want.ref(), C.byref(win), f32p(carr))
+    assert frame.current_window.tuple() == (0, 0, 2, 2)
+    assert np.array_equal(frame.array, want.array)
+    assert np.allclose(orc.half_to_float(frame.array[0, 0]), carr, atol=5e-4)
+    frame2 = HostFrame((-1, -1, 1, 1), np.uint16)
+    cvs.video_copy_frame_f16(frame2.ref(), frame.ref())
+    assert frame2.current_window.tuple() == (0, 0, 1, 1)
+    # SolidColorVideoSource.py:46-55 (moving window)
+    for w in [(-2, -2, 2, 2), (-3, -3, 1, 4), (-4, -4, 0, 6)]:
+        f = HostFrame((-5, -5, 5, 6), np.float32)
+        bw = box2i.of(*w)
+        cvs.video_fill_solid_f32(f.ref(), C.byref(bw), C.byref(color))
+        assert f.current_window.tuple() == w and (f.window_view() == carr).all()
+
+
+# ------------------------------------------------------------------ chain (config 2 at small size)
+
+def _synth_layers(w, h, n, frame=0):
+    return [synth.layer_frame(w, h, k, frame) for k in range(n)]
+
+
+@pytest.mark.parametrize("nlayers", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("size", [(64, 36), (33, 7)])       # even and odd pixel counts
+def test_chain_fused_matches_oracle(cvs, orc, nlayers, size):
+    w, h = size
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    layers = _synth_layers(w, h, nlayers)
+    want = orc.chain_color_over(layers, m, orc.transfer_table(0), None)
+    dl = [DeviceFrame.from_host(l) for l in layers]
+    out = DeviceFrame((0, 0, w - 1, h - 1), np.uint16)
+    chain_color_over([(out, dl)], m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE)
+    _lib.check(cvs.cvs_stream_sync(None))
+    assert cvs.cvs_chain_last_was_fused() == 1
+    got = out.download()
+    assert got.current_window.tuple() == (0, 0, w - 1, h - 1)
+    assert_same_f16(got.array, want.array, "fused chain, %d layers" % nlayers)
+
+
+def test_chain_batch_and_lut_variants(cvs, orc):
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    for pre, post in [(-1, -1), (-1, 2), (0, 3)]:
+        jobs, wants = [], []
+        for frame in range(3):
+            layers = _synth_layers(48, 20, 2, frame)
+            wants.append(orc.chain_color_over(layers, m, None if pre < 0 else orc.transfer_table(pre),
+                                              None if post < 0 else orc.transfer_table(post)))
+            jobs.append((DeviceFrame((0, 0, 47, 19), np.uint16), [DeviceFrame.from_host(l) for l in layers]))
+        chain_color_over(jobs, m, pre, post)
+        _lib.check(cvs.cvs_stream_sync(None))
+        for (out, _), want in zip(jobs, wants):
+            assert_same_f16(out.download().array, want.array, "batch pre=%d post=%d" % (pre, post))
+
+
+def test_chain_ragged_windows_take_the_node_by_node_path(cvs, orc):
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    rng = np.random.default_rng(12)
+    full = (0, 0, 47, 19)
+    layers = [rand_f16_frame(rng, full, full, alpha="one"), rand_f16_frame(rng, full, (5, 3, 30, 15)),
+              rand_f16_frame(rng, full, (20, 0, 47, 10))]
+    want = orc.chain_color_over(layers, m, orc.transfer_table(0), None)
+    dl = [DeviceFrame.from_host(l) for l in layers]
+    out = DeviceFrame(full, np.uint16)
+    chain_color_over([(out, dl)], m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE)
+    assert cvs.cvs_chain_last_was_fused() == 0
+    got = out.download()
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f16(got.window_view(), want.window_view(), "unfused chain")
+
+
+# ------------------------------------------------------------------ A4 / A8 pulls and the workspace
+
+def _py_source(fill16=None, fill32=None):
+    """A video_source whose vtable is implemented in Python; returns (source, keepalive)."""
+    keep = []
+
+    def g16(self, idx, fp):
+        fill16(idx, fp.contents)
+
+    def g32(self, idx, fp):
+        fill32(idx, fp.contents)
+
+    cb16 = GET_FRAME_F16(g16) if fill16 else C.cast(None, GET_FRAME_F16)
+    cb32 = GET_FRAME_F32(g32) if fill32 else C.cast(None, GET_FRAME_F32)
+    funcs = video_frame_source_funcs(0, cb16, cb32, None)
+    src = video_source(None, C.pointer(funcs))
+    keep += [cb16, cb32, funcs]
+    return src, keep
+
+
+def _fill_from(host_frames):
+    def fill(idx, f):
+        src = host_frames[idx % len(host_frames)]
+        n = f.full_window.width * f.full_window.height
+        if src.dtype == np.uint16:
+            dst = np.ctypeslib.as_array(C.cast(f.data, C.POINTER(C.c_uint16)), shape=(f.full_window.height, f.full_window.width, 4))
+        else:
+            dst = np.ctypeslib.as_array(C.cast(f.data, C.POINTER(C.c_float)), shape=(f.full_window.height, f.full_window.width, 4))
+        assert n == src.array.shape[0] * src.array.shape[1]
+        dst[:] = src.array
+        f.current_window = src.current_window
+    return fill
+
+
+def test_pull_dispatch_converts_between_formats(cvs, orc):
+    rng = np.random.default_rng(21)
+    full = (0, 0, 20, 9)
+    h = rand_f16_frame(rng, full, (2, 1, 18, 8))
+    f = rand_f32_frame(rng, full, (1, 2, 19, 7), lo=-2, hi=2)
+    s16, k1 = _py_source(fill16=_fill_from([h]))
+    s32, k2 = _py_source(fill32=_fill_from([f]))
+    # f16 source pulled as f32 (main.c:115-139)
+    out32 = HostFrame(full, np.float32, fill=9.0)
+    cvs.video_get_frame_f32(C.byref(s16), 0, out32.ref())
+    assert out32.current_window.tuple() == (2, 1, 18, 8)
+    assert np.array_equal(out32.window_view().view(np.uint32), orc.half_to_float(h.window_view()).view(np.uint32))
+    assert (out32.array[0] == 9.0).all()                                  # outside current_window: untouched
+    # f32 source pulled as f16 (main.c:43-71)
+    out16 = HostFrame(full, np.uint16, fill=0x1111)
+    cvs.video_get_frame_f16(C.byref(s32), 0, out16.ref())
+    assert out16.current_window.tuple() == (1, 2, 19, 7)
+    assert np.array_equal(out16.window_view(), orc.float_to_half(f.window_view()))
+    assert (out16.array[0] == 0x1111).all()
+    # NULL source => empty window (main.c:35-38)
+    cvs.video_get_frame_f16(None, 0, out16.ref())
+    assert out16.current_window.is_empty()
+
+
+def test_workspace_stack_host_and_device(cvs, orc):
+    rng = np.random.default_rng(31)
+    full = (0, 0, 31, 15)
+    frames = [rand_f16_frame(rng, full, full, alpha="one"), rand_f16_frame(rng, full, (4, 2, 20, 12)),
+              rand_f16_frame(rng, full, (10, 0, 31, 9))]
+    sources = [_py_source(fill16=_fill_from([fr])) for fr in frames]
+    ws = cvs.workspace_create()
+    zs = [0, 7, 3]
+    items = [cvs.workspace_add_item(ws, C.cast(C.pointer(s[0]), C.c_void_p), 0, 10, 0, z, None) for s, z in zip(sources, zs)]
+    assert cvs.workspace_get_length(ws) == 3
+    vs = video_source()
+    cvs.workspace_as_video_source(ws, C.byref(vs))
+
+    # the oracle's stack over the same sources
+    oitems = (orc.ws_item * 3)(*[orc.ws_item(0, 10, z, 0, C.pointer(s[0])) for s, z in zip(sources, zs)])
+    want32 = HostFrame(full, np.float32)
+    orc.lib().orc_workspace_get_frame_f32(oitems, 3, 4, want32.ref())
+    want16 = orc.float_to_half(want32.array)
+
+    got32 = HostFrame(full, np.float32)
+    cvs.video_get_frame_f32(C.byref(vs), 4, got32.ref())                 # host path
+    assert same_window(got32.current_window, want32.current_window)
+    assert_same_f32(got32.window_view(), want32.window_view(), "workspace host")
+
+    got16 = HostFrame(full, np.uint16)                                   # through slot 3: whole stack in HBM
+    dev = _lib.rgba_frame_dev(cvs.cvs_malloc(got16.array.nbytes), 1, got16.full_window, got16.full_window, None)
+    cvs.video_get_frame_dev(C.byref(vs), 4, C.byref(dev))
+    _lib.check(cvs.cvs_memcpy_d2h(got16.array.ctypes.data, dev.data, got16.array.nbytes, None))
+    assert dev.current_window.tuple() == want32.current_window.tuple()
+    x0, y0, x1, y1 = dev.current_window.tuple()
+    assert_same_f16(got16.array[y0:y1 + 1, x0:x1 + 1], want16[y0:y1 + 1, x0:x1 + 1], "workspace device")
+    cvs.cvs_free(dev.data)
+
+    # membership: outside every item => empty (workspace.c:504-508)
+    cvs.video_get_frame_f32(C.byref(vs), 10, got32.ref())
+    assert got32.current_window.is_empty()
+    # item API round trip
+    x, ln, z = C.c_int64(), C.c_int64(), C.c_int64()
+    cvs.workspace_get_item_pos(items[1], C.byref(x), C.byref(ln), C.byref(z))
+    assert (x.value, ln.value, z.value) == (0, 10, 7)
+    nz = C.c_int64(-5)
+    cvs.workspace_update_item(items[1], None, None, C.byref(nz), None, None, None)
+    cvs.workspace_remove_item(items[2])
+    assert cvs.workspace_get_length(ws) == 2
+    cvs.workspace_free(ws)
+
+
+# ------------------------------------------------------------------ A9 scaler, A11 blur, Lanczos
+
+SCALE_CASES = [
+    # target full, source full, source current, target_point, source_point, factors
+    ((0, 0, 31, 17), (0, 0, 15, 8), (0, 0, 15, 8), (0, 0), (0, 0), (2.0, 2.0)),
+    ((0, 0, 31, 17), (0, 0, 15, 8), (2, 1, 13, 7), (0, 0), (0, 0), (2.0, 2.0)),
+    ((0, 0, 15, 8), (0, 0, 31, 17), (0, 0, 31, 17), (0, 0), (0, 0), (0.5, 0.5)),       # the partial-coverage case
+    ((0, 0, 15, 17), (0, 0, 31, 17), (0, 0, 31, 17), (0, 0), (0, 0), (0.5, 1.0)),       # x only
+    ((0, 0, 31, 8), (0, 0, 31, 17), (1, 1, 30, 16), (0, 0), (0, 0), (1.0, 0.5)),        # y only
+    ((0, 0, 40, 30), (0, 0, 15, 8), (0, 0, 15, 8), (3.5, 2.25), (1.0, 0.5), (2.5, 3.0)),  # fractional points
+    ((0, 0, 20, 40), (0, 0, 15, 8), (0, 0, 15, 8), (0, 0), (0, 0), (1.3, 4.0)),         # x first
+    ((0, 0, 15, 8), (0, 0, 15, 8), (0, 0, 15, 8), (0, 0), (0, 0), (1.0, 1.0)),          # identity
+    ((0, 0, 15, 8), (0, 0, 15, 8), (0, 0, 15, 8), (2.0, 0.0), (0, 0), (1.0, 1.0)),      # shift only: factor 1, points differ
+    ((-8, -4, 23, 13), (0, 0, 15, 8), (0, 0, 15, 8), (0, 0), (8.0, 4.0), (2.0, 2.0)),   # negative origin
+]
+
+
+@pytest.mark.parametrize("tfull,sfull,scur,tp,sp,fac", SCALE_CASES)
+def test_scale_bilinear(cvs, orc, tfull, sfull, scur, tp, sp, fac):
+    rng = np.random.default_rng(41)
+    src = rand_f32_frame(rng, sfull, scur)
+    got = rand_f32_frame(rng, tfull)
+    want = got.copy()
+    cvs.video_scale_bilinear_f32(got.ref(), v2f(*tp), src.ref(), v2f(*sp), v2f(*fac))
+    orc.lib().orc_scale_bilinear_f32(want.ref(), v2f(*tp), src.ref(), v2f(*sp), v2f(*fac))
+    assert same_window(got.current_window, want.current_window), (got.current_window, want.current_window)
+    assert_same_f32(got.array, want.array, "scale")
+
+
+def test_scale_pull(cvs, orc):
+    rng = np.random.default_rng(43)
+    sfull = (0, 0, 63, 35)
+    big = rand_f32_frame(rng, sfull)
+
+    def fill(idx, f):
+        fw = f.full_window
+        dst = np.ctypeslib.as_array(C.cast(f.data, C.POINTER(C.c_float)), shape=(fw.height, fw.width, 4))
+        dst[:] = big.array[fw.min.y:fw.max.y + 1, fw.min.x:fw.max.x + 1]
+        f.current_window = fw
+
+    src, keep = _py_source(fill32=fill)
+    rect = box2i.of(*sfull)
+    for fac in [(2.0, 2.0), (0.5, 1.0), (0.0, 1.0), (1.0, 1.0)]:
+        got, want = HostFrame((0, 0, 31, 17), np.float32), HostFrame((0, 0, 31, 17), np.float32)
+        cvs.video_scale_bilinear_f32_pull(got.ref(), v2f(4, 2), C.byref(src), 0, C.byref(rect), v2f(10, 6), v2f(*fac))
+        orc.lib().orc_scale_bilinear_f32_pull(want.ref(), v2f(4, 2), C.byref(src), 0, C.byref(rect), v2f(10, 6), v2f(*fac))
+        assert same_window(got.current_window, want.current_window)
+        if not want.current_window.is_empty():
+            assert_same_f32(got.array, want.array, "scale pull %r" % (fac,))
+
+
+@pytest.mark.parametrize("scur", [(0, 0, 47, 26), (5, 3, 40, 20)])
+@pytest.mark.parametrize("ntaps", [9, 5, 1, 4])
+def test_fir_blur(cvs, orc, scur, ntaps):
+    rng = np.random.default_rng(51)
+    full = (0, 0, 47, 26)
+    src = rand_f32_frame(rng, full, scur)
+    taps = synth.gaussian_taps(ntaps, 1.5)
+    want = HostFrame(full, np.float32)
+    orc.lib().orc_fir_blur_f32(want.ref(), src.ref(), f32p(taps), ntaps)
+    d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(full, np.float32)
+    _lib.check(cvs.cvs_fir_blur_f32_dev(d_out.ref(), d_src.ref(), f32p(taps), ntaps, None))
+    got = d_out.download()
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f32(got.window_view(), want.window_view(), "blur")
+
+
+@pytest.mark.parametrize("fx,fy,tsize", [(0.5, 0.5, (32, 18)), (0.25, 0.5, (16, 18)), (2.0, 1.5, (128, 54))])
+def test_lanczos_resample(cvs, orc, fx, fy, tsize):
+    rng = np.random.default_rng(61)
+    src = rand_f32_frame(rng, (0, 0, 63, 35))
+    tfull = (0, 0, tsize[0] - 1, tsize[1] - 1)
+    want = HostFrame(tfull, np.float32)
+    orc.lib().orc_resample_lanczos_f32(want.ref(), src.ref(), C.c_float(fx), C.c_float(fy), 3)
+    d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(tfull, np.float32)
+    _lib.check(cvs.cvs_resample_lanczos_f32_dev(d_out.ref(), d_src.ref(), C.c_float(fx), C.c_float(fy), 3, None))
+    got = d_out.download()
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f32(got.array, want.array, "lanczos")
+
+
+# ------------------------------------------------------------------ BASELINE sizes
+
+def test_config2_full_4k_frame_against_oracle(cvs, orc):
+    """3840x2160, 2 layers, Rec.709 LUT + RGB->Y'PbPr + over: one whole frame, every pixel."""
+    w, h = 3840, 2160
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    layers = _synth_layers(w, h, 2)
+    want = orc.chain_color_over(layers, m, orc.transfer_table(0), None)
+    dl = [DeviceFrame.from_host(l) for l in layers]
+    out = DeviceFrame((0, 0, w - 1, h - 1), np.uint16)
+    chain_color_over([(out, dl)], m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE)
+    _lib.check(cvs.cvs_stream_sync(None))
+    assert cvs.cvs_chain_last_was_fused() == 1
+    assert_same_f16(out.download().array, want.array, "4K config 2")
+
+
+def test_config4_8k_three_layer_properties(cvs, orc):
+    """7680x4320 3-layer over stack through size-independent properties:
+    an opaque top layer wins; a fully transparent layer is the identity; the first rows equal the oracle."""
+    w, h = 7680, 4320
+    ident = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1], np.float32)
+    rng = np.random.default_rng(4)
+    base = synth.layer_pixels(w, h, 0, 0)
+    mid = synth.layer_pixels(w, h, 1, 0)
+    clear = mid.copy()
+    clear[..., 3] = 0
+    opaque = synth.layer_pixels(w, h, 2, 0)
+    opaque[..., 3] = 0x3C00
+    full = (0, 0, w - 1, h - 1)
+
+    def run(arrays):
+        dl = []
+        for a in arrays:
+            d = DeviceFrame(full, np.uint16)
+            d.upload(a)
+            dl.append(d)
+        out = DeviceFrame(full, np.uint16)
+        chain_color_over([(out, dl)], ident)
+        _lib.check(cvs.cvs_stream_sync(None))
+        res = out.download().array
+        for d in dl + [out]:
+            d.free()
+        return res
+
+    top_wins = run([base, mid, opaque])
+    assert np.array_equal(top_wins, opaque)                    # (x*0 + c*1)/1 == c exactly
+    two = run([base, mid])
+    three = run([base, clear, mid])
+    assert np.array_equal(two, three)                          # alpha 0 layer changes nothing
+    # head of the frame against the oracle
+    rows = 8
+    heads = [HostFrame((0, 0, w - 1, rows - 1), np.uint16, a[:rows]) for a in (base, mid)]
+    want = orc.chain_color_over(heads, ident, None, None)
+    assert_same_f16(two[:rows], want.array, "8K head rows")
+    del rng

@@ -1,0 +1,117 @@
+"""The N>1 path on CPU: two processes, gloo backend, the same sharding/broadcast code bench.py
+runs over RCCL.  No GPU, no pixels: a stand-in object plays the library's LUT store."""
+import ctypes as C
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from canvas_amd import shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_round_robin_assignment_is_a_partition():
+    for world in (1, 2, 4, 8):
+        owned = [shard.frames_of_rank(r, world, 5) for r in range(world)]
+        flat = sorted(g for o in owned for g in o)
+        assert flat == list(range(5 * world))
+        for r, o in enumerate(owned):
+            assert all(shard.owner_of_frame(g, world) == r for g in o)
+    assert shard.frames_of_rank(1, 4, 3, first=10) == [13, 17, 21]
+
+
+class FakeStore:
+    """cvs_lut_host / cvs_lut_install / cvs_lut_device of the real library, minus the GPU."""
+
+    def __init__(self, tables=None):
+        self.tables = dict(tables or {})
+        self.installed = {}
+
+    def cvs_lut_host(self, which):
+        t = self.tables.get(which)
+        return None if t is None else t.ctypes.data_as(C.POINTER(C.c_uint16))
+
+    def cvs_lut_device(self, which):
+        return 1 if which in self.tables else None
+
+    def cvs_lut_install(self, which, ptr):
+        self.installed[which] = np.ctypeslib.as_array(ptr, shape=(65536,)).copy()
+        return 0
+
+
+def test_pack_unpack_round_trip():
+    rng = np.random.default_rng(0)
+    tabs = {0: rng.integers(0, 65536, 65536).astype(np.uint16), 3: rng.integers(0, 65536, 65536).astype(np.uint16)}
+    m = rng.normal(size=9).astype(np.float32)
+    block = shard.pack_parameters(FakeStore(tabs), m, [0, 3])
+    assert block.nbytes == 36 + 2 * 131072
+    dst = FakeStore()
+    m2 = shard.unpack_parameters(dst, block, [0, 3])
+    assert np.array_equal(m, m2)
+    assert np.array_equal(dst.installed[0], tabs[0]) and np.array_equal(dst.installed[3], tabs[3])
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    sys.path.insert(0, %(root)r)
+    import torch.distributed as dist
+    from canvas_amd import shard
+    from tests.test_shard_gloo import FakeStore
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo")
+    rng = np.random.default_rng(123)
+    table = rng.integers(0, 65536, 65536).astype(np.uint16)
+    if rank == 0:
+        store, m = FakeStore({0: table}), np.arange(9, dtype=np.float32) * 0.5
+    else:
+        store, m = FakeStore(), np.zeros(9, np.float32)
+    got = shard.broadcast_parameters(store, dist, rank, m, [0])
+    ok_m = bool(np.array_equal(got, np.arange(9, dtype=np.float32) * 0.5))
+    ok_t = rank == 0 or bool(np.array_equal(store.installed[0], table))
+    mine = shard.frames_of_rank(rank, world, 6)
+    stats = shard.gather_stats(dist, len(mine), sum(mine), 0.25 * (rank + 1))
+    print(json.dumps({"rank": rank, "ok_m": ok_m, "ok_t": ok_t, "frames": mine, "stats": stats}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_broadcast_and_gather_over_gloo(tmp_path):
+    import json
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, err = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, err[-2000:]
+        outs.append(json.loads(out.strip().splitlines()[-1]))
+    outs.sort(key=lambda o: o["rank"])
+    assert all(o["ok_m"] and o["ok_t"] for o in outs)
+    assert outs[0]["frames"] == [0, 2, 4, 6, 8, 10] and outs[1]["frames"] == [1, 3, 5, 7, 9, 11]
+    for o in outs:
+        assert [s[0] for s in o["stats"]] == [6, 6]
+        assert [s[1] for s in o["stats"]] == [30, 36]
+        assert [round(s[2], 2) for s in o["stats"]] == [0.25, 0.5]
