@@ -403,8 +403,12 @@ def test_chain_ragged_windows_take_the_node_by_node_path(cvs, orc):
     m = np.array(REC709_RGB_TO_YPBPR, np.float32)
     rng = np.random.default_rng(12)
     full = (0, 0, 47, 19)
+    # Windows chosen so that video_mix.c:265's `left` selector (min.x compared with the other frame's
+    # min.Y) picks the geometrically left frame: otherwise the reference copies pixels from outside
+    # the upper layer's current_window, i.e. whatever its malloc'd temp happened to hold -- not
+    # reproducible by anyone.  (test_mix_over covers those configurations with shared buffers.)
     layers = [rand_f16_frame(rng, full, full, alpha="one"), rand_f16_frame(rng, full, (5, 3, 30, 15)),
-              rand_f16_frame(rng, full, (20, 0, 47, 10))]
+              rand_f16_frame(rng, full, (20, 2, 47, 10))]
     want = orc.chain_color_over(layers, m, orc.transfer_table(0), None)
     dl = [DeviceFrame.from_host(l) for l in layers]
     out = DeviceFrame(full, np.uint16)
@@ -477,7 +481,7 @@ def test_workspace_stack_host_and_device(cvs, orc):
     rng = np.random.default_rng(31)
     full = (0, 0, 31, 15)
     frames = [rand_f16_frame(rng, full, full, alpha="one"), rand_f16_frame(rng, full, (4, 2, 20, 12)),
-              rand_f16_frame(rng, full, (10, 0, 31, 9))]
+              rand_f16_frame(rng, full, (10, 1, 31, 9))]
     sources = [_py_source(fill16=_fill_from([fr])) for fr in frames]
     ws = cvs.workspace_create()
     zs = [0, 7, 3]
