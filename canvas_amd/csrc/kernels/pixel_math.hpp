@@ -96,3 +96,65 @@ __device__ __forceinline__ px32 blend_cross(px32 a, px32 b, float mix_a, float m
 }
 
 }  // namespace cvs
+
+// ---------------------------------------------------------------- two pixels at a time
+// A lane of the chain kernel owns a PAIR of pixels (one 16-byte word).  Keeping the pair as
+// 2-wide vectors lets every mul/add of the matrix and of the blend issue as v_pk_mul_f32 /
+// v_pk_add_f32 (2 f32 results per instruction, full rate on CDNA3/4): same operations, same
+// rounding, half the VALU issue slots.  Conversions, gathers and the divides stay per channel.
+namespace cvs {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct px32x2 { f32x2 r, g, b, a; };   // .x = first pixel of the pair, .y = second
+
+// 16-byte word: x = g0:r0, y = a0:b0, z = g1:r1, w = a1:b1
+__device__ __forceinline__ px32x2 widen2(uint4 p) {
+    px32x2 v;
+    v.r = f32x2{ h2f(p.x & 0xFFFFu), h2f(p.z & 0xFFFFu) };
+    v.g = f32x2{ h2f(p.x >> 16), h2f(p.z >> 16) };
+    v.b = f32x2{ h2f(p.y & 0xFFFFu), h2f(p.w & 0xFFFFu) };
+    v.a = f32x2{ h2f(p.y >> 16), h2f(p.w >> 16) };
+    return v;
+}
+
+__device__ __forceinline__ f32x2 saturate_to_inf2(f32x2 x) { return (x * 0x1p112f) * 0x1p-112f; }
+
+__device__ __forceinline__ uint32_t pkrtz(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+
+__device__ __forceinline__ uint4 narrow2(px32x2 v) {
+    f32x2 r = saturate_to_inf2(v.r), g = saturate_to_inf2(v.g), b = saturate_to_inf2(v.b), a = saturate_to_inf2(v.a);
+    return make_uint4(pkrtz(r.x, g.x), pkrtz(b.x, a.x), pkrtz(r.y, g.y), pkrtz(b.y, a.y));
+}
+
+__device__ __forceinline__ px32x2 mat3x2(px32x2 v, const float *m) {
+    px32x2 o;
+    o.r = v.r * m[0] + v.g * m[3] + v.b * m[6];
+    o.g = v.r * m[1] + v.g * m[4] + v.b * m[7];
+    o.b = v.r * m[2] + v.g * m[5] + v.b * m[8];
+    o.a = v.a;
+    return o;
+}
+
+// video_mix.c:323-337 with mix_b == 1.0f (workspace.c:543): b.a * 1.0f is b.a exactly
+__device__ __forceinline__ px32x2 blend_over2_mix1(px32x2 lo, px32x2 b) {
+    f32x2 alpha_b = b.a;
+    f32x2 alpha_a = lo.a * (1.0f - b.a);
+    f32x2 a = alpha_a + alpha_b;
+    f32x2 nr = lo.r * alpha_a + b.r * alpha_b;
+    f32x2 ng = lo.g * alpha_a + b.g * alpha_b;
+    f32x2 nb = lo.b * alpha_a + b.b * alpha_b;
+    px32x2 o;
+    // IEEE divides, per pixel; a == 0 selects the zero pixel afterwards (x/0 is never used)
+    o.r = f32x2{ nr.x / a.x, nr.y / a.y };
+    o.g = f32x2{ ng.x / a.x, ng.y / a.y };
+    o.b = f32x2{ nb.x / a.x, nb.y / a.y };
+    o.a = a;
+    if (a.x == 0.0f) { o.r.x = 0.0f; o.g.x = 0.0f; o.b.x = 0.0f; o.a.x = 0.0f; }
+    if (a.y == 0.0f) { o.r.y = 0.0f; o.g.y = 0.0f; o.b.y = 0.0f; o.a.y = 0.0f; }
+    return o;
+}
+
+}  // namespace cvs
