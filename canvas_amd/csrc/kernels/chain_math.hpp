@@ -1,0 +1,101 @@
+// chain_math.hpp -- the arithmetic of the fused chain on PAIRS of pixels, trimmed to what the
+// reference's results actually require.  Every shortcut below is exact (bit-identical to the
+// straightforward form in pixel_math.hpp / grade.hpp, which the v0 kernel keeps for A/B checks):
+//
+//   * alpha never goes through truncate+widen: the colour filter copies alpha (color.c:41), the value
+//     is already a half, and f2h(h2f(c)) == c for every code c;
+//   * the |x| >= 65536 -> Inf fix-up of the truncation (pixel_math.hpp) is only executed by waves in
+//     which some lane actually holds such a value (one v_max3 chain + one wave-uniform branch
+//     instead of two multiplies per channel);
+//   * x / 1.0f == x: when the blended alpha of both pixels of the pair is exactly 1.0f (always the
+//     case over an opaque lower layer: a*(1-b)+b with a == 1 is exactly 1 for half-valued b) the
+//     three IEEE divides are skipped; lanes that need them take the general path;
+//   * gathered table entries are converted straight from the gather result, without re-packing two
+//     halfs into a dword first.
+// VALU cost matters here: measured on gfx950 (tools/valubench.hip) the kernel's instruction mix
+// issues at ~4.5 cycles per wave-instruction per SIMD with 4 waves per SIMD, which made the first
+// version of this kernel compute-bound (245 us of arithmetic against 290 us of HBM time per launch).
+#pragma once
+#include "lut_common.hpp"
+
+namespace cvs {
+
+__device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
+
+// truncate a pair of f32 to half and widen back (the rounding point between the colour filter and the
+// stack, color.c:132 / :159 + main.c:128-136); POST applies the post-table to the half codes
+template <bool POST_LDS, bool POST_GLB>
+__device__ __forceinline__ f32x2 through_half(f32x2 v, const uint16_t *lds_lut, const uint16_t *glb_post) {
+    uint32_t pk = pkrtz(v.x, v.y);
+    uint32_t lo = pk & 0xFFFFu, hi = pk >> 16;
+    if (POST_LDS) { lo = lds_lut[lo]; hi = lds_lut[hi]; }
+    if (POST_GLB) { lo = glb_post[lo]; hi = glb_post[hi]; }
+    return f32x2{ h2f(lo), h2f(hi) };
+}
+
+template <bool PRE, bool POST>
+__device__ __forceinline__ px32x2 grade_pair(u32x4 p, const Mat &mat, const uint16_t *lds_lut, const uint16_t *glb_post) {
+    uint32_t c[8] = { p.x & 0xFFFFu, p.x >> 16, p.y & 0xFFFFu, p.y >> 16, p.z & 0xFFFFu, p.z >> 16, p.w & 0xFFFFu, p.w >> 16 };
+    if (PRE) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) c[i] = lds_lut[c[i]];
+    }
+    px32x2 v;
+    v.r = f32x2{ h2f(c[0]), h2f(c[4]) };
+    v.g = f32x2{ h2f(c[1]), h2f(c[5]) };
+    v.b = f32x2{ h2f(c[2]), h2f(c[6]) };
+    px32x2 o = mat3x2(v, mat.m);
+    // rare: a channel at or beyond the half range must become Inf, not 65504
+    const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.r.x), __builtin_fabsf(o.g.x)), __builtin_fabsf(o.b.x)),
+                                      __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.r.y), __builtin_fabsf(o.g.y)), __builtin_fabsf(o.b.y)));
+    if (wave_any(big >= 65536.0f)) { o.r = saturate_to_inf2(o.r); o.g = saturate_to_inf2(o.g); o.b = saturate_to_inf2(o.b); }
+    constexpr bool post_lds = POST && !PRE, post_glb = POST && PRE;     // the LDS slot belongs to the pre table when both exist
+    o.r = through_half<post_lds, post_glb>(o.r, lds_lut, glb_post);
+    o.g = through_half<post_lds, post_glb>(o.g, lds_lut, glb_post);
+    o.b = through_half<post_lds, post_glb>(o.b, lds_lut, glb_post);
+    // alpha: copied by the matrix, already a half -> only the optional post-table touches it
+    uint32_t a0 = c[3], a1 = c[7];
+    if (post_lds) { a0 = lds_lut[a0]; a1 = lds_lut[a1]; }
+    if (post_glb) { a0 = glb_post[a0]; a1 = glb_post[a1]; }
+    o.a = f32x2{ h2f(a0), h2f(a1) };
+    return o;
+}
+
+// video_mix.c:323-337 with mix_b == 1.0f (workspace.c:543)
+__device__ __forceinline__ px32x2 over_pair(px32x2 lo, px32x2 b) {
+    const f32x2 alpha_b = b.a;                       // b.a * 1.0f
+    const f32x2 alpha_a = lo.a * (1.0f - b.a);
+    const f32x2 a = alpha_a + alpha_b;
+    px32x2 o;
+    o.r = lo.r * alpha_a + b.r * alpha_b;
+    o.g = lo.g * alpha_a + b.g * alpha_b;
+    o.b = lo.b * alpha_a + b.b * alpha_b;
+    o.a = a;
+    if (!(a.x == 1.0f && a.y == 1.0f)) {             // x / 1.0f == x: nothing to do for unit alpha
+        o.r = f32x2{ o.r.x / a.x, o.r.y / a.y };
+        o.g = f32x2{ o.g.x / a.x, o.g.y / a.y };
+        o.b = f32x2{ o.b.x / a.x, o.b.y / a.y };
+        if (a.x == 0.0f) { o.r.x = 0.0f; o.g.x = 0.0f; o.b.x = 0.0f; o.a.x = 0.0f; }
+        if (a.y == 0.0f) { o.r.y = 0.0f; o.g.y = 0.0f; o.b.y = 0.0f; o.a.y = 0.0f; }
+    }
+    return o;
+}
+
+// main.c:43-71: the stack's f32 result, truncated
+__device__ __forceinline__ u32x4 narrow_pair(px32x2 v) {
+    const float big = __builtin_fmaxf(
+        __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v.r.x), __builtin_fabsf(v.g.x)), __builtin_fabsf(v.b.x)), __builtin_fabsf(v.a.x)),
+        __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v.r.y), __builtin_fabsf(v.g.y)), __builtin_fabsf(v.b.y)), __builtin_fabsf(v.a.y)));
+    if (wave_any(big >= 65536.0f)) { v.r = saturate_to_inf2(v.r); v.g = saturate_to_inf2(v.g); v.b = saturate_to_inf2(v.b); v.a = saturate_to_inf2(v.a); }
+    return u32x4{ pkrtz(v.r.x, v.g.x), pkrtz(v.b.x, v.a.x), pkrtz(v.r.y, v.g.y), pkrtz(v.b.y, v.a.y) };
+}
+
+template <int NL, bool PRE, bool POST>
+__device__ __forceinline__ u32x4 chain_pair_lean(const u32x4 (&w)[NL], const Mat &mat, const uint16_t *lut, const uint16_t *post) {
+    px32x2 acc = grade_pair<PRE, POST>(w[0], mat, lut, post);
+#pragma unroll
+    for (int k = 1; k < NL; k++) acc = over_pair(acc, grade_pair<PRE, POST>(w[k], mat, lut, post));
+    return narrow_pair(acc);
+}
+
+}  // namespace cvs

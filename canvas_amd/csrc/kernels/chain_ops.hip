@@ -21,6 +21,7 @@
 // Bound: HBM.  Algorithmic bytes per output pixel: 8 * (nlayers + 1)  (config 2: 24).
 #include "lut_common.hpp"
 #include "grade.hpp"
+#include "chain_math.hpp"
 #include <stdlib.h>
 
 using namespace cvs;
@@ -236,7 +237,7 @@ __device__ __forceinline__ void st4_nt(void *p, size_t i, uint4 v) {
 }
 
 // NL in 1..4 (uniform per batch), P in {1, 2}; every job has npixels >= 2
-template <int NL, int P, bool PRE, bool POST, bool NT, int DIAG = 0>
+template <int NL, int P, bool PRE, bool POST, bool NT, int DIAG = 0, bool LEAN = false, int PF = 0>
 __global__ __launch_bounds__(kWG) void k_chain_pipe(Batch batch, int njobs, Mat mat,
                                                     const uint16_t *__restrict__ pre, const uint16_t *__restrict__ post) {
     __shared__ uint16_t lut[(PRE || POST) ? kLutHalfs : 1];
@@ -279,26 +280,53 @@ __global__ __launch_bounds__(kWG) void k_chain_pipe(Batch batch, int njobs, Mat 
             const size_t first = same ? nbase : lane;
             const size_t last = (same ? npairs : nnpairs) - 1;
             if (!same) primed = true;
+            auto prefetch = [&]() {
 #pragma unroll
-            for (int p = 0; p < P; p++) {
-                size_t idx = first + (size_t)p * stride;
-                idx = idx < last ? idx : last;
+                for (int p = 0; p < P; p++) {
+                    size_t idx = first + (size_t)p * stride;
+                    idx = idx < last ? idx : last;
 #pragma unroll
-                for (int k = 0; k < NL; k++) { if (DIAG == 2) nxt[p][k] = cur[p][k]; else asm_ld4<NT>(nxt[p][k], same ? lp[k] : nlp[k], idx); }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int k = 0; k < NL; k++) { if (DIAG == 2) nxt[p][k] = cur[p][k]; else asm_ld4<NT>(nxt[p][k], same ? lp[k] : nlp[k], idx); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (PF == 0) prefetch();
 
             // results first, into registers ...
             uint4 res[P];
+            if (LEAN && PF > 0) {
+                // same arithmetic as chain_pair_lean, opened up so that the prefetch can be issued part-way
+                // through the trip: fewer bytes in flight per CU for the same latency cover
+                px32x2 acc[P];
+#pragma unroll
+                for (int p = 0; p < P; p++) acc[p] = grade_pair<PRE, POST>(cur[p][0], mat, lut, post);
+                __builtin_amdgcn_sched_barrier(0);
+                if (PF == 1) prefetch();
+#pragma unroll
+                for (int k = 1; k < NL; k++) {
+#pragma unroll
+                    for (int p = 0; p < P; p++) acc[p] = over_pair(acc[p], grade_pair<PRE, POST>(cur[p][k], mat, lut, post));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (PF == 2) prefetch();
+#pragma unroll
+                for (int p = 0; p < P; p++) { const u32x4 r = narrow_pair(acc[p]); res[p] = make_uint4(r.x, r.y, r.z, r.w); }
+            } else {
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 const size_t idx = base + (size_t)p * stride;
                 if (idx < npairs) {
-                    uint4 w[NL];
+                    if (LEAN) {
+                        const u32x4 r = chain_pair_lean<NL, PRE, POST>(cur[p], mat, lut, post);
+                        res[p] = make_uint4(r.x, r.y, r.z, r.w);
+                    } else {
+                        uint4 w[NL];
 #pragma unroll
-                    for (int k = 0; k < NL; k++) w[k] = make_uint4(cur[p][k].x, cur[p][k].y, cur[p][k].z, cur[p][k].w);
-                    res[p] = chain_pair<NL, PRE, POST>(w, NL, mat, lut, post);
+                        for (int k = 0; k < NL; k++) w[k] = make_uint4(cur[p][k].x, cur[p][k].y, cur[p][k].z, cur[p][k].w);
+                        res[p] = chain_pair<NL, PRE, POST>(w, NL, mat, lut, post);
+                    }
                 }
+            }
             }
             __builtin_amdgcn_sched_barrier(0);
             // ... then ONE wait.  Measured on gfx950: a younger store can retire before an older load, so
@@ -347,6 +375,22 @@ template <int NL, int P>
 int launch_pipe_diag(const Batch &jobs, int njobs, const Mat &mat, const uint16_t *pre, const uint16_t *post, unsigned grid, unsigned block, hipStream_t s) {
     if (pre) hipLaunchKernelGGL((k_chain_pipe<NL, P, true, false, true, 2>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, pre, post);
     else     hipLaunchKernelGGL((k_chain_pipe<NL, P, false, false, true, 2>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, pre, post);
+    return (int)hipGetLastError();
+}
+
+template <int NL, int P, int PF>
+int launch_lean_pf(const Batch &jobs, int njobs, const Mat &mat, const uint16_t *pre, const uint16_t *post, unsigned grid, unsigned block, hipStream_t s) {
+    if (pre) hipLaunchKernelGGL((k_chain_pipe<NL, P, true, false, true, 0, true, PF>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, pre, post);
+    else     hipLaunchKernelGGL((k_chain_pipe<NL, P, false, false, true, 0, true, PF>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, pre, post);
+    return (int)hipGetLastError();
+}
+
+template <int NL, int P, int DIAG>
+int launch_lean(const Batch &jobs, int njobs, const Mat &mat, const uint16_t *pre, const uint16_t *post, unsigned grid, unsigned block, hipStream_t s) {
+    if (pre && post)  hipLaunchKernelGGL((k_chain_pipe<NL, P, true, true, true, DIAG, true>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, pre, post);
+    else if (pre)     hipLaunchKernelGGL((k_chain_pipe<NL, P, true, false, true, DIAG, true>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, pre, post);
+    else if (post)    hipLaunchKernelGGL((k_chain_pipe<NL, P, false, true, true, DIAG, true>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, pre, post);
+    else              hipLaunchKernelGGL((k_chain_pipe<NL, P, false, false, true, DIAG, true>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, pre, post);
     return (int)hipGetLastError();
 }
 
@@ -405,6 +449,13 @@ extern "C" int cvk_chain_color_over(const cvk_chain_job *jobs, int njobs, int un
         int rc;
 #define CVK_DISPATCH(NLV)                                                                   \
         (variant == 0 ? launch_v0<NLV>(b, n, mat, pre, post, grid, s)                      \
+         : variant == 6 ? launch_lean<NLV, 2, 0>(b, n, mat, pre, post, grid, block, s)      \
+         : variant == 7 ? launch_lean<NLV, 1, 0>(b, n, mat, pre, post, grid, block, s)      \
+         : variant == 71 ? launch_lean_pf<NLV, 1, 1>(b, n, mat, pre, post, grid, block, s)  \
+         : variant == 72 ? launch_lean_pf<NLV, 1, 2>(b, n, mat, pre, post, grid, block, s)  \
+         : variant == 61 ? launch_lean_pf<NLV, 2, 1>(b, n, mat, pre, post, grid, block, s)  \
+         : variant == 62 ? launch_lean_pf<NLV, 2, 2>(b, n, mat, pre, post, grid, block, s)  \
+         : variant == 16 ? launch_lean<NLV, 2, 2>(b, n, mat, pre, post, grid, block, s)     \
          : variant == 12 ? launch_pipe_diag<NLV, 2>(b, n, mat, pre, post, grid, block, s)   \
          : variant == 13 ? launch_pipe_diag<NLV, 1>(b, n, mat, pre, post, grid, block, s)   \
          : variant == 10 ? launch_diag<NLV, 2>(b, n, mat, pre, post, grid * gridmul, s)     \
