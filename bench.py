@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--translucent-base", action="store_true",
+                    help="NOT the BASELINE input: random alpha on layer 0 as well, so every divide of the over operator is live")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -148,7 +150,7 @@ def main():
         layers = []
         for k in range(nl):
             d = DeviceFrame(full, np.uint16)
-            d.upload(synth.layer_pixels(w, h, k, g))
+            d.upload(synth.layer_pixels(w, h, k, g, opaque_base=not args.translucent_base))
             layers.append(d)
         ring.append((DeviceFrame(full, np.uint16), layers))
 
@@ -194,7 +196,7 @@ def main():
             import oracle
             rows = 4
             from canvas_amd.abi import HostFrame
-            heads = [HostFrame((0, 0, w - 1, rows - 1), np.uint16, synth.layer_pixels(w, h, k, my_frames[0])[:rows]) for k in range(nl)]
+            heads = [HostFrame((0, 0, w - 1, rows - 1), np.uint16, synth.layer_pixels(w, h, k, my_frames[0], opaque_base=not args.translucent_base)[:rows]) for k in range(nl)]
             want = oracle.chain_color_over(heads, m, oracle.transfer_table(0), None)
             got = ring[0][0].download(stream).array[:rows]
             verified = bool(np.array_equal(got, want.array))
@@ -226,7 +228,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f16 storage, f32 arithmetic",
-            "data": "synthetic (Philox, seed 0xC0FFEE+1000*layer+frame), resident in HBM",
+            "data": "synthetic (Philox, seed 0xC0FFEE+1000*layer+frame), resident in HBM" + (
+                "; NON-BASELINE variant: random alpha on layer 0 too" if args.translucent_base else ""),
             "config": {"workload": "%dx%d f16 RGBA, Rec.709->linear LUT + RGB->Y'PbPr 3x3 on %d layers + %d-layer alpha-over, f16 out" % (w, h, nl, nl),
                        "frames_per_step_per_gpu": args.batch, "ring_frames_per_gpu": len(ring),
                        "sharding": "frame g -> gpu g %% %d, no data-path collective" % world},

@@ -21,11 +21,13 @@ def truncate_to_half(x):
     return codes
 
 
-def layer_pixels(width, height, layer, frame):
+def layer_pixels(width, height, layer, frame, opaque_base=True):
+    """opaque_base=False is NOT the BASELINE input: it gives layer 0 a random alpha too, so that the
+    over operator's divides see denominators other than 1.0 (bench.py --translucent-base)."""
     rng = np.random.Generator(np.random.Philox(SEED_BASE + 1000 * layer + frame))
     px = rng.random((height, width, 4), dtype=np.float32)
     codes = truncate_to_half(px)
-    if layer == 0:
+    if layer == 0 and opaque_base:
         codes[..., 3] = 0x3C00
     return codes
 

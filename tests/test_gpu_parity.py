@@ -384,6 +384,30 @@ def test_chain_fused_matches_oracle(cvs, orc, nlayers, size):
     assert_same_f16(got.array, want.array, "fused chain, %d layers" % nlayers)
 
 
+@pytest.mark.parametrize("nlayers", [2, 3, 4])
+def test_chain_fused_with_live_divides(cvs, orc, nlayers):
+    """Every layer translucent (alpha 0, 1 and in between, per pixel): the x/1.0 shortcut of the kernel
+    must not be taken where the blended alpha is not exactly 1, and alpha 0 must give the zero pixel."""
+    rng = np.random.default_rng(100 + nlayers)
+    full = (0, 0, 95, 53)
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    from tests.util import rand_f32_frame
+    from canvas_amd.synth import truncate_to_half
+    layers = []
+    for k in range(nlayers):
+        f = rand_f32_frame(rng, full, full, alpha="mixed", lo=-0.25, hi=1.5)   # out-of-gamut values too
+        layers.append(HostFrame(full, np.uint16, truncate_to_half(f.array)))
+    layers[1].array[3, 5] = [0x7BFF, 0x7BFF, 0xFBFF, 0x3C00]                  # 65504: pushes sums past the half range
+    layers[0].array[3, 5] = [0x7BFF, 0x7BFF, 0xFBFF, 0x3800]
+    want = orc.chain_color_over(layers, m, orc.transfer_table(0), None)
+    dl = [DeviceFrame.from_host(l) for l in layers]
+    out = DeviceFrame(full, np.uint16)
+    chain_color_over([(out, dl)], m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE)
+    _lib.check(cvs.cvs_stream_sync(None))
+    assert cvs.cvs_chain_last_was_fused() == 1
+    assert_same_f16(out.download().array, want.array, "fused chain, translucent layers")
+
+
 def test_chain_batch_and_lut_variants(cvs, orc):
     m = np.array(REC709_RGB_TO_YPBPR, np.float32)
     for pre, post in [(-1, -1), (-1, 2), (0, 3)]:
