@@ -89,6 +89,9 @@ SIGNATURES = {
     "cvs_compute_units": (C.c_int, []),
     "cvs_malloc": (_vp, [C.c_size_t]),
     "cvs_free": (None, [_vp]),
+    "cvs_pool_malloc": (_vp, [C.c_size_t, _vp]),
+    "cvs_pool_free": (None, [_vp, _vp]),
+    "cvs_pool_trim": (None, []),
     "cvs_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "cvs_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
     "cvs_memcpy_d2d": (C.c_int, [_vp, _vp, C.c_size_t, _vp]),

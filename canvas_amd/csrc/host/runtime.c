@@ -148,6 +148,70 @@ CVS_EXPORT int cvs_stream_sync(cvs_stream_t s) {
     return 0;
 }
 
+/* ---- scratch pool: intermediates of a filter graph (f32 temps, pulled layers) come and go once per
+ * frame; hipFree synchronises the device and hipMalloc costs tens of microseconds, so freed blocks
+ * are parked and handed back to the next request of the same size.  A block remembers the stream it
+ * was last used on; handing it to a different stream first waits for that stream. */
+#define POOL_SLOTS 64
+static struct { void *ptr; size_t bytes; hipStream_t stream; int live; } g_pool[POOL_SLOTS];
+static size_t g_pool_parked;                         /* bytes sitting idle in the pool */
+static const size_t kPoolParkedMax = (size_t)8 << 30;
+
+CVS_EXPORT void *cvs_pool_malloc(size_t bytes, cvs_stream_t s) {
+    if (cvs_enter() != 0) return NULL;
+    if (!bytes) bytes = 1;
+    hipStream_t st = cvs_pick_stream(s);
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < POOL_SLOTS; i++)
+        if (g_pool[i].ptr && !g_pool[i].live && g_pool[i].bytes == bytes) {
+            g_pool[i].live = 1;
+            g_pool_parked -= bytes;
+            hipStream_t prev = g_pool[i].stream;
+            void *p = g_pool[i].ptr;
+            g_pool[i].stream = st;
+            pthread_mutex_unlock(&g_lock);
+            if (prev != st) hipStreamSynchronize(prev);
+            return p;
+        }
+    pthread_mutex_unlock(&g_lock);
+    void *p = NULL;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { cvs_set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return NULL; }
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < POOL_SLOTS; i++)
+        if (!g_pool[i].ptr) { g_pool[i].ptr = p; g_pool[i].bytes = bytes; g_pool[i].stream = st; g_pool[i].live = 1; break; }
+    pthread_mutex_unlock(&g_lock);      /* table full: the block is simply untracked and freed directly later */
+    return p;
+}
+
+CVS_EXPORT void cvs_pool_free(void *dev, cvs_stream_t s) {
+    if (!dev || cvs_enter() != 0) return;
+    hipStream_t st = cvs_pick_stream(s);
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < POOL_SLOTS; i++)
+        if (g_pool[i].ptr == dev) {
+            if (g_pool_parked + g_pool[i].bytes <= kPoolParkedMax) {
+                g_pool[i].live = 0;
+                g_pool[i].stream = st;
+                g_pool_parked += g_pool[i].bytes;
+                pthread_mutex_unlock(&g_lock);
+                return;
+            }
+            g_pool[i].ptr = NULL;
+            break;
+        }
+    pthread_mutex_unlock(&g_lock);
+    hipFree(dev);
+}
+
+CVS_EXPORT void cvs_pool_trim(void) {
+    if (cvs_enter() != 0) return;
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < POOL_SLOTS; i++)
+        if (g_pool[i].ptr && !g_pool[i].live) { hipFree(g_pool[i].ptr); g_pool_parked -= g_pool[i].bytes; g_pool[i].ptr = NULL; }
+    pthread_mutex_unlock(&g_lock);
+}
+
 CVS_EXPORT cvs_event_t cvs_event_create(void) {
     hipEvent_t e = NULL;
     if (cvs_enter() != 0) return NULL;

@@ -1,0 +1,301 @@
+/*
+ * pyframes.c -- RgbaFrameF16 / RgbaFrameF32 (host-resident result frames that are themselves video
+ * sources), VideoSource.get_frame_f16/f32, and the constant-time frame functions.
+ *
+ * Surface kept from src/process/RgbaFrameF16.c:58-63,100-157,185-260 and RgbaFrameF32.c:
+ *   attributes full_window / current_window (basetypes.box2i), len(frame), frame[i] -> rgba,
+ *   pixel(x, y) -> rgba or None outside current_window, to_argb32_bytes(); a frame pulled through
+ *   get_frame_f16/f32 re-windows itself with video_copy_frame_f16 / video_copy_frame_alpha_f32.
+ * Frame functions: src/process/basicframefuncs.c:69-177 (LinearFrameFunc, LerpFunc) and
+ *   :362-456 (FrameFunction.get_values).
+ */
+#include "pyext.h"
+
+/* ---------------------------------------------------------------- frame objects */
+
+typedef struct { PyObject_HEAD rgba_frame_f16 frame; } py_frame16;
+typedef struct { PyObject_HEAD rgba_frame_f32 frame; } py_frame32;
+
+static PyTypeObject py_type_RgbaFrameF16, py_type_RgbaFrameF32;
+static PyObject *frame16_capsule, *frame32_capsule;
+
+static void frame16_as_source16(py_frame16 *self, int frame_index, rgba_frame_f16 *out) { video_copy_frame_f16(out, &self->frame); }
+static void frame32_as_source32(py_frame32 *self, int frame_index, rgba_frame_f32 *out) { video_copy_frame_alpha_f32(out, &self->frame, 1.0f); }
+
+static video_frame_source_funcs frame16_funcs = { .flags = 0, .get_frame = (video_get_frame_func)frame16_as_source16 };
+static video_frame_source_funcs frame32_funcs = { .flags = 0, .get_frame_32 = (video_get_frame_32_func)frame32_as_source32 };
+
+static void frame16_dealloc(py_frame16 *self) { PyMem_Free(self->frame.data); Py_TYPE(self)->tp_free((PyObject *)self); }
+static void frame32_dealloc(py_frame32 *self) { PyMem_Free(self->frame.data); Py_TYPE(self)->tp_free((PyObject *)self); }
+
+PyObject *py_RgbaFrameF16_new(box2i *full_window, rgba_frame_f16 **frame) {
+    py_frame16 *f = (py_frame16 *)py_type_RgbaFrameF16.tp_alloc(&py_type_RgbaFrameF16, 0);
+    if (!f) return NULL;
+    f->frame.full_window = *full_window;
+    box2i_set_empty(&f->frame.current_window);
+    size_t bytes = frame_bytes(full_window, CVS_FORMAT_F16);
+    f->frame.data = PyMem_Malloc(bytes ? bytes : 1);
+    if (!f->frame.data) { Py_DECREF(f); return PyErr_NoMemory(); }
+    if (frame) *frame = &f->frame;
+    return (PyObject *)f;
+}
+
+PyObject *py_RgbaFrameF32_new(box2i *full_window, rgba_frame_f32 **frame) {
+    py_frame32 *f = (py_frame32 *)py_type_RgbaFrameF32.tp_alloc(&py_type_RgbaFrameF32, 0);
+    if (!f) return NULL;
+    f->frame.full_window = *full_window;
+    box2i_set_empty(&f->frame.current_window);
+    size_t bytes = frame_bytes(full_window, CVS_FORMAT_F32);
+    f->frame.data = PyMem_Malloc(bytes ? bytes : 1);
+    if (!f->frame.data) { Py_DECREF(f); return PyErr_NoMemory(); }
+    if (frame) *frame = &f->frame;
+    return (PyObject *)f;
+}
+
+static bool parse_pull_args(PyObject *args, PyObject *kw, int *frame_index, box2i *window) {
+    static char *kwlist[] = { "frame_index", "data_window", "force_gl", NULL };
+    PyObject *window_obj = NULL, *force_gl = NULL;      /* force_gl is accepted and ignored: there is no GL path */
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "iO|O", kwlist, frame_index, &window_obj, &force_gl)) return false;
+    return py_parse_box2i(window_obj, window);
+}
+
+PyObject *py_get_frame_f16(PyObject *self, PyObject *args, PyObject *kw) {
+    int frame_index; box2i window; rgba_frame_f16 *frame;
+    if (!parse_pull_args(args, kw, &frame_index, &window)) return NULL;
+    PyObject *result = py_RgbaFrameF16_new(&window, &frame);
+    if (!result) return NULL;
+    video_source *source = NULL;
+    if (!py_video_take_source(self, &source)) { Py_DECREF(result); return NULL; }
+    frame->current_window = frame->full_window;
+    video_get_frame_f16(source, frame_index, frame);
+    py_video_take_source(NULL, &source);
+    return result;
+}
+
+PyObject *py_get_frame_f32(PyObject *self, PyObject *args, PyObject *kw) {
+    int frame_index; box2i window; rgba_frame_f32 *frame;
+    if (!parse_pull_args(args, kw, &frame_index, &window)) return NULL;
+    PyObject *result = py_RgbaFrameF32_new(&window, &frame);
+    if (!result) return NULL;
+    video_source *source = NULL;
+    if (!py_video_take_source(self, &source)) { Py_DECREF(result); return NULL; }
+    frame->current_window = frame->full_window;
+    video_get_frame_f32(source, frame_index, frame);
+    py_video_take_source(NULL, &source);
+    return result;
+}
+
+static PyObject *frame16_full(py_frame16 *self, void *c) { return py_make_box2i(&self->frame.full_window); }
+static PyObject *frame16_current(py_frame16 *self, void *c) { return py_make_box2i(&self->frame.current_window); }
+static PyObject *frame32_full(py_frame32 *self, void *c) { return py_make_box2i(&self->frame.full_window); }
+static PyObject *frame32_current(py_frame32 *self, void *c) { return py_make_box2i(&self->frame.current_window); }
+
+static Py_ssize_t frame16_len(py_frame16 *self) { v2i s; box2i_get_size(&self->frame.full_window, &s); return (Py_ssize_t)s.x * s.y; }
+static Py_ssize_t frame32_len(py_frame32 *self) { v2i s; box2i_get_size(&self->frame.full_window, &s); return (Py_ssize_t)s.x * s.y; }
+
+/* one pixel f16 -> rgba: through the library's converter (half.c pointer), like RgbaFrameF16.c:74-79 */
+static PyObject *pixel16_to_python(const rgba_f16 *p) {
+    rgba_f32 c;
+    half_convert_to_float(&c.r, &p->r, 4);
+    return py_make_rgba_f32(&c);
+}
+
+static PyObject *frame16_item(py_frame16 *self, Py_ssize_t i) {
+    if (i < 0 || i >= frame16_len(self)) { PyErr_SetString(PyExc_IndexError, "Index was out of range."); return NULL; }
+    return pixel16_to_python(&self->frame.data[i]);
+}
+static PyObject *frame32_item(py_frame32 *self, Py_ssize_t i) {
+    if (i < 0 || i >= frame32_len(self)) { PyErr_SetString(PyExc_IndexError, "Index was out of range."); return NULL; }
+    return py_make_rgba_f32(&self->frame.data[i]);
+}
+
+static bool inside(const box2i *w, int x, int y) { return x >= w->min.x && x <= w->max.x && y >= w->min.y && y <= w->max.y; }
+
+static PyObject *frame16_pixel(py_frame16 *self, PyObject *args) {
+    int x, y;
+    if (!PyArg_ParseTuple(args, "ii", &x, &y)) return NULL;
+    if (!inside(&self->frame.current_window, x, y)) Py_RETURN_NONE;
+    return pixel16_to_python(video_get_pixel_f16(&self->frame, x, y));
+}
+static PyObject *frame32_pixel(py_frame32 *self, PyObject *args) {
+    int x, y;
+    if (!PyArg_ParseTuple(args, "ii", &x, &y)) return NULL;
+    if (!inside(&self->frame.current_window, x, y)) Py_RETURN_NONE;
+    return py_make_rgba_f32(video_get_pixel_f32(&self->frame, x, y));
+}
+
+/* RgbaFrameF16.c:114-149: gamma-0.45 ramp per channel, premultiplied ARGB32, current_window only */
+static PyObject *frame16_to_argb32(py_frame16 *self, PyObject *args) {
+    const box2i *w = &self->frame.current_window;
+    if (box2i_is_empty(w)) Py_RETURN_NONE;
+    const uint8_t *ramp = video_get_gamma45_ramp();
+    if (!ramp) { PyErr_SetString(PyExc_RuntimeError, cvs_last_error()); return NULL; }
+    v2i size;
+    box2i_get_size(w, &size);
+    PyObject *result = PyByteArray_FromStringAndSize(NULL, (Py_ssize_t)size.x * size.y * 4);
+    if (!result) return NULL;
+    uint32_t *out = (uint32_t *)PyByteArray_AS_STRING(result);
+    for (int y = w->min.y; y <= w->max.y; y++) {
+        const rgba_f16 *row = video_get_pixel_f16(&self->frame, w->min.x, y);
+        for (int x = 0; x < size.x; x++) {
+            uint32_t a = ramp[row[x].a];
+            *out++ = (a << 24) | (((ramp[row[x].r] * a >> 8) & 0xFF) << 16) | (((ramp[row[x].g] * a >> 8) & 0xFF) << 8) | ((ramp[row[x].b] * a >> 8) & 0xFF);
+        }
+    }
+    return result;
+}
+
+static PyGetSetDef frame16_getset[] = {
+    { VIDEO_FRAME_SOURCE_FUNCS, pyext_capsule_getter, NULL, "Video frame source C API.", &frame16_capsule },
+    { "full_window", (getter)frame16_full, NULL, "The full data window for this frame." },
+    { "current_window", (getter)frame16_current, NULL, "The current (defined) data window for this frame." },
+    { NULL }
+};
+static PyGetSetDef frame32_getset[] = {
+    { VIDEO_FRAME_SOURCE_FUNCS, pyext_capsule_getter, NULL, "Video frame source C API.", &frame32_capsule },
+    { "full_window", (getter)frame32_full, NULL, "The full data window for this frame." },
+    { "current_window", (getter)frame32_current, NULL, "The current (defined) data window for this frame." },
+    { NULL }
+};
+static PyMethodDef frame16_methods[] = {
+    { "pixel", (PyCFunction)frame16_pixel, METH_VARARGS, "pixel(x, y) -> rgba, or None outside current_window" },
+    { "to_argb32_bytes", (PyCFunction)frame16_to_argb32, METH_VARARGS, "Premultiplied ARGB32 of the defined window (gamma 0.45), for QImage." },
+    { NULL }
+};
+static PyMethodDef frame32_methods[] = {
+    { "pixel", (PyCFunction)frame32_pixel, METH_VARARGS, "pixel(x, y) -> rgba, or None outside current_window" },
+    { NULL }
+};
+static PySequenceMethods frame16_seq = { .sq_length = (lenfunc)frame16_len, .sq_item = (ssizeargfunc)frame16_item };
+static PySequenceMethods frame32_seq = { .sq_length = (lenfunc)frame32_len, .sq_item = (ssizeargfunc)frame32_item };
+
+static PyTypeObject py_type_RgbaFrameF16 = {
+    PyVarObject_HEAD_INIT(NULL, 0)
+    .tp_name = "fluggo.media.process.RgbaFrameF16", .tp_basicsize = sizeof(py_frame16), .tp_flags = Py_TPFLAGS_DEFAULT,
+    .tp_base = &py_type_VideoSource, .tp_dealloc = (destructor)frame16_dealloc,
+    .tp_getset = frame16_getset, .tp_methods = frame16_methods, .tp_as_sequence = &frame16_seq,
+};
+static PyTypeObject py_type_RgbaFrameF32 = {
+    PyVarObject_HEAD_INIT(NULL, 0)
+    .tp_name = "fluggo.media.process.RgbaFrameF32", .tp_basicsize = sizeof(py_frame32), .tp_flags = Py_TPFLAGS_DEFAULT,
+    .tp_base = &py_type_VideoSource, .tp_dealloc = (destructor)frame32_dealloc,
+    .tp_getset = frame32_getset, .tp_methods = frame32_methods, .tp_as_sequence = &frame32_seq,
+};
+
+int init_frames(PyObject *module) {
+    if (pyext_make_capsule(&frame16_capsule, &frame16_funcs) < 0 || pyext_make_capsule(&frame32_capsule, &frame32_funcs) < 0) return -1;
+    if (pyext_add_type(module, "RgbaFrameF16", &py_type_RgbaFrameF16) < 0) return -1;
+    return pyext_add_type(module, "RgbaFrameF32", &py_type_RgbaFrameF32);
+}
+
+/* ---------------------------------------------------------------- frame functions */
+
+static PyObject *framefunc_get_values(PyObject *self, PyObject *args) {
+    PyObject *frames_obj;
+    if (!PyArg_ParseTuple(args, "O", &frames_obj)) return NULL;
+    Py_ssize_t count = 1;
+    double *frames = NULL;
+    if (PySequence_Check(frames_obj)) {
+        PyObject *fast = PySequence_Fast(frames_obj, "expected a number or a sequence of numbers");
+        if (!fast) return NULL;
+        count = PySequence_Fast_GET_SIZE(fast);
+        frames = PyMem_Malloc(sizeof(double) * (size_t)(count ? count : 1));
+        for (Py_ssize_t i = 0; frames && i < count; i++) frames[i] = PyFloat_AsDouble(PySequence_Fast_GET_ITEM(fast, i));
+        Py_DECREF(fast);
+    } else {
+        frames = PyMem_Malloc(sizeof(double));
+        if (frames) frames[0] = PyFloat_AsDouble(frames_obj);
+    }
+    if (!frames) return PyErr_NoMemory();
+    if (PyErr_Occurred()) { PyMem_Free(frames); return NULL; }
+
+    FrameFunctionHolder holder = { 0 };
+    if (!py_framefunc_take_source(self, &holder)) { PyMem_Free(frames); return NULL; }
+    PyObject *result = PyList_New(count);
+    double (*values)[4] = PyMem_Malloc(sizeof(double) * 4 * (size_t)(count ? count : 1));
+    if (result && values) {
+        if (holder.funcs && holder.funcs->get_values) holder.funcs->get_values(holder.source, count, frames, values);
+        else for (Py_ssize_t i = 0; i < count; i++) memcpy(values[i], holder.constant, sizeof holder.constant);
+        for (Py_ssize_t i = 0; i < count; i++)
+            PyList_SET_ITEM(result, i, Py_BuildValue("dddd", values[i][0], values[i][1], values[i][2], values[i][3]));
+    }
+    PyMem_Free(values);
+    PyMem_Free(frames);
+    py_framefunc_take_source(NULL, &holder);
+    return result;
+}
+
+static PyMethodDef FrameFunction_methods[] = {
+    { "get_values", framefunc_get_values, METH_VARARGS, "value_list = func.get_values(frame or [frames])" },
+    { NULL }
+};
+
+CVS_EXPORT PyTypeObject py_type_FrameFunction = {
+    PyVarObject_HEAD_INIT(NULL, 0)
+    .tp_name = "fluggo.media.process.FrameFunction", .tp_basicsize = sizeof(PyObject),
+    .tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_BASETYPE, .tp_methods = FrameFunction_methods, .tp_new = PyType_GenericNew,
+};
+
+/* f(frame) = a * frame + b in slot 0 (basicframefuncs.c:69-101) */
+typedef struct { PyObject_HEAD double a, b; } py_linear;
+static PyObject *linear_capsule;
+static int linear_init(py_linear *self, PyObject *args, PyObject *kw) {
+    static char *kwlist[] = { "a", "b", NULL };
+    return PyArg_ParseTupleAndKeywords(args, kw, "dd", kwlist, &self->a, &self->b) ? 0 : -1;
+}
+static void linear_values(py_linear *self, ssize_t count, double *frames, double (*out)[4]) {
+    for (ssize_t i = 0; i < count; i++) { out[i][0] = frames[i] * self->a + self->b; out[i][1] = out[i][2] = out[i][3] = 0.0; }
+}
+static FrameFunctionFuncs linear_funcs = { 0, (framefunc_get_values_func)linear_values };
+static PyGetSetDef linear_getset[] = { { FRAME_FUNCTION_FUNCS, pyext_capsule_getter, NULL, "Frame function C API.", &linear_capsule }, { NULL } };
+static PyTypeObject py_type_LinearFrameFunc = {
+    PyVarObject_HEAD_INIT(NULL, 0)
+    .tp_name = "fluggo.media.process.LinearFrameFunc", .tp_basicsize = sizeof(py_linear), .tp_flags = Py_TPFLAGS_DEFAULT,
+    .tp_base = &py_type_FrameFunction, .tp_new = PyType_GenericNew, .tp_init = (initproc)linear_init, .tp_getset = linear_getset,
+};
+
+/* four-slot linear interpolation start -> end over `length` frames, extrapolating (basicframefuncs.c:104-177) */
+typedef struct { PyObject_HEAD float start[4], end[4]; double length; } py_lerp;
+static PyObject *lerp_capsule;
+static bool read4(PyObject *obj, float out[4], const char *what) {
+    PyObject *fast = PySequence_Fast(obj, what);
+    if (!fast) return false;
+    for (Py_ssize_t i = 0; i < 4; i++)
+        out[i] = i < PySequence_Fast_GET_SIZE(fast) ? (float)PyFloat_AsDouble(PySequence_Fast_GET_ITEM(fast, i)) : 0.0f;
+    Py_DECREF(fast);
+    return !PyErr_Occurred();
+}
+static int lerp_init(py_lerp *self, PyObject *args, PyObject *kw) {
+    static char *kwlist[] = { "start", "end", "length", NULL };
+    PyObject *s, *e;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "OOd", kwlist, &s, &e, &self->length)) return -1;
+    if (self->length <= 0.0) { PyErr_SetString(PyExc_Exception, "length must be greater than zero."); return -1; }
+    /* box2i-style arguments ((x0,y0),(x1,y1)) flatten to four numbers */
+    box2f b;
+    if (PyTuple_Check(s) && PyTuple_GET_SIZE(s) == 2 && PyTuple_Check(PyTuple_GET_ITEM(s, 0)) && py_parse_box2f(s, &b)) { self->start[0] = b.min.x; self->start[1] = b.min.y; self->start[2] = b.max.x; self->start[3] = b.max.y; }
+    else { PyErr_Clear(); if (!read4(s, self->start, "Expected a tuple or list for start.")) return -1; }
+    if (PyTuple_Check(e) && PyTuple_GET_SIZE(e) == 2 && PyTuple_Check(PyTuple_GET_ITEM(e, 0)) && py_parse_box2f(e, &b)) { self->end[0] = b.min.x; self->end[1] = b.min.y; self->end[2] = b.max.x; self->end[3] = b.max.y; }
+    else { PyErr_Clear(); if (!read4(e, self->end, "Expected a tuple or list for end.")) return -1; }
+    return 0;
+}
+static void lerp_values(py_lerp *self, ssize_t count, double *frames, double (*out)[4]) {
+    for (ssize_t i = 0; i < count; i++)
+        for (int k = 0; k < 4; k++)
+            out[i][k] = frames[i] * (self->end[k] - self->start[k]) / self->length + self->start[k];
+}
+static FrameFunctionFuncs lerp_funcs = { 0, (framefunc_get_values_func)lerp_values };
+static PyGetSetDef lerp_getset[] = { { FRAME_FUNCTION_FUNCS, pyext_capsule_getter, NULL, "Frame function C API.", &lerp_capsule }, { NULL } };
+static PyTypeObject py_type_LerpFunc = {
+    PyVarObject_HEAD_INIT(NULL, 0)
+    .tp_name = "fluggo.media.process.LerpFunc", .tp_basicsize = sizeof(py_lerp), .tp_flags = Py_TPFLAGS_DEFAULT,
+    .tp_base = &py_type_FrameFunction, .tp_new = PyType_GenericNew, .tp_init = (initproc)lerp_init, .tp_getset = lerp_getset,
+};
+
+int init_framefuncs(PyObject *module) {
+    linear_capsule = PyCapsule_New(&linear_funcs, FRAME_FUNCTION_FUNCS, NULL);
+    lerp_capsule = PyCapsule_New(&lerp_funcs, FRAME_FUNCTION_FUNCS, NULL);
+    if (!linear_capsule || !lerp_capsule) return -1;
+    if (pyext_add_type(module, "FrameFunction", &py_type_FrameFunction) < 0) return -1;
+    if (pyext_add_type(module, "LinearFrameFunc", &py_type_LinearFrameFunc) < 0) return -1;
+    return pyext_add_type(module, "LerpFunc", &py_type_LerpFunc);
+}

@@ -225,6 +225,11 @@ CVS_EXPORT int cvs_compute_units(void);
 
 CVS_EXPORT void *cvs_malloc(size_t bytes);
 CVS_EXPORT void cvs_free(void *dev);
+/* recycled scratch for per-frame intermediates (no device sync on free, unlike hipFree); a block
+ * handed to a different stream than it was last used on waits for that stream first */
+CVS_EXPORT void *cvs_pool_malloc(size_t bytes, cvs_stream_t s);
+CVS_EXPORT void cvs_pool_free(void *dev, cvs_stream_t s);
+CVS_EXPORT void cvs_pool_trim(void);
 CVS_EXPORT int cvs_memcpy_h2d(void *dev, const void *host, size_t bytes, cvs_stream_t s);
 CVS_EXPORT int cvs_memcpy_d2h(void *host, const void *dev, size_t bytes, cvs_stream_t s);
 CVS_EXPORT int cvs_memcpy_d2d(void *dst, const void *src, size_t bytes, cvs_stream_t s);

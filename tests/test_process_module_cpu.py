@@ -1,0 +1,160 @@
+"""fluggo.media.process, CPU side: the module imports, exposes the reference's Python surface
+(SURVEY.md section 8b), and its parameter / bookkeeping logic is right.  No pixels are produced here:
+without a GPU every pull reports an empty window (and says why)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def process():
+    try:
+        from fluggo.media import process
+    except ImportError:
+        import __graft_entry__
+        __graft_entry__.build()
+        from fluggo.media import process
+    return process
+
+
+def test_surface_is_complete(process):
+    for name in ["VideoSource", "RgbaFrameF16", "RgbaFrameF32", "SolidColorVideoSource", "EmptyVideoSource",
+                 "VideoGainOffsetFilter", "VideoMixFilter", "VideoScaler", "VideoPassThroughFilter", "VideoSequence",
+                 "VideoWorkspace", "VideoPullQueue", "FrameFunction", "LerpFunc", "LinearFrameFunc",
+                 "get_frame_time", "get_time_frame", "time_get_frame", "enable_glib_logging",
+                 "create_offscreen_gl_context", "set_current_gl_context", "check_context_supported"]:
+        assert hasattr(process, name), name
+    for t in [process.SolidColorVideoSource, process.VideoMixFilter, process.VideoWorkspace, process.VideoSequence,
+              process.VideoPassThroughFilter, process.RgbaFrameF16]:
+        assert issubclass(t, process.VideoSource)
+        assert hasattr(t, "get_frame_f16") and hasattr(t, "get_frame_f32")
+
+
+def test_every_source_carries_the_named_capsule(process):
+    from fluggo.media.basetypes import box2i
+    solid = process.SolidColorVideoSource((0, 0, 0, 1))
+    objs = [solid, process.EmptyVideoSource(), process.VideoGainOffsetFilter(solid), process.VideoMixFilter(solid, solid, 0.5),
+            process.VideoScaler(solid, (0, 0), (0, 0), (2, 2), box2i(0, 0, 9, 9)), process.VideoPassThroughFilter(solid),
+            process.VideoSequence(), process.VideoWorkspace()]
+    for o in objs:
+        cap = o._video_frame_source_funcs
+        assert type(cap).__name__ == "PyCapsule" and '"_video_frame_source_funcs"' in repr(cap)
+    with pytest.raises(Exception):
+        process.VideoPassThroughFilter(object())            # no capsule -> refused (src/process/main.c:52-58)
+    process.VideoPassThroughFilter(None)                    # None is "no source"
+
+
+def test_lerp_func_kat(process):
+    """tests/process/frame_func.py:13-29 of the reference."""
+    func = process.LerpFunc((1.0, 2.0, 3.0, 4.0), (-1.0, -2.0, -3.0, -4.0), 4)
+    want = {0: (1.0, 2.0, 3.0, 4.0), 1: (0.5, 1.0, 1.5, 2.0), 2: (0.0, 0.0, 0.0, 0.0), 3: (-0.5, -1.0, -1.5, -2.0), 4: (-1.0, -2.0, -3.0, -4.0)}
+    for frame, values in want.items():
+        assert func.get_values(frame)[0] == pytest.approx(values)
+    got = func.get_values([4, 1, 2, 0, 3])
+    for g, f in zip(got, [4, 1, 2, 0, 3]):
+        assert g == pytest.approx(want[f])
+    lin = process.LinearFrameFunc(2.0, -1.0)
+    assert lin.get_values([0, 1.5])[1] == pytest.approx((2.0, 0, 0, 0))
+    assert isinstance(func, process.FrameFunction)
+    with pytest.raises(Exception):
+        process.LerpFunc((0,), (1,), 0)
+
+
+def test_basetypes(process):
+    from fluggo.media.basetypes import box2f, box2i, rgba, v2f, v2i
+    assert box2i(0, 0, 3, 3) == box2i((0, 0), (3, 3)) == ((0, 0), (3, 3))
+    assert box2i(0, 0, 3, 3).width == 4 and box2i(0, 0, 3, 2).height == 3 and box2i(0, 0, 3, 3).size() == v2i(4, 4)
+    assert box2i().empty() and not box2i() and box2i(2, 2, 1, 5).empty() and bool(box2i(0, 0, 0, 0))
+    assert v2i(1, 2) + v2i(3, 4) == (4, 6) and v2f((1, 2)) - (0.5, 0.5) == (0.5, 1.5)
+    assert rgba(1, 0.5, 0.25) == (1.0, 0.5, 0.25, 1.0)
+    assert repr(box2i(0, 0, 3, 3)) == "box2i(v2i(0, 0), v2i(3, 3))"
+    assert box2f(0, 0, 1.5, 2).width == 2.5
+
+
+def test_frame_time_functions(process):
+    from fractions import Fraction
+    ntsc = Fraction(30000, 1001)
+    assert process.get_frame_time(ntsc, 0) == 1
+    for f in (0, 1, 29, 30, 1000):
+        assert process.get_time_frame(ntsc, process.get_frame_time(ntsc, f)) == f
+    assert process.get_frame_time(24, 24) == 10 ** 9 + 1
+
+
+def test_sequence_list_protocol(process):
+    red = process.SolidColorVideoSource((1, 0, 0, 1))
+    seq = process.VideoSequence()
+    seq.append((red, 1, 10))
+    seq.append((red, 1, 5))
+    seq.insert(1, (red, 0, 3))
+    assert len(seq) == 3
+    assert [seq.get_start_frame(i) for i in range(3)] == [0, 10, 13]
+    assert seq[1][2] == 3 and seq[1][0] is red
+    seq[0] = (red, 2, 4)
+    assert [seq.get_start_frame(i) for i in range(3)] == [0, 4, 7]
+    del seq[1]
+    assert len(seq) == 2 and seq.get_start_frame(1) == 4
+    with pytest.raises(ValueError):
+        seq.append((red, 0, -1))
+    with pytest.raises(IndexError):
+        seq[5]
+
+
+def test_workspace_items(process):
+    red = process.SolidColorVideoSource((1, 0, 0, 1))
+    green = process.SolidColorVideoSource((0, 1, 0, 1))
+    ws = process.VideoWorkspace()
+    a = ws.add(source=red, x=10, length=5, z=3, offset=0, tag="a")
+    b = ws.add(source=green, x=0, length=20, z=9, offset=7, tag="b")
+    assert len(ws) == 2 and ws[0] is b and ws[1] is a
+    assert (a.x, a.length, a.z, a.offset, a.tag) == (10, 5, 3, 0, "a") and a.source is red
+    a.update(x=-4, source=green, tag=None)
+    assert a.x == -4 and a.source is green and a.tag is None and ws[0] is a
+    ws.remove(b)
+    assert len(ws) == 1
+    with pytest.raises(Exception):
+        b.x
+
+
+def test_passthrough_is_subclassable_and_has_properties(process):
+    class Stream(process.VideoPassThroughFilter):            # fluggo/editor/plugins/_source.py:399 does this
+        def __init__(self, source):
+            process.VideoPassThroughFilter.__init__(self, source, offset=3, start_frame=None, end_frame=10)
+            self.extra = "x"
+
+    red = process.SolidColorVideoSource((1, 0, 0, 1))
+    s = Stream(red)
+    assert (s.offset, s.start_frame, s.end_frame, s.extra) == (3, None, 10, "x") and s.source is red
+    s.offset, s.start_frame = 5, 2
+    s.set_source(None)
+    assert (s.offset, s.start_frame, s.source) == (5, 2, None)
+    g = process.VideoGainOffsetFilter(red)
+    assert (g.gain, g.offset) == (1.0, 0.0) and g.source is red
+    g.gain = process.LinearFrameFunc(1, 0)
+    assert isinstance(g.gain, process.LinearFrameFunc)
+
+
+def test_without_a_gpu_pulls_are_empty_and_loud(process):
+    from canvas_amd import _lib
+    if _lib.load().cvs_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from fluggo.media.basetypes import box2i
+    frame = process.SolidColorVideoSource((1, 0.5, 0.25, 1)).get_frame_f16(0, box2i(0, 0, 3, 3))
+    assert frame.current_window.empty() and frame.full_window == box2i(0, 0, 3, 3)
+    assert frame.pixel(0, 0) is None
+    assert "no CPU path" in process.last_error()
+    assert process.check_context_supported() is False
+
+
+def test_extension_links_only_the_library_not_the_oracle():
+    import glob
+    so = glob.glob(os.path.join(ROOT, "fluggo", "media", "process*.so"))
+    assert so
+    out = subprocess.run(["ldd", so[0]], stdout=subprocess.PIPE, text=True).stdout
+    assert "libcanvas_hip.so" in out and "oracle" not in out
+    for f in glob.glob(os.path.join(ROOT, "canvas_amd", "pyext", "*.[ch]")):
+        assert "orc_" not in open(f).read()
+

@@ -1,0 +1,258 @@
+"""fluggo.media.process on the GPU: the reference's own Python tests re-expressed (same inputs, same
+assertions, force_gl accepted and ignored), plus graphs checked against the CPU oracle.
+
+Reference tests mirrored:
+  tests/process/video/RgbaFrameF16.py:6-23            test_solid
+  tests/process/video/SolidColorVideoSource.py:13-55   const colour / const window / moving colour / moving window
+  tests/process/video/VideoWorkspace.py:12-38          10 000 random add / move / remove / pull operations
+  tests/canvas/sequence.py:58-100                      check1: cut, cut, crossfade -- built by hand from the
+                                                       same process.* objects the editor's graph code creates
+"""
+import ctypes as C
+import random
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def process():
+    from fluggo.media import process
+    assert process.check_context_supported(), process.last_error()
+    return process
+
+
+@pytest.fixture(scope="module")
+def bt():
+    from fluggo.media import basetypes
+    return basetypes
+
+
+def almost(a, b, places):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert round(x - y, places) == 0, (a, b)
+
+
+def getcolor(source, frame, bt):
+    return source.get_frame_f32(frame, bt.box2i(0, 0, 0, 0)).pixel(0, 0)
+
+
+# ---------------------------------------------------------------- RgbaFrameF16.py
+
+def test_solid_frame_and_rewindow(process, bt):
+    color = (1.0, 0.5, 0.333333, 0.2)
+    solid = process.SolidColorVideoSource(color, bt.box2i((0, 0), (2, 2)))
+    frame = solid.get_frame_f16(0, bt.box2i((0, 0), (3, 3)))
+    assert frame.current_window == bt.box2i(0, 0, 2, 2)
+    assert frame.full_window == bt.box2i(0, 0, 3, 3)
+    almost(frame.pixel(0, 0), color, 3)
+    assert frame.pixel(3, 3) is None and len(frame) == 16
+    frame2 = frame.get_frame_f16(0, bt.box2i(-1, -1, 1, 1))
+    assert frame2.current_window == bt.box2i(0, 0, 1, 1)
+    assert frame2.full_window == bt.box2i(-1, -1, 1, 1)
+    almost(frame2.pixel(0, 0), color, 3)
+    raw = frame.to_argb32_bytes()
+    assert len(raw) == 9 * 4
+
+
+# ---------------------------------------------------------------- SolidColorVideoSource.py
+
+@pytest.mark.parametrize("force_gl", [True, False])
+def test_solid_const_color_and_window(process, bt, force_gl):
+    color = (1.0, 0.5, 0.333333, 0.2)
+    solid = process.SolidColorVideoSource(color)
+    frame = solid.get_frame_f32(0, bt.box2i(0, 0, 3, 3), force_gl=force_gl)
+    assert frame.current_window == bt.box2i(0, 0, 3, 3)
+    almost(frame.pixel(0, 0), color, 6)
+    solid = process.SolidColorVideoSource(color, bt.box2i(0, 0, 2, 2))
+    frame = solid.get_frame_f32(0, bt.box2i(0, 0, 3, 3), force_gl=force_gl)
+    assert frame.current_window == bt.box2i(0, 0, 2, 2)
+    almost(frame.pixel(0, 0), color, 6)
+    frame2 = frame.get_frame_f32(0, bt.box2i(-1, -1, 1, 1), force_gl=force_gl)
+    assert frame2.current_window == bt.box2i(0, 0, 1, 1)
+    almost(frame2.pixel(0, 0), color, 6)
+
+
+def test_solid_moving_color_and_window(process, bt):
+    solid = process.SolidColorVideoSource(process.LerpFunc((0.5, 0.25, 2.0, 1.0), (-0.5, -0.25, -2.0, 0.0), 2))
+    almost(getcolor(solid, 0, bt), (0.5, 0.25, 2.0, 1.0), 6)
+    almost(getcolor(solid, 1, bt), (0.0, 0.0, 0.0, 0.5), 6)
+    almost(getcolor(solid, 2, bt), (-0.5, -0.25, -2.0, 0.0), 6)
+    solid = process.SolidColorVideoSource(bt.rgba(0.0, 0.0, 1.0, 1.0), process.LerpFunc((-2, -2, 2, 2), (-4, -4, 0, 6), 2))
+    for i, want in enumerate([(-2, -2, 2, 2), (-3, -3, 1, 4), (-4, -4, 0, 6)]):
+        frame = solid.get_frame_f32(i, bt.box2i(-5, -5, 5, 6))
+        assert frame.current_window == bt.box2i(*want)
+
+
+# ---------------------------------------------------------------- sequence.py check1
+
+def ramp(process, channel):
+    hi = [0, 0, 0, 1]
+    hi[channel] = 100
+    return process.SolidColorVideoSource(process.LerpFunc((0, 0, 0, 1), tuple(hi), 100))
+
+
+def test_sequence_cut_cut_crossfade(process, bt):
+    red, green, blue = ramp(process, 0), ramp(process, 1), ramp(process, 2)
+    fade = process.VideoMixFilter(src_a=process.VideoPassThroughFilter(green, offset=6),
+                                  src_b=process.VideoPassThroughFilter(blue, offset=1),
+                                  mix_b=process.LerpFunc((0,), (1,), 5))
+    seq = process.VideoSequence()
+    seq.append((red, 1, 10))
+    seq.append((green, 1, 5))
+    seq.append((fade, 0, 5))
+    seq.append((blue, 6, 5))
+    colors = [getcolor(seq, i, bt) for i in range(30)]
+    for i in range(0, 10):
+        almost(colors[i], (i + 1.0, 0, 0, 1), 6)
+    for i in range(10, 15):
+        almost(colors[i], (0, i - 10 + 1.0, 0, 1), 6)
+    for i in range(15, 20):
+        m = (i - 15) / 5.0
+        almost(colors[i], (0.0, (i - 10 + 1.0) * (1.0 - m), (i - 15 + 1.0) * m, 1.0), 6)
+    for i in range(20, 25):
+        almost(colors[i], (0, 0, i - 15 + 1.0, 1), 6)
+    for i in range(25, 30):
+        assert colors[i] is None
+    assert getcolor(seq, -1, bt) is None
+
+
+# ---------------------------------------------------------------- VideoWorkspace.py
+
+def test_workspace_random_operations(process, bt):
+    red, green, blue = ramp(process, 0), ramp(process, 1), ramp(process, 2)
+    rnd = random.Random(5)
+    workspace = process.VideoWorkspace()
+    for _ in range(10000):
+        action = rnd.randint(1, 7)
+        n = len(workspace)
+        if action == 1 and n:
+            workspace[rnd.randrange(n)].update(x=rnd.randint(0, 1000))
+        elif action == 2 and n:
+            workspace[rnd.randrange(n)].update(z=rnd.randint(-10, 10))
+        elif action == 3 and n:
+            workspace[rnd.randrange(n)].update(length=rnd.randint(1, 100))
+        elif action == 4 and n:
+            workspace[rnd.randrange(n)].update(offset=rnd.randint(-20, 20))
+        elif action == 5 and n:
+            workspace.remove(workspace[rnd.randrange(n)])
+        elif action == 6:
+            for _ in range(3):
+                getcolor(workspace, rnd.randint(-100, 1100), bt)
+        else:
+            workspace.add(source=rnd.choice((red, green, blue)), x=rnd.randint(0, 1000), z=rnd.randint(-10, 10),
+                          length=rnd.randint(1, 100), offset=rnd.randint(-20, 20))
+
+
+def test_workspace_stack_values(process, bt, orc):
+    """Three windowed translucent solids over an opaque one, through the Python API, against the oracle's
+    over applied bottom-to-top (workspace.c:530-544)."""
+    from canvas_amd.abi import HostFrame
+    full = (0, 0, 31, 17)
+    spec = [((0.2, 0.4, 0.6, 1.0), full, 0), ((0.9, 0.1, 0.3, 0.5), (4, 2, 20, 12), 5), ((0.3, 0.8, 0.1, 0.25), (10, 3, 31, 9), 2)]
+    ws = process.VideoWorkspace()
+    for color, win, z in spec:
+        ws.add(source=process.SolidColorVideoSource(color, bt.box2i(*win)), x=0, length=10, z=z, offset=0)
+    got = ws.get_frame_f32(3, bt.box2i(*full))
+    assert got.current_window == bt.box2i(*full)
+    acc = None
+    for color, win, z in sorted(spec, key=lambda s: s[2]):
+        arr = np.zeros((18, 32, 4), np.float32)
+        arr[win[1]:win[3] + 1, win[0]:win[2] + 1] = np.array(color, np.float32)
+        layer = HostFrame(full, np.float32, arr, win)
+        if acc is None:
+            acc = layer
+        else:
+            orc.lib().orc_mix_over_f32(acc.ref(), layer.ref(), C.c_float(1.0))
+    for y in range(18):
+        for x in (0, 5, 12, 25, 31):
+            almost(got.pixel(x, y), tuple(float(v) for v in acc.array[y, x]), 7)
+
+
+# ---------------------------------------------------------------- config 1: SolidColor -> gain -> pull
+
+def test_config1_solid_gain_pull(process, bt, orc):
+    solid = process.SolidColorVideoSource((0.25, 0.5, 0.75, 1.0))
+    gain = process.VideoGainOffsetFilter(solid, gain=1.5, offset=0.0625)
+    frame = gain.get_frame_f16(0, bt.box2i(0, 0, 1919, 1079))
+    assert frame.current_window == bt.box2i(0, 0, 1919, 1079)
+    # expected per the repo's definition of gain/offset: truncate(color) -> widen -> *1.5 + 0.0625 -> truncate
+    c = orc.half_to_float(orc.float_to_half(np.array([0.25, 0.5, 0.75, 1.0], np.float32)))
+    want = c.copy()
+    want[:3] = (c[:3] * np.float32(1.5)).astype(np.float32) + np.float32(0.0625)
+    want = orc.half_to_float(orc.float_to_half(want))
+    for xy in [(0, 0), (1919, 1079), (960, 540)]:
+        assert tuple(frame.pixel(*xy)) == tuple(float(v) for v in want)
+    ns = process.time_get_frame(gain, 0, 99, (0, 0, 1919, 1079))        # the reference's timing primitive
+    assert ns > 0
+    print("config 1: 100 x 1920x1080 SolidColor->gain->pull: %.1f ms, %.0f Mpx/s (host frames, PCIe included)" % (
+        ns / 1e6, 100 * 1920 * 1080 / (ns / 1e9) / 1e6))
+
+
+def test_scaler_node_matches_oracle(process, bt, orc):
+    from canvas_amd.abi import HostFrame, v2f
+    solid = process.SolidColorVideoSource((0.2, 0.4, 0.6, 0.8), bt.box2i(2, 1, 13, 7))
+    scaler = process.VideoScaler(solid, target_point=(0, 0), source_point=(0, 0), scale_factors=(2.0, 2.0), source_rect=bt.box2i(0, 0, 15, 8))
+    got = scaler.get_frame_f32(0, bt.box2i(0, 0, 31, 17))
+    src = HostFrame((0, 0, 15, 8), np.float32, current_window=(2, 1, 13, 7))
+    src.array[1:8, 2:14] = np.array([0.2, 0.4, 0.6, 0.8], np.float32)
+    # the pull rectangle of video_scale.c:303-309 for this target is (-1,-1,16,9) clipped to source_rect
+    want = HostFrame((0, 0, 31, 17), np.float32)
+    orc.lib().orc_scale_bilinear_f32(want.ref(), v2f(0, 0), src.ref(), v2f(0, 0), v2f(2.0, 2.0))
+    assert got.current_window == bt.box2i(*want.current_window.tuple())
+    x0, y0, x1, y1 = want.current_window.tuple()
+    for y in range(y0, y1 + 1, 3):
+        for x in range(x0, x1 + 1, 5):
+            almost(got.pixel(x, y), tuple(float(v) for v in want.array[y, x]), 7)
+
+
+# ---------------------------------------------------------------- plugin protocol + pull queue
+
+def test_foreign_host_only_source_plugs_in(process, bt):
+    """A third-party source: a Python object whose capsule wraps a vtable with only get_frame_32 filled
+    (no device slot) -- pulled through device-resident nodes."""
+    from canvas_amd.abi import GET_FRAME_F32, video_frame_source_funcs
+
+    def fill(self_ptr, idx, fp):
+        f = fp.contents
+        n = f.full_window.width * f.full_window.height
+        arr = np.ctypeslib.as_array(C.cast(f.data, C.POINTER(C.c_float)), shape=(n, 4))
+        arr[:] = (idx, 0.5, 0.25, 1.0)
+        f.current_window = f.full_window
+
+    cb = GET_FRAME_F32(fill)
+    funcs = video_frame_source_funcs(0, C.cast(None, type(video_frame_source_funcs().get_frame)), cb, None)
+    C.pythonapi.PyCapsule_New.restype = C.py_object
+    C.pythonapi.PyCapsule_New.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+
+    class Foreign:
+        _video_frame_source_funcs = C.pythonapi.PyCapsule_New(C.addressof(funcs), b"_video_frame_source_funcs", None)
+
+    src = Foreign()
+    chain = process.VideoGainOffsetFilter(process.VideoPassThroughFilter(src, offset=2), gain=2.0, offset=0.0)
+    px = chain.get_frame_f32(5, bt.box2i(0, 0, 3, 3)).pixel(1, 1)
+    almost(px, (14.0, 1.0, 0.5, 1.0), 6)
+
+
+def test_pull_queue_delivers_frames(process, bt):
+    q = process.VideoPullQueue()
+    solid = ramp(process, 0)
+    done, seen = threading.Event(), {}
+
+    def callback(frame_index, frame, user_data):
+        seen[frame_index] = (frame.pixel(0, 0), user_data)
+        if len(seen) == 8:
+            done.set()
+
+    items = [q.enqueue(source=solid, frame_index=i, window=bt.box2i(0, 0, 1, 1), callback=callback, user_data="u%d" % i) for i in range(8)]
+    assert done.wait(30), "callbacks did not arrive"
+    for i in range(8):
+        almost(seen[i][0], (float(i), 0, 0, 1), 6)
+        assert seen[i][1] == "u%d" % i
+    cancelled = q.enqueue(source=solid, frame_index=99, window=bt.box2i(0, 0, 1, 1), callback=callback, user_data=None)
+    cancelled.cancel()
+    del items
