@@ -123,7 +123,8 @@ def main():
         args.gpus = world
 
     dist = None
-    if world > 1:
+    # CANVAS_FORCE_DIST=1 takes the multi-process path at world size 1 too (rehearsal of the RCCL code on one GPU)
+    if world > 1 or (os.environ.get("CANVAS_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ):
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

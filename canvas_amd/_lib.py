@@ -125,6 +125,7 @@ SIGNATURES = {
     "cvs_scale_bilinear_f32_dev": (C.c_int, [_F32, v2f, _F32, v2f, v2f, _vp]),
     "cvs_fir_blur_f32_dev": (C.c_int, [_F32, _F32, _f32p, C.c_int, _vp]),
     "cvs_resample_lanczos_f32_dev": (C.c_int, [_F32, _F32, C.c_float, C.c_float, C.c_int, _vp]),
+    "cvs_blur_lanczos_f16_dev": (C.c_int, [_F16, _F16, _f32p, C.c_int, C.c_float, C.c_float, C.c_int, _vp]),
     # (3) fused chain
     "cvs_chain_color_over_f16_dev": (C.c_int, [P(chain_job), C.c_int, _f32p, C.c_int, C.c_int, _vp]),
     "cvs_chain_last_was_fused": (C.c_int, []),

@@ -248,10 +248,8 @@ static int plan_blur(tap_table *tb, int t0, int t1, int s0, int s1, const float 
     return rc;
 }
 
-CVS_EXPORT int cvs_fir_blur_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, const float *taps, int ntaps, cvs_stream_t stream) {
-    if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
-    if (ntaps < 1 || !taps) { cvs_set_error("blur: need at least one tap"); box2i_set_empty(&target->current_window); return -1; }
-    hipStream_t s = cvs_pick_stream(stream);
+/* fallback: the two passes through an f32 intermediate in HBM (footprints too large for an LDS tile) */
+static int blur_two_pass(rgba_frame_f32 *target, const rgba_frame_f32 *source, const float *taps, int ntaps, hipStream_t s) {
     box2i win;
     box2i_intersect(&win, &source->current_window, &target->full_window);
     target->current_window = win;
@@ -297,13 +295,7 @@ static int plan_lanczos(tap_table *tb, int t0, int t1, int s0, int s1, float fac
     return rc;
 }
 
-CVS_EXPORT int cvs_resample_lanczos_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, float fx, float fy, int ksize, cvs_stream_t stream) {
-    if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
-    if (!(fx > 0.0f) || !(fy > 0.0f) || ksize < 1 || box2i_is_empty(&source->current_window) || box2i_is_empty(&target->full_window)) {
-        box2i_set_empty(&target->current_window);
-        return 0;
-    }
-    hipStream_t s = cvs_pick_stream(stream);
+static int lanczos_two_pass(rgba_frame_f32 *target, const rgba_frame_f32 *source, float fx, float fy, int ksize, hipStream_t s) {
     const box2i *sw = &source->current_window, *tf = &target->full_window;
     rgba_frame_f32 mid;
     box2i_set(&mid.full_window, tf->min.x, sw->min.y, tf->max.x, sw->max.y);
@@ -321,5 +313,225 @@ CVS_EXPORT int cvs_resample_lanczos_f32_dev(rgba_frame_f32 *target, const rgba_f
     cvs_free(mid.data);
     if (rc == 0) target->current_window = *tf;
     else box2i_set_empty(&target->current_window);
+    return rc;
+}
+
+/* ---------------------------------------------------------------- fused separable FIR (kernels/fir_ops.hip: k_fir2d)
+ *
+ * One tap table per axis, built by the planners above, kept on the device and reused: a table depends
+ * only on (kind, factor or taps, target range, source range), which repeat from frame to frame, so in
+ * steady state a blur or a resample is one kernel launch with no host-side planning, no upload, no sync. */
+#include <pthread.h>
+
+typedef struct {
+    int kind;                 /* 1 = blur taps, 2 = lanczos */
+    uint32_t fbits;           /* lanczos: factor bits */
+    int ksize;                /* lanczos: kernel size; blur: tap count */
+    uint64_t taps_hash;       /* blur: FNV-1a of the tap values */
+    int t0, t1, s0, s1;
+    int tile;                 /* tile edge along this axis */
+} axis_key;
+
+typedef struct {
+    axis_key key;
+    int valid;
+    uint64_t stamp;
+    char *dev;                /* one block: ntaps | src | taps | foot */
+    cvk_fir_axis axis;
+    int max_foot;
+} axis_entry;
+
+#define AXIS_CACHE 16
+static axis_entry g_axis[AXIS_CACHE];
+static uint64_t g_axis_clock;
+static pthread_mutex_t g_axis_lock = PTHREAD_MUTEX_INITIALIZER;
+
+/* keys are compared with memcmp: build them from zeroed storage so that padding is defined */
+static axis_key make_key(int kind, uint32_t fbits, int ksize, uint64_t taps_hash, int t0, int t1, int s0, int s1, int tile) {
+    axis_key k;
+    memset(&k, 0, sizeof k);
+    k.kind = kind; k.fbits = fbits; k.ksize = ksize; k.taps_hash = taps_hash;
+    k.t0 = t0; k.t1 = t1; k.s0 = s0; k.s1 = s1; k.tile = tile;
+    return k;
+}
+
+static uint64_t fnv1a(const void *p, size_t n) {
+    const unsigned char *b = p;
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+/* device copy of one axis table (+ per-tile footprints); returns 0 and fills *out on success */
+static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
+    const int lines = tb->t1 >= tb->t0 ? tb->t1 - tb->t0 + 1 : 0;
+    const int tiles = (lines + tile - 1) / tile;
+    int *foot = malloc(sizeof(int) * 2 * (size_t)(tiles ? tiles : 1));
+    int *ntaps = malloc(sizeof(int) * (size_t)(lines ? lines : 1));
+    if (!foot || !ntaps) { free(foot); free(ntaps); return -1; }
+    int max_foot = 0;
+    for (int i = 0; i < lines; i++) ntaps[i] = tb->ntaps[i] < tb->stride ? tb->ntaps[i] : tb->stride;
+    for (int t = 0; t < tiles; t++) {
+        int first = INT_MAX, last = INT_MIN;
+        for (int i = t * tile; i < lines && i < (t + 1) * tile; i++) {
+            if (!ntaps[i]) continue;
+            const int *src = tb->tap_src + (size_t)i * tb->stride;
+            if (src[0] < first) first = src[0];
+            if (src[ntaps[i] - 1] > last) last = src[ntaps[i] - 1];
+        }
+        if (last < first) { first = 0; last = -1; }
+        foot[2 * t] = first; foot[2 * t + 1] = last;
+        if (last - first + 1 > max_foot) max_foot = last - first + 1;
+    }
+    const size_t n_l = (size_t)(lines ? lines : 1), n_t = n_l * (size_t)tb->stride;
+    const size_t off_src = (n_l * sizeof(int) + 255) & ~(size_t)255;
+    const size_t off_tap = off_src + ((n_t * sizeof(int) + 255) & ~(size_t)255);
+    const size_t off_foot = off_tap + ((n_t * sizeof(float) + 255) & ~(size_t)255);
+    const size_t total = off_foot + sizeof(int) * 2 * (size_t)(tiles ? tiles : 1);
+    char *dev = NULL;
+    hipError_t err = hipMalloc((void **)&dev, total);
+    if (err == hipSuccess) err = hipMemcpy(dev, ntaps, n_l * sizeof(int), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(dev + off_src, tb->tap_src, n_t * sizeof(int), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(dev + off_tap, tb->taps, n_t * sizeof(float), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(dev + off_foot, foot, sizeof(int) * 2 * (size_t)(tiles ? tiles : 1), hipMemcpyHostToDevice);
+    free(foot); free(ntaps);
+    if (err != hipSuccess) { if (dev) hipFree(dev); cvs_set_error("FIR table upload: %s", hipGetErrorString(err)); return -1; }
+    e->dev = dev;
+    e->axis.ntaps = (const int *)dev;
+    e->axis.src = (const int *)(dev + off_src);
+    e->axis.taps = (const float *)(dev + off_tap);
+    e->axis.foot = (const int *)(dev + off_foot);
+    e->axis.stride = tb->stride;
+    e->max_foot = max_foot;
+    return 0;
+}
+
+/* cached table for one axis; `taps` only for kind 1 */
+static int axis_get(const axis_key *key, const float *taps, float factor, cvk_fir_axis *out, int *max_foot) {
+    pthread_mutex_lock(&g_axis_lock);
+    int victim = 0;
+    for (int i = 0; i < AXIS_CACHE; i++) {
+        if (g_axis[i].valid && memcmp(&g_axis[i].key, key, sizeof *key) == 0) {
+            g_axis[i].stamp = ++g_axis_clock;
+            *out = g_axis[i].axis; *max_foot = g_axis[i].max_foot;
+            pthread_mutex_unlock(&g_axis_lock);
+            return 0;
+        }
+        if (!g_axis[i].valid) victim = i;
+        else if (g_axis[victim].valid && g_axis[i].stamp < g_axis[victim].stamp) victim = i;
+    }
+    tap_table tb;
+    int rc = key->kind == 1 ? plan_blur(&tb, key->t0, key->t1, key->s0, key->s1, taps, key->ksize)
+                            : plan_lanczos(&tb, key->t0, key->t1, key->s0, key->s1, factor, key->ksize);
+    axis_entry fresh;
+    memset(&fresh, 0, sizeof fresh);
+    if (rc == 0) { rc = axis_upload(&tb, key->tile, &fresh); table_free(&tb); }
+    if (rc == 0) {
+        axis_entry *e = &g_axis[victim];
+        if (e->valid && e->dev) { hipDeviceSynchronize(); hipFree(e->dev); }     /* eviction is rare; nothing may still read it */
+        fresh.key = *key; fresh.valid = 1; fresh.stamp = ++g_axis_clock;
+        *e = fresh;
+        *out = e->axis; *max_foot = e->max_foot;
+    }
+    pthread_mutex_unlock(&g_axis_lock);
+    return rc;
+}
+
+/* 0 = launched, 1 = does not fit an LDS tile (caller falls back), <0 = error */
+static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, int in_half,
+                        const box2i *rect, const cvk_fir_axis *h, int h_foot, const cvk_fir_axis *v, int v_foot, hipStream_t s) {
+    cvk_fir2d_params fp;
+    memset(&fp, 0, sizeof fp);
+    fp.target = cvs_view(tdata, tfull);
+    fp.source = cvs_view((void *)sdata, sfull);
+    fp.in_half = in_half; fp.out_half = out_half;
+    fp.tx0 = rect->min.x; fp.ty0 = rect->min.y; fp.tx1 = rect->max.x; fp.ty1 = rect->max.y;
+    fp.h = *h; fp.v = *v;
+    fp.max_sw = h_foot > 0 ? h_foot : 1;
+    fp.max_sh = v_foot > 0 ? v_foot : 1;
+    if (cvk_fir2d_lds_bytes(&fp) > 150 * 1024 || h->stride > 64 || v->stride > 64) return 1;
+    int rc = cvk_fir2d(&fp, s);
+    if (rc != 0) { cvs_set_error("fused FIR launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
+    return 0;
+}
+
+static int blur_fused(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
+                      const box2i *win, const float *taps, int ntaps, hipStream_t s) {
+    const uint64_t th = fnv1a(taps, sizeof(float) * (size_t)ntaps);
+    axis_key kh = make_key(1, 0, ntaps, th, win->min.x, win->max.x, sw->min.x, sw->max.x, CVK_FIR2D_TILE_X);
+    axis_key kv = make_key(1, 0, ntaps, th, win->min.y, win->max.y, sw->min.y, sw->max.y, CVK_FIR2D_TILE_Y);
+    cvk_fir_axis h, v; int hf, vf;
+    if (axis_get(&kh, taps, 0.0f, &h, &hf) != 0 || axis_get(&kv, taps, 0.0f, &v, &vf) != 0) return -1;
+    return fir2d_launch(tdata, tfull, out_half, sdata, sfull, in_half, win, &h, hf, &v, vf, s);
+}
+
+static int lanczos_fused(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
+                         float fx, float fy, int ksize, hipStream_t s) {
+    uint32_t bx, by;
+    memcpy(&bx, &fx, 4); memcpy(&by, &fy, 4);
+    axis_key kh = make_key(2, bx, ksize, 0, tfull->min.x, tfull->max.x, sw->min.x, sw->max.x, CVK_FIR2D_TILE_X);
+    axis_key kv = make_key(2, by, ksize, 0, tfull->min.y, tfull->max.y, sw->min.y, sw->max.y, CVK_FIR2D_TILE_Y);
+    cvk_fir_axis h, v; int hf, vf;
+    if (axis_get(&kh, NULL, fx, &h, &hf) != 0 || axis_get(&kv, NULL, fy, &v, &vf) != 0) return -1;
+    return fir2d_launch(tdata, tfull, out_half, sdata, sfull, in_half, tfull, &h, hf, &v, vf, s);
+}
+
+CVS_EXPORT int cvs_fir_blur_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, const float *taps, int ntaps, cvs_stream_t stream) {
+    if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
+    if (ntaps < 1 || !taps) { cvs_set_error("blur: need at least one tap"); box2i_set_empty(&target->current_window); return -1; }
+    hipStream_t s = cvs_pick_stream(stream);
+    box2i win;
+    box2i_intersect(&win, &source->current_window, &target->full_window);
+    target->current_window = win;
+    if (box2i_is_empty(&win)) return 0;
+    int rc = blur_fused(target->data, &target->full_window, 0, source->data, &source->full_window, &source->current_window, 0, &win, taps, ntaps, s);
+    if (rc == 1) rc = blur_two_pass(target, source, taps, ntaps, s);
+    if (rc != 0) box2i_set_empty(&target->current_window);
+    return rc;
+}
+
+CVS_EXPORT int cvs_resample_lanczos_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, float fx, float fy, int ksize, cvs_stream_t stream) {
+    if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
+    if (!(fx > 0.0f) || !(fy > 0.0f) || ksize < 1 || box2i_is_empty(&source->current_window) || box2i_is_empty(&target->full_window)) {
+        box2i_set_empty(&target->current_window);
+        return 0;
+    }
+    hipStream_t s = cvs_pick_stream(stream);
+    int rc = lanczos_fused(target->data, &target->full_window, 0, source->data, &source->full_window, &source->current_window, 0, fx, fy, ksize, s);
+    if (rc == 1) return lanczos_two_pass(target, source, fx, fy, ksize, s);
+    if (rc == 0) target->current_window = target->full_window;
+    else box2i_set_empty(&target->current_window);
+    return rc;
+}
+
+/* BASELINE config 3 on f16 frames: widen -> blur (f32) -> Lanczos resample (f32) -> truncate, as two fused
+ * launches with one f32 intermediate; the widen and the truncate ride on the first load and the last store. */
+CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, const float *taps, int ntaps,
+                                        float fx, float fy, int ksize, cvs_stream_t stream) {
+    if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
+    if (ntaps < 1 || !taps || !(fx > 0.0f) || !(fy > 0.0f) || ksize < 1) { cvs_set_error("blur+lanczos: bad arguments"); box2i_set_empty(&target->current_window); return -1; }
+    if (box2i_is_empty(&source->current_window) || box2i_is_empty(&target->full_window)) { box2i_set_empty(&target->current_window); return 0; }
+    hipStream_t s = cvs_pick_stream(stream);
+    /* the blurred frame covers the source's current window (blur: output window = source window) */
+    const box2i *sw = &source->current_window;
+    rgba_frame_f32 mid = { NULL, *sw, *sw };
+    mid.data = cvs_pool_malloc(cvs_box_pixels(sw) * sizeof(rgba_f32), s);
+    if (!mid.data) { box2i_set_empty(&target->current_window); return -1; }
+    int rc = blur_fused(mid.data, &mid.full_window, 0, source->data, &source->full_window, sw, 1, sw, taps, ntaps, s);
+    if (rc == 0) rc = lanczos_fused(target->data, &target->full_window, 1, mid.data, &mid.full_window, sw, 0, fx, fy, ksize, s);
+    if (rc == 1) {
+        /* tiles too large for LDS: same nodes one by one on f32 frames */
+        rgba_frame_f32 wide = { cvs_pool_malloc(cvs_box_pixels(&source->full_window) * sizeof(rgba_f32), s), source->full_window, source->full_window };
+        rgba_frame_f32 small = { cvs_pool_malloc(cvs_box_pixels(&target->full_window) * sizeof(rgba_f32), s), target->full_window, target->full_window };
+        rc = (wide.data && small.data) ? cvs_frame_f16_to_f32_dev(&wide, source, s) : -1;
+        if (rc == 0) rc = blur_two_pass(&mid, &wide, taps, ntaps, s);
+        if (rc == 0) rc = lanczos_two_pass(&small, &mid, fx, fy, ksize, s);
+        if (rc == 0) rc = cvs_frame_f32_to_f16_dev(target, &small, s);
+        cvs_pool_free(wide.data, s); cvs_pool_free(small.data, s);
+    } else if (rc == 0) {
+        target->current_window = target->full_window;
+    }
+    cvs_pool_free(mid.data, s);
+    if (rc != 0) box2i_set_empty(&target->current_window);
     return rc;
 }

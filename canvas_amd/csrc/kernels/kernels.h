@@ -83,6 +83,28 @@ typedef struct {
 int cvk_fir_gather(const cvk_fir_params *fp, void *stream);
 int cvk_zero_f32(cvk_view v, void *stream);
 
+/* separable FIR, both passes in one launch with the source tile and the horizontal result staged in LDS.
+ * One device table per axis (cvk_fir_axis): for target line i (0-based within the rect) ntaps[i] taps,
+ * source indices src[i*stride + k] (ascending) and weights taps[i*stride + k]; foot[2*t], foot[2*t+1] =
+ * first and last source index any line of tile t touches (first > last: the tile touches nothing). */
+typedef struct {
+    const int *ntaps, *src;
+    const float *taps;
+    const int *foot;
+    int stride;
+} cvk_fir_axis;
+typedef struct {
+    cvk_view target, source;
+    int in_half, out_half;     /* 0: rgba_f32 pixels, 1: rgba_f16 pixels */
+    int tx0, ty0, tx1, ty1;    /* target rectangle */
+    cvk_fir_axis h, v;         /* h: per target column, v: per target row */
+    int max_sw, max_sh;        /* largest tile footprint in source pixels (sizes the LDS tile) */
+} cvk_fir2d_params;
+#define CVK_FIR2D_TILE_X 32
+#define CVK_FIR2D_TILE_Y 16
+size_t cvk_fir2d_lds_bytes(const cvk_fir2d_params *fp);     /* dynamic LDS the launch would need */
+int cvk_fir2d(const cvk_fir2d_params *fp, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -278,6 +278,9 @@ CVS_EXPORT int cvs_scale_bilinear_f32_dev(rgba_frame_f32 *target, v2f target_poi
  * gather resampler built on filter_createLanczos */
 CVS_EXPORT int cvs_fir_blur_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, const float *taps_host, int ntaps, cvs_stream_t s);
 CVS_EXPORT int cvs_resample_lanczos_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, float factor_x, float factor_y, int kernel_size, cvs_stream_t s);
+/* BASELINE config 3 on f16 frames: widen -> blur -> Lanczos resample -> truncate, f32 in between, two launches */
+CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, const float *taps_host, int ntaps,
+                                        float factor_x, float factor_y, int kernel_size, cvs_stream_t s);
 
 /* ------------------------------------------------------------------ (3) fused chain: BASELINE config 2
  * out = f16( over-stack_{k=0..n-1}( f32( colour(layer_k) ) ) ), i.e. what the reference computes with

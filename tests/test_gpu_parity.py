@@ -629,6 +629,53 @@ def test_lanczos_resample(cvs, orc, fx, fy, tsize):
     assert_same_f32(got.array, want.array, "lanczos")
 
 
+def _oracle_config3(orc, src16, tsize, taps, fx, fy):
+    """widen -> blur -> Lanczos -> truncate with the oracle's pieces."""
+    src32 = HostFrame(src16.full_window, np.float32, orc.half_to_float(src16.array), src16.current_window)
+    blurred = HostFrame(src16.full_window, np.float32)
+    orc.lib().orc_fir_blur_f32(blurred.ref(), src32.ref(), f32p(taps), len(taps))
+    small = HostFrame((0, 0, tsize[0] - 1, tsize[1] - 1), np.float32)
+    orc.lib().orc_resample_lanczos_f32(small.ref(), blurred.ref(), C.c_float(fx), C.c_float(fy), 3)
+    return HostFrame(small.full_window, np.uint16, orc.float_to_half(small.array), small.current_window)
+
+
+@pytest.mark.parametrize("ssize,tsize,fx,fy", [((128, 72), (64, 36), 0.5, 0.5), ((97, 55), (49, 28), 0.5, 0.5), ((64, 36), (128, 54), 2.0, 1.5),
+                                               ((200, 40), (20, 40), 0.1, 1.0)])      # the last one does not fit an LDS tile: fallback path
+def test_config3_pipeline_f16(cvs, orc, ssize, tsize, fx, fy):
+    layer = synth.layer_frame(ssize[0], ssize[1], 1, 0)
+    taps = synth.gaussian_taps(9, 1.5)
+    want = _oracle_config3(orc, layer, tsize, taps, fx, fy)
+    d_src = DeviceFrame.from_host(layer)
+    d_out = DeviceFrame((0, 0, tsize[0] - 1, tsize[1] - 1), np.uint16)
+    for _ in range(2):                                     # second call runs from the cached tap tables
+        _lib.check(cvs.cvs_blur_lanczos_f16_dev(d_out.ref(), d_src.ref(), f32p(taps), 9, C.c_float(fx), C.c_float(fy), 3, None))
+        got = d_out.download()
+        assert same_window(got.current_window, want.current_window)
+        assert_same_f16(got.array, want.array, "config 3 pipeline %r -> %r" % (ssize, tsize))
+
+
+def test_config3_full_size_properties(cvs, orc):
+    """3840x2160 -> 1920x1080: a constant frame stays constant away from the borders (taps sum to 1 within
+    float rounding), and the top-left corner block equals the oracle run on a crop that contains its footprint."""
+    w, h = 3840, 2160
+    taps = synth.gaussian_taps(9, 1.5)
+    layer = synth.layer_frame(w, h, 1, 0)
+    d_src = DeviceFrame.from_host(layer)
+    d_out = DeviceFrame((0, 0, w // 2 - 1, h // 2 - 1), np.uint16)
+    _lib.check(cvs.cvs_blur_lanczos_f16_dev(d_out.ref(), d_src.ref(), f32p(taps), 9, C.c_float(0.5), C.c_float(0.5), 3, None))
+    got = d_out.download()
+    assert got.current_window.tuple() == (0, 0, w // 2 - 1, h // 2 - 1)
+    # corner: output block (0..47, 0..26) depends on source (0..~110, 0..~70); a 256x160 crop reproduces it exactly
+    crop = HostFrame((0, 0, 255, 159), np.uint16, layer.array[:160, :256])
+    want = _oracle_config3(orc, crop, (128, 80), taps, 0.5, 0.5)
+    assert_same_f16(got.array[:27, :48], want.array[:27, :48], "4K config 3, corner block")
+    const = HostFrame((0, 0, w - 1, h - 1), np.uint16, fill=0x3800)        # 0.5 everywhere
+    d_src.upload(const.array)
+    _lib.check(cvs.cvs_blur_lanczos_f16_dev(d_out.ref(), d_src.ref(), f32p(taps), 9, C.c_float(0.5), C.c_float(0.5), 3, None))
+    inner = orc.half_to_float(d_out.download().array[16:-16, 16:-16])
+    assert np.abs(inner - 0.5).max() < 2e-3
+
+
 # ------------------------------------------------------------------ BASELINE sizes
 
 def test_config2_full_4k_frame_against_oracle(cvs, orc):
