@@ -9,8 +9,8 @@ round-robin: global frame g belongs to rank g % N; no collective on the frame pa
 only the parameter block (matrix + 128 KiB LUT) once at start and the timings at the end.
 
 A "step" = one batch of --batch frames per GPU through the fused chain kernel (one launch).
-The input ring (--ring frame sets, default 8 x 199 MB) is several times the 256 MiB Infinity
-Cache, so every launch streams from HBM.
+The input ring (--ring frame sets, default 8 x 199 MB = 1.6 GB) is several times the 256 MiB Infinity
+Cache, so every launch streams from HBM (a 16-frame step walks the ring twice).
 """
 import argparse
 import ctypes as C
@@ -32,15 +32,16 @@ BYTES_PER_PIXEL_PER_LAYER = 8  # one rgba_f16 read per layer pixel + one written
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU (one kernel launch)")
+    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU (one kernel launch)")
     ap.add_argument("--ring", type=int, default=8, help="distinct frame sets resident per GPU")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--translucent-base", action="store_true",
                     help="NOT the BASELINE input: random alpha on layer 0 as well, so every divide of the over operator is live")
+    ap.add_argument("--no-arena", action="store_true", help="one hipMalloc per frame instead of one arena for the ring")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -147,13 +148,27 @@ def main():
     full = (0, 0, w - 1, h - 1)
     ring = []
     my_frames = frames_of_rank(rank, world, args.ring)          # global frame ids g with g % world == rank
+    # one arena for the whole ring: a single large allocation maps with far fewer page-table entries than
+    # dozens of 66 MB ones, and the TLB reach of the chip is what a multi-GB streaming working set leans on
+    frame_bytes = w * h * 8
+    slot = (frame_bytes + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+    arena = None if args.no_arena else lib.cvs_malloc(slot * (nl + 1) * len(my_frames))
+    at = [arena]
+
+    def place():
+        if arena is None:
+            return DeviceFrame(full, np.uint16)
+        d = DeviceFrame(full, np.uint16, ptr=at[0])
+        at[0] += slot
+        return d
+
     for g in my_frames:
         layers = []
         for k in range(nl):
-            d = DeviceFrame(full, np.uint16)
+            d = place()
             d.upload(synth.layer_pixels(w, h, k, g, opaque_base=not args.translucent_base))
             layers.append(d)
-        ring.append((DeviceFrame(full, np.uint16), layers))
+        ring.append((place(), layers))
 
     def step(i):
         jobs = [ring[(i * args.batch + b) % len(ring)] for b in range(args.batch)]
@@ -214,7 +229,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("k_chain_bytes_per_launch")
+                # PMC-measured HBM bytes per output pixel of k_chain (FETCH_SIZE x2-corrected + WRITE_SIZE, separate
+                # rocprofv3 --pmc passes, tools/profile_bench.sh), scaled to this run's pixels per launch
+                traffic = round(json.load(open(tpath))["k_chain_bytes_per_output_pixel"] * px_per_step)
             except Exception:
                 traffic = None
         res = {

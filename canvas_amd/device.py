@@ -13,14 +13,17 @@ from .abi import HostFrame, box2i, rgba_frame_f16, rgba_frame_f32
 class DeviceFrame:
     """An rgba_frame_f16/f32 whose `data` points into HBM."""
 
-    def __init__(self, full_window, dtype, current_window=None):
+    def __init__(self, full_window, dtype, current_window=None, ptr=None):
+        """ptr: place the frame at this device address (memory owned by the caller, e.g. one arena
+        holding a whole ring of frames); default: own allocation."""
         lib = _lib.load()
         fw = full_window if isinstance(full_window, box2i) else box2i.of(*full_window)
         self.dtype = np.dtype(dtype)
         assert self.dtype in (np.dtype(np.uint16), np.dtype(np.float32))
         self.height, self.width = fw.height, fw.width
         self.nbytes = self.height * self.width * 4 * self.dtype.itemsize
-        self.ptr = lib.cvs_malloc(max(self.nbytes, 1))
+        self.owns = ptr is None
+        self.ptr = lib.cvs_malloc(max(self.nbytes, 1)) if ptr is None else ptr
         if not self.ptr:
             raise MemoryError("cvs_malloc(%d): %s" % (self.nbytes, _lib.last_error()))
         cls = rgba_frame_f16 if self.dtype == np.uint16 else rgba_frame_f32
@@ -58,7 +61,8 @@ class DeviceFrame:
 
     def free(self):
         if self.ptr:
-            _lib.load().cvs_free(self.ptr)
+            if self.owns:
+                _lib.load().cvs_free(self.ptr)
             self.ptr = None
             self.c.data = None
 

@@ -1,0 +1,62 @@
+"""The oracle against its frozen answers (tests/golden/cprocess_small.npz, made by tests/golden/make_golden.py),
+and -- on the GPU box -- the library against the same file.  See make_golden.py for what these vectors pin."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests.util import assert_same_f16, canon_f16, canon_f32
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(os.path.join(HERE, "golden", "cprocess_small.npz"))
+
+
+def test_oracle_reproduces_every_golden_vector(orc, golden):
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden
+    fresh = make_golden.cases()
+    assert sorted(fresh) == sorted(golden.files)
+    for k in golden.files:
+        a, b = fresh[k], golden[k]
+        assert a.shape == b.shape and a.dtype == b.dtype, k
+        if a.dtype == np.float32:
+            assert np.array_equal(canon_f32(a), canon_f32(b)), k
+        elif a.dtype == np.uint16:
+            assert np.array_equal(canon_f16(a), canon_f16(b)), k
+        else:
+            assert np.array_equal(a, b), k
+
+
+@pytest.mark.gpu
+def test_library_reproduces_golden_chain_and_tables(golden):
+    from canvas_amd import REC709_RGB_TO_YPBPR, _lib, synth
+    from canvas_amd.device import DeviceFrame, chain_color_over
+    lib = _lib.load()
+    assert lib.cvs_init(0) == 0
+    lib.init_half()
+    for k in range(4):
+        tab = np.ctypeslib.as_array(lib.cvs_lut_host(k), shape=(65536,))
+        assert_same_f16(tab, golden["lut%d" % k], "lut %d" % k)
+    out = np.empty(golden["f2h_in"].shape, np.uint16)
+    _lib.half_pointer("half_convert_from_float")(out.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                                 golden["f2h_in"].ctypes.data_as(C.POINTER(C.c_float)), out.size)
+    assert np.array_equal(out, golden["f2h_out"])
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    for nl in (2, 3, 4):
+        dl = [DeviceFrame.from_host(synth.layer_frame(64, 36, k, 0)) for k in range(nl)]
+        res = DeviceFrame((0, 0, 63, 35), np.uint16)
+        chain_color_over([(res, dl)], m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE)
+        _lib.check(lib.cvs_stream_sync(None))
+        assert_same_f16(res.download().array, golden["chain%d" % nl], "chain %d" % nl)
+    taps = synth.gaussian_taps(9, 1.5)
+    src = DeviceFrame.from_host(synth.layer_frame(96, 54, 1, 0))
+    small = DeviceFrame((0, 0, 47, 26), np.uint16)
+    _lib.check(lib.cvs_blur_lanczos_f16_dev(small.ref(), src.ref(), taps.ctypes.data_as(C.POINTER(C.c_float)), 9,
+                                            C.c_float(0.5), C.c_float(0.5), 3, None))
+    assert_same_f16(small.download().array, golden["config3_96x54"], "config 3")

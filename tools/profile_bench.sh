@@ -1,9 +1,14 @@
+#!/bin/bash
+# rocprofv3 evidence for the bench kernel: one kernel-trace/stats run, then one run per PMC group
+# (FETCH_SIZE and WRITE_SIZE cannot share a pass; no --pmc together with other trace domains).
+# Run on the GPU box from the repo root:  bash tools/profile_bench.sh ; summaries -> tools/summarize_profile.py
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > gpurun_out/prof_trace.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/prof_pmc1 -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/prof_pmc1.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d gpurun_out/prof_pmc2 -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/prof_pmc2.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/prof_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/prof_write.log 2>&1
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+B="python bench.py --batch 8 --no-cpu-baseline"
+rm -rf gpurun_out/prof_trace gpurun_out/prof_pmc1 gpurun_out/prof_pmc2 gpurun_out/prof_fetch gpurun_out/prof_write
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace -- $B --steps 20 --warmup 3 > gpurun_out/prof_trace.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/prof_pmc1 -- $B --steps 6 --warmup 2 > gpurun_out/prof_pmc1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d gpurun_out/prof_pmc2 -- $B --steps 6 --warmup 2 > gpurun_out/prof_pmc2.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -- $B --steps 6 --warmup 2 > gpurun_out/prof_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -- $B --steps 6 --warmup 2 > gpurun_out/prof_write.log 2>&1
 find gpurun_out -name "*.csv" | head -40
