@@ -16,7 +16,23 @@ CVS_EXPORT int cvs_color_matrix_f16_dev(rgba_frame_f16 *frame, const float m[9],
     if (!cvs_box_contains(&frame->full_window, &frame->current_window)) { cvs_set_error("colour matrix: current_window outside the buffer"); return -1; }
     const half *pre = cvs_lut_dev_or_null(pre_lut), *post = cvs_lut_dev_or_null(post_lut);
     if ((pre_lut != CVS_LUT_NONE && !pre) || (post_lut != CVS_LUT_NONE && !post)) return -1;
-    CVS_KERNEL(cvk_color_matrix(cvs_view(frame->data, &frame->full_window), cvs_rect(&frame->current_window), m, pre, post, cvs_cus(), cvs_pick_stream(s)));
+    cvk_view v = cvs_view(frame->data, &frame->full_window);
+    CVS_KERNEL(cvk_color_matrix(v, v, cvs_rect(&frame->current_window), m, pre, post, cvs_cus(), cvs_pick_stream(s)));
+    return 0;
+}
+
+/* the same filter writing into another frame: out.current = out.full ∩ in.current (the one-input window rule,
+ * gl.c:584), one pass instead of video_copy_frame_f16 + the in-place filter */
+CVS_EXPORT int cvs_color_matrix_f16_to_dev(rgba_frame_f16 *out, const rgba_frame_f16 *in, const float m[9], int pre_lut, int post_lut, cvs_stream_t s) {
+    if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
+    box2i win;
+    box2i_intersect(&win, &out->full_window, &in->current_window);
+    out->current_window = win;
+    if (box2i_is_empty(&win)) return 0;
+    if (!cvs_box_contains(&in->full_window, &win)) { cvs_set_error("colour matrix: source window outside its buffer"); box2i_set_empty(&out->current_window); return -1; }
+    const half *pre = cvs_lut_dev_or_null(pre_lut), *post = cvs_lut_dev_or_null(post_lut);
+    if ((pre_lut != CVS_LUT_NONE && !pre) || (post_lut != CVS_LUT_NONE && !post)) { box2i_set_empty(&out->current_window); return -1; }
+    CVS_KERNEL(cvk_color_matrix(cvs_view(out->data, &out->full_window), cvs_view(in->data, &in->full_window), cvs_rect(&win), m, pre, post, cvs_cus(), cvs_pick_stream(s)));
     return 0;
 }
 
@@ -83,7 +99,7 @@ static int chain_unfused(const cvs_chain_job *j, const float m[9], int pre_lut, 
     for (int k = 0; rc == 0 && k < j->nlayers; k++) {
         /* the layer source: a graded copy of the input, clipped like video_copy_frame_f16 */
         rc = cvs_copy_frame_f16_dev(&graded, j->layers[k], s);
-        if (rc == 0) rc = cvs_color_matrix_f16_dev(&graded, m, pre_lut, post_lut, s);
+        if (rc == 0 && m) rc = cvs_color_matrix_f16_dev(&graded, m, pre_lut, post_lut, s);
         if (rc != 0) break;
         if (!have_acc) {                       /* workspace.c:530: lowest item straight into the output */
             rc = cvs_frame_f16_to_f32_dev(&acc, &graded, s);
@@ -105,6 +121,7 @@ CVS_EXPORT int cvs_chain_color_over_f16_dev(const cvs_chain_job *jobs, int njobs
     if (cvs_enter() != 0) return -1;
     if (njobs <= 0) return 0;
     hipStream_t s = cvs_pick_stream(stream);
+    if (!m && (pre_lut != CVS_LUT_NONE || post_lut != CVS_LUT_NONE)) { cvs_set_error("chain: transfer tables need a colour matrix (m == NULL means no colour stage)"); return -1; }
     const half *pre = cvs_lut_dev_or_null(pre_lut), *post = cvs_lut_dev_or_null(post_lut);
     if ((pre_lut != CVS_LUT_NONE && !pre) || (post_lut != CVS_LUT_NONE && !post)) return -1;
 

@@ -490,6 +490,30 @@ CVS_EXPORT int cvs_fir_blur_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32
     return rc;
 }
 
+/* A blur node between two f16 frames: what video_get_frame_f16 on a blur whose input is an f16 source computes
+ * (widen, framework.h f16->f32 path; both passes in f32; truncate on the way out), in one launch. */
+CVS_EXPORT int cvs_fir_blur_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, const float *taps, int ntaps, cvs_stream_t stream) {
+    if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
+    if (ntaps < 1 || !taps) { cvs_set_error("blur: need at least one tap"); box2i_set_empty(&target->current_window); return -1; }
+    hipStream_t s = cvs_pick_stream(stream);
+    box2i win;
+    box2i_intersect(&win, &source->current_window, &target->full_window);
+    target->current_window = win;
+    if (box2i_is_empty(&win)) return 0;
+    int rc = blur_fused(target->data, &target->full_window, 1, source->data, &source->full_window, &source->current_window, 1, &win, taps, ntaps, s);
+    if (rc == 1) {
+        /* tile too large for LDS: the same nodes one by one on f32 frames */
+        rgba_frame_f32 wide = { cvs_pool_malloc(cvs_box_pixels(&source->full_window) * sizeof(rgba_f32), s), source->full_window, source->full_window };
+        rgba_frame_f32 out = { cvs_pool_malloc(cvs_box_pixels(&target->full_window) * sizeof(rgba_f32), s), target->full_window, target->full_window };
+        rc = (wide.data && out.data) ? cvs_frame_f16_to_f32_dev(&wide, source, s) : -1;
+        if (rc == 0) rc = blur_two_pass(&out, &wide, taps, ntaps, s);
+        if (rc == 0) rc = cvs_frame_f32_to_f16_dev(target, &out, s);
+        cvs_pool_free(wide.data, s); cvs_pool_free(out.data, s);
+    }
+    if (rc != 0) box2i_set_empty(&target->current_window);
+    return rc;
+}
+
 CVS_EXPORT int cvs_resample_lanczos_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, float fx, float fy, int ksize, cvs_stream_t stream) {
     if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
     if (!(fx > 0.0f) || !(fy > 0.0f) || ksize < 1 || box2i_is_empty(&source->current_window) || box2i_is_empty(&target->full_window)) {

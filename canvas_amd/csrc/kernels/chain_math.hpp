@@ -90,12 +90,49 @@ __device__ __forceinline__ u32x4 narrow_pair(px32x2 v) {
     return u32x4{ pkrtz(v.r.x, v.g.x), pkrtz(v.b.x, v.a.x), pkrtz(v.r.y, v.g.y), pkrtz(v.b.y, v.a.y) };
 }
 
+// a layer as the stack sees it: through the colour filter, or (mat.plain, wave-uniform) just widened
+template <bool PRE, bool POST>
+__device__ __forceinline__ px32x2 layer_pair(u32x4 p, const Mat &mat, const uint16_t *lut, const uint16_t *post) {
+    if (mat.plain) return widen2(make_uint4(p.x, p.y, p.z, p.w));
+    return grade_pair<PRE, POST>(p, mat, lut, post);
+}
+
 template <int NL, bool PRE, bool POST>
 __device__ __forceinline__ u32x4 chain_pair_lean(const u32x4 (&w)[NL], const Mat &mat, const uint16_t *lut, const uint16_t *post) {
-    px32x2 acc = grade_pair<PRE, POST>(w[0], mat, lut, post);
+    px32x2 acc = layer_pair<PRE, POST>(w[0], mat, lut, post);
 #pragma unroll
-    for (int k = 1; k < NL; k++) acc = over_pair(acc, grade_pair<PRE, POST>(w[k], mat, lut, post));
+    for (int k = 1; k < NL; k++) acc = over_pair(acc, layer_pair<PRE, POST>(w[k], mat, lut, post));
     return narrow_pair(acc);
+}
+
+// the colour filter alone, codes in -> codes out (color.c structure on a pair of pixels)
+template <bool PRE, bool POST>
+__device__ __forceinline__ u32x4 color_pair_codes(u32x4 p, const Mat &mat, const uint16_t *lds_lut, const uint16_t *glb_post) {
+    uint32_t c[8] = { p.x & 0xFFFFu, p.x >> 16, p.y & 0xFFFFu, p.y >> 16, p.z & 0xFFFFu, p.z >> 16, p.w & 0xFFFFu, p.w >> 16 };
+    if (PRE) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) c[i] = lds_lut[c[i]];
+    }
+    px32x2 v;
+    v.r = f32x2{ h2f(c[0]), h2f(c[4]) };
+    v.g = f32x2{ h2f(c[1]), h2f(c[5]) };
+    v.b = f32x2{ h2f(c[2]), h2f(c[6]) };
+    px32x2 o = mat3x2(v, mat.m);
+    const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.r.x), __builtin_fabsf(o.g.x)), __builtin_fabsf(o.b.x)),
+                                      __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.r.y), __builtin_fabsf(o.g.y)), __builtin_fabsf(o.b.y)));
+    if (wave_any(big >= 65536.0f)) { o.r = saturate_to_inf2(o.r); o.g = saturate_to_inf2(o.g); o.b = saturate_to_inf2(o.b); }
+    uint32_t rr = pkrtz(o.r.x, o.r.y), gg = pkrtz(o.g.x, o.g.y), bb = pkrtz(o.b.x, o.b.y);    // lo: first pixel, hi: second
+    uint32_t q[8] = { rr & 0xFFFFu, gg & 0xFFFFu, bb & 0xFFFFu, c[3], rr >> 16, gg >> 16, bb >> 16, c[7] };
+    constexpr bool post_lds = POST && !PRE, post_glb = POST && PRE;
+    if (post_lds) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) q[i] = lds_lut[q[i]];
+    }
+    if (post_glb) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) q[i] = glb_post[q[i]];
+    }
+    return u32x4{ q[0] | (q[1] << 16), q[2] | (q[3] << 16), q[4] | (q[5] << 16), q[6] | (q[7] << 16) };
 }
 
 }  // namespace cvs

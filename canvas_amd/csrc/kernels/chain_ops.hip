@@ -35,10 +35,10 @@ struct Batch { cvk_chain_job jobs[kJobsPerLaunch]; };
 
 template <int MAXL, bool PRE, bool POST>
 __device__ __forceinline__ uint2 chain_pixel(const uint2 (&px)[MAXL], int nl, const Mat &mat, const uint16_t *lut, const uint16_t *post) {
-    px32 acc = grade<PRE, POST>(px[0], mat, lut, post);
+    px32 acc = mat.plain ? widen(px[0]) : grade<PRE, POST>(px[0], mat, lut, post);
 #pragma unroll
     for (int k = 1; k < MAXL; k++)      // static indices only: a runtime-indexed array would live in scratch
-        if (k < nl) acc = blend_over(acc, grade<PRE, POST>(px[k], mat, lut, post), 1.0f);
+        if (k < nl) acc = blend_over(acc, mat.plain ? widen(px[k]) : grade<PRE, POST>(px[k], mat, lut, post), 1.0f);
     return narrow(acc);
 }
 
@@ -241,7 +241,7 @@ int launch_v0(const Batch &jobs, int njobs, const Mat &mat, const uint16_t *pre,
 //   CVS_CHAIN_VARIANT  unset/1 = production kernel; 0 = the simple first version (A/B reference);
 //                      10 = memory traffic only, 12 = arithmetic only (diagnostic builds, wrong output)
 //   CVS_CHAIN_BLOCK    lanes per workgroup (default 512 = 2 waves per SIMD; one workgroup per CU)
-extern "C" int cvk_chain_color_over(const cvk_chain_job *jobs, int njobs, int uniform_layers, const float m[9],
+extern "C" int cvk_chain_color_over(const cvk_chain_job *jobs, int njobs, int uniform_layers, const float *m,
                                     const uint16_t *pre, const uint16_t *post, int cus, void *stream) {
     Mat mat = make_mat(m);
     const unsigned grid = (unsigned)(cus > 0 ? cus : 256);

@@ -19,6 +19,7 @@
 // chain = 8 * nlayers r + 8 w per output pixel (config 2: 24 B/px).
 #include "lut_common.hpp"
 #include "grade.hpp"
+#include "chain_math.hpp"
 
 using namespace cvs;
 
@@ -47,21 +48,44 @@ __global__ __launch_bounds__(kWG) void k_lookup(const uint16_t *__restrict__ tab
     }
 }
 
-// ---------------------------------------------------------------- colour matrix in place on a window
+// ---------------------------------------------------------------- colour matrix on a window (dst may be src)
 
 template <bool PRE, bool POST>
-__global__ __launch_bounds__(kWG) void k_color(cvk_view f, cvk_rect r, Mat mat, const uint16_t *__restrict__ pre,
+__global__ __launch_bounds__(kWG) void k_color(cvk_view dst, cvk_view src, cvk_rect r, Mat mat, const uint16_t *__restrict__ pre,
                                                const uint16_t *__restrict__ post) {
     __shared__ uint16_t lut[(PRE || POST) ? kLutHalfs : 1];
     if (PRE) stage_lut(lut, pre);
     else if (POST) stage_lut(lut, post);
     const int w = r.x1 - r.x0 + 1, h = r.y1 - r.y0 + 1;
     const size_t n = (size_t)w * (size_t)h, stride = (size_t)gridDim.x * kWG;
-    uint2 *base = reinterpret_cast<uint2 *>(f.data);
     for (size_t i = (size_t)blockIdx.x * kWG + threadIdx.x; i < n; i += stride) {
         int row = (int)(i / (size_t)w), col = (int)(i - (size_t)row * (size_t)w);
-        uint2 *p = base + (size_t)(r.y0 + row - f.fy0) * (size_t)f.pitch + (size_t)(r.x0 + col - f.fx0);
-        *p = grade_h<PRE, POST>(*p, mat, lut, post);
+        const uint2 *p = reinterpret_cast<const uint2 *>(src.data) + (size_t)(r.y0 + row - src.fy0) * (size_t)src.pitch + (size_t)(r.x0 + col - src.fx0);
+        uint2 *q = reinterpret_cast<uint2 *>(dst.data) + (size_t)(r.y0 + row - dst.fy0) * (size_t)dst.pitch + (size_t)(r.x0 + col - dst.fx0);
+        *q = grade_h<PRE, POST>(*p, mat, lut, post);
+    }
+}
+
+// whole rows, both buffers packed the same way: a flat stream of pixel pairs (16 B per lane, non-temporal),
+// 512 lanes per CU as in the chain kernel.  8 B read + 8 B written per pixel.
+template <bool PRE, bool POST>
+__global__ __launch_bounds__(kWG) void k_color_flat(uint16_t *__restrict__ dst, const uint16_t *__restrict__ src, size_t npixels, Mat mat,
+                                                    const uint16_t *__restrict__ pre, const uint16_t *__restrict__ post) {
+    __shared__ uint16_t lut[(PRE || POST) ? kLutHalfs : 1];
+    if (PRE || POST) {
+        const uint4 *t = reinterpret_cast<const uint4 *>(PRE ? pre : post);
+        uint4 *d = reinterpret_cast<uint4 *>(lut);
+        for (int i = threadIdx.x; i < kLutHalfs * 2 / 16; i += blockDim.x) d[i] = t[i];
+        __syncthreads();
+    }
+    const size_t npairs = npixels / 2, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += stride) {
+        const u32x4 p = __builtin_nontemporal_load((g_cu4)src + i);
+        __builtin_nontemporal_store(color_pair_codes<PRE, POST>(p, mat, lut, post), (g_u4)dst + i);
+    }
+    if ((npixels & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint2 p = reinterpret_cast<const uint2 *>(src)[npixels - 1];
+        reinterpret_cast<uint2 *>(dst)[npixels - 1] = grade_h<PRE, POST>(p, mat, lut, post);
     }
 }
 
@@ -74,17 +98,30 @@ extern "C" int cvk_half_lookup(const uint16_t *table, uint16_t *out, const uint1
     return (int)hipGetLastError();
 }
 
-extern "C" int cvk_color_matrix(cvk_view frame, cvk_rect r, const float m[9], const uint16_t *pre, const uint16_t *post,
+extern "C" int cvk_color_matrix(cvk_view dst, cvk_view src, cvk_rect r, const float m[9], const uint16_t *pre, const uint16_t *post,
                                 int cus, void *stream) {
     if (r.x1 < r.x0 || r.y1 < r.y0) return 0;
     size_t n = (size_t)(r.x1 - r.x0 + 1) * (size_t)(r.y1 - r.y0 + 1);
-    dim3 grid(persistent_grid(cus, n)), block(kWG);
     Mat mat = make_mat(m);
     hipStream_t s = (hipStream_t)stream;
-    if (pre && post)  hipLaunchKernelGGL((k_color<true, true>), grid, block, 0, s, frame, r, mat, pre, post);
-    else if (pre)     hipLaunchKernelGGL((k_color<true, false>), grid, block, 0, s, frame, r, mat, pre, post);
-    else if (post)    hipLaunchKernelGGL((k_color<false, true>), grid, block, 0, s, frame, r, mat, pre, post);
-    else              hipLaunchKernelGGL((k_color<false, false>), grid, block, 0, s, frame, r, mat, pre, post);
+    // full rows of both buffers, same pitch: the rectangle is one contiguous run of pixels
+    const bool rows = r.x0 == dst.fx0 && r.x1 == dst.fx1 && r.x0 == src.fx0 && r.x1 == src.fx1 && dst.pitch == src.pitch;
+    if (rows) {
+        uint16_t *d = reinterpret_cast<uint16_t *>(dst.data) + (size_t)(r.y0 - dst.fy0) * (size_t)dst.pitch * 4;
+        const uint16_t *q = reinterpret_cast<const uint16_t *>(src.data) + (size_t)(r.y0 - src.fy0) * (size_t)src.pitch * 4;
+        if (((((uintptr_t)d) | ((uintptr_t)q)) & 15u) == 0) {
+            dim3 grid((unsigned)(cus > 0 ? cus : 256)), block(512);
+            if (pre && post)  hipLaunchKernelGGL((k_color_flat<true, true>), grid, block, 0, s, d, q, n, mat, pre, post);
+            else if (pre)     hipLaunchKernelGGL((k_color_flat<true, false>), grid, block, 0, s, d, q, n, mat, pre, post);
+            else if (post)    hipLaunchKernelGGL((k_color_flat<false, true>), grid, block, 0, s, d, q, n, mat, pre, post);
+            else              hipLaunchKernelGGL((k_color_flat<false, false>), grid, block, 0, s, d, q, n, mat, pre, post);
+            return (int)hipGetLastError();
+        }
+    }
+    dim3 grid(persistent_grid(cus, n)), block(kWG);
+    if (pre && post)  hipLaunchKernelGGL((k_color<true, true>), grid, block, 0, s, dst, src, r, mat, pre, post);
+    else if (pre)     hipLaunchKernelGGL((k_color<true, false>), grid, block, 0, s, dst, src, r, mat, pre, post);
+    else if (post)    hipLaunchKernelGGL((k_color<false, true>), grid, block, 0, s, dst, src, r, mat, pre, post);
+    else              hipLaunchKernelGGL((k_color<false, false>), grid, block, 0, s, dst, src, r, mat, pre, post);
     return (int)hipGetLastError();
 }
-

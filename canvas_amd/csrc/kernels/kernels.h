@@ -51,8 +51,9 @@ typedef struct {
 } cvk_mix_params;
 int cvk_mix(const cvk_mix_params *mp, void *stream);
 
-/* colour matrix on an f16 frame, in place, color.c structure; LUT pointers are device tables or NULL */
-int cvk_color_matrix(cvk_view frame, cvk_rect r, const float m[9], const uint16_t *pre_lut,
+/* colour matrix on an f16 frame (dst may be the same buffer as src), color.c structure; LUT pointers are
+ * device tables or NULL */
+int cvk_color_matrix(cvk_view dst, cvk_view src, cvk_rect r, const float m[9], const uint16_t *pre_lut,
                      const uint16_t *post_lut, int cus, void *stream);
 
 /* fused colour + over chain; `jobs` is a HOST array (records are passed as kernel arguments,
@@ -65,7 +66,8 @@ typedef struct {
     int pad;
     uint64_t npixels;
 } cvk_chain_job;
-int cvk_chain_color_over(const cvk_chain_job *jobs, int njobs, int uniform_layers, const float m[9],
+/* m == NULL: no colour stage (plain over stack of the f16 layers) */
+int cvk_chain_color_over(const cvk_chain_job *jobs, int njobs, int uniform_layers, const float *m,
                          const uint16_t *pre_lut, const uint16_t *post_lut, int cus, void *stream);
 
 /* separable FIR passes (video_scale.c structure) */

@@ -9,7 +9,7 @@ namespace cvs {
 constexpr int kWG = 1024;                  // 16 waves: the LDS table allows one workgroup per CU
 constexpr int kLutHalfs = 65536;
 
-struct Mat { float m[9]; };
+struct Mat { float m[9]; int plain; };     // plain: no colour stage at all (layers go straight to the stack)
 
 // Pointers that arrive inside a job record are generic to the compiler, which then emits flat_load
 // (counts on BOTH vmcnt and lgkmcnt and so serialises against the LDS gathers).  Tell it they are global.
@@ -48,9 +48,10 @@ inline unsigned persistent_grid(int cus, size_t work_items) {
     return (unsigned)g;
 }
 
-inline Mat make_mat(const float m[9]) {
+inline Mat make_mat(const float *m) {
     Mat r;
-    for (int i = 0; i < 9; i++) r.m[i] = m[i];
+    r.plain = m ? 0 : 1;
+    for (int i = 0; i < 9; i++) r.m[i] = m ? m[i] : (i % 4 == 0 ? 1.0f : 0.0f);
     return r;
 }
 

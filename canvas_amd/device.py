@@ -82,7 +82,7 @@ def chain_color_over(jobs, matrix, pre_lut=_lib.LUT_NONE, post_lut=_lib.LUT_NONE
         for k, l in enumerate(layers):
             arr[i].layers[k] = C.pointer(l.c)
         arr[i].nlayers = len(layers)
-    m = np.ascontiguousarray(matrix, np.float32).reshape(9)
-    rc = lib.cvs_chain_color_over_f16_dev(arr, len(jobs), m.ctypes.data_as(C.POINTER(C.c_float)), pre_lut, post_lut, stream)
+    m = None if matrix is None else np.ascontiguousarray(matrix, np.float32).reshape(9)      # None: plain over stack
+    rc = lib.cvs_chain_color_over_f16_dev(arr, len(jobs), None if m is None else m.ctypes.data_as(C.POINTER(C.c_float)), pre_lut, post_lut, stream)
     _lib.check(rc, "cvs_chain_color_over_f16_dev")
     return arr

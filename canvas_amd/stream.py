@@ -1,0 +1,74 @@
+"""BASELINE config 5: a 10-node graph over a synthetic frame stream, on device frames.
+
+    stream input S ─ colour(Rec.709 LUT + RGB→Y'PbPr) ─ blur(9-tap separable Gaussian) ─┐
+    overlay sources O1..O4 ─────────────────────────────────────────────────────────────┴ over ×4 → output
+
+Ten nodes = colour + blur + four overlay sources + four alpha-over steps (the stream input is what
+feeds the graph).  In the reference this is a colour filter on an f16 source (color.c structure), a blur
+node pulled through video_get_frame_f16 (main.c:43-71 widen/truncate), and a workspace whose five items
+are stacked with video_mix_over_f32(mix 1.0) (workspace.c:530-544).  Here it is three launches per frame:
+
+    cvs_color_matrix_f16_to_dev   8 B read + 8 B written per pixel
+    cvs_fir_blur_f16_dev          8 B read + 8 B written
+    cvs_chain_color_over (m=NULL) 5 x 8 B read + 8 B written          => 80 B per output pixel
+
+Frames are independent, so frame g belongs to rank g % world (shard.frames_of_rank); nothing is
+exchanged on the data path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, synth
+from .device import DeviceFrame, chain_color_over
+from .shard import frames_of_rank
+
+BYTES_PER_PIXEL = 16 + 16 + 48
+OVERLAYS = 4
+
+
+class GraphStream:
+    """Device-resident ring of input sets plus the intermediates of one in-flight frame per slot."""
+
+    def __init__(self, width, height, ring=4, matrix=None, pre_lut=_lib.LUT_REC709_TO_LINEAR_SCENE,
+                 post_lut=_lib.LUT_NONE, taps=None, overlays=OVERLAYS, first_frame=0):
+        from . import REC709_RGB_TO_YPBPR
+        self.lib = _lib.load()
+        self.w, self.h, self.ring, self.overlays = width, height, ring, overlays
+        self.full = (0, 0, width - 1, height - 1)
+        self.matrix = np.ascontiguousarray(REC709_RGB_TO_YPBPR if matrix is None else matrix, np.float32).reshape(9)
+        self.pre_lut, self.post_lut = pre_lut, post_lut
+        self.taps = np.ascontiguousarray(synth.gaussian_taps(9, 1.5) if taps is None else taps, np.float32)
+        self.slots = []
+        for slot in range(ring):
+            src = DeviceFrame(self.full, np.uint16)
+            src.upload(synth.layer_pixels(width, height, 0, first_frame + slot))
+            over = []
+            for k in range(1, overlays + 1):
+                o = DeviceFrame(self.full, np.uint16)
+                o.upload(synth.layer_pixels(width, height, k, first_frame + slot))
+                over.append(o)
+            self.slots.append({"src": src, "over": over, "graded": DeviceFrame(self.full, np.uint16),
+                               "blurred": DeviceFrame(self.full, np.uint16), "out": DeviceFrame(self.full, np.uint16)})
+        self._m = self.matrix.ctypes.data_as(C.POINTER(C.c_float))
+        self._t = self.taps.ctypes.data_as(C.POINTER(C.c_float))
+
+    @staticmethod
+    def host_inputs(width, height, frame, overlays=OVERLAYS):
+        """The synthetic inputs of stream frame `frame` as host frames (what the oracle is run on)."""
+        return [synth.layer_frame(width, height, k, frame) for k in range(overlays + 1)]
+
+    def render(self, slot, stream=None):
+        """Enqueue the three launches of one frame on `stream`; returns the output DeviceFrame."""
+        s, lib = self.slots[slot % self.ring], self.lib
+        _lib.check(lib.cvs_color_matrix_f16_to_dev(s["graded"].ref(), s["src"].ref(), self._m, self.pre_lut, self.post_lut, stream), "colour")
+        _lib.check(lib.cvs_fir_blur_f16_dev(s["blurred"].ref(), s["graded"].ref(), self._t, len(self.taps), stream), "blur")
+        chain_color_over([(s["out"], [s["blurred"]] + s["over"])], None, stream=stream)
+        return s["out"]
+
+    def run(self, frames, rank=0, world=1, stream=None):
+        """Render this rank's share of stream frames [0, frames); returns how many it rendered."""
+        mine = frames_of_rank(rank, world, frames)
+        for i, _g in enumerate(mine):
+            self.render(i, stream)
+        return len(mine)

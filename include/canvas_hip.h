@@ -270,6 +270,8 @@ CVS_EXPORT int cvs_mix_over_f32_dev(rgba_frame_f32 *out, const rgba_frame_f32 *b
 /* colour matrix with the color.c structure; m is column-major as color.c passes it:
  * m[0..2] = coefficients multiplying r (a.x a.y a.z), m[3..5] those of g, m[6..8] those of b */
 CVS_EXPORT int cvs_color_matrix_f16_dev(rgba_frame_f16 *frame, const float m[9], int pre_lut, int post_lut, cvs_stream_t s);
+/* the same filter, out of place: out.current = out.full ∩ in.current, one pass */
+CVS_EXPORT int cvs_color_matrix_f16_to_dev(rgba_frame_f16 *out, const rgba_frame_f16 *in, const float m[9], int pre_lut, int post_lut, cvs_stream_t s);
 CVS_EXPORT int cvs_gain_offset_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *in, float gain, float offset, cvs_stream_t s);
 CVS_EXPORT int cvs_fill_solid_f16_dev(rgba_frame_f16 *frame, const box2i *window, const rgba_f32 *color, cvs_stream_t s);
 CVS_EXPORT int cvs_fill_solid_f32_dev(rgba_frame_f32 *frame, const box2i *window, const rgba_f32 *color, cvs_stream_t s);
@@ -277,6 +279,8 @@ CVS_EXPORT int cvs_scale_bilinear_f32_dev(rgba_frame_f32 *target, v2f target_poi
 /* separable FIR blur at factor 1 (absent from the reference; defined in DESIGN.md) and the Lanczos
  * gather resampler built on filter_createLanczos */
 CVS_EXPORT int cvs_fir_blur_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, const float *taps_host, int ntaps, cvs_stream_t s);
+/* blur node between two f16 frames (widen on load, f32 passes, truncate on store), one launch */
+CVS_EXPORT int cvs_fir_blur_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, const float *taps, int ntaps, cvs_stream_t stream);
 CVS_EXPORT int cvs_resample_lanczos_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, float factor_x, float factor_y, int kernel_size, cvs_stream_t s);
 /* BASELINE config 3 on f16 frames: widen -> blur -> Lanczos resample -> truncate, f32 in between, two launches */
 CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, const float *taps_host, int ntaps,
@@ -292,6 +296,7 @@ typedef struct {
     const rgba_frame_f16 *layers[CVS_CHAIN_MAX_LAYERS];/* device frames, bottom first */
     int nlayers;
 } cvs_chain_job;
+/* m == NULL: no colour stage -- the plain workspace stack of f16 layers (both tables must then be CVS_LUT_NONE) */
 CVS_EXPORT int cvs_chain_color_over_f16_dev(const cvs_chain_job *jobs, int njobs, const float m[9],
                                             int pre_lut, int post_lut, cvs_stream_t s);
 /* how the last chain call ran: 1 = single fused kernel, 0 = node-by-node device kernels

@@ -150,10 +150,10 @@ def chain_color_over(layers, matrix, pre_lut=None, post_lut=None, full_window=No
     fw = full_window or layers[0].full_window
     out = HostFrame(fw, np.uint16)
     arr = (C.POINTER(rgba_frame_f16) * len(layers))(*[C.pointer(l.c) for l in layers])
-    m = np.ascontiguousarray(matrix, np.float32).reshape(9)
+    m = None if matrix is None else np.ascontiguousarray(matrix, np.float32).reshape(9)    # None: plain stack
     pre_a = None if pre_lut is None else np.ascontiguousarray(pre_lut, np.uint16)
     post_a = None if post_lut is None else np.ascontiguousarray(post_lut, np.uint16)
-    lib().orc_chain_color_over_f16(out.ref(), arr, len(layers), _f32(m),
+    lib().orc_chain_color_over_f16(out.ref(), arr, len(layers), None if m is None else _f32(m),
                                    None if pre_a is None else _u16(pre_a),
                                    None if post_a is None else _u16(post_a))
     return out

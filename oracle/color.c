@@ -132,7 +132,7 @@ void orc_chain_color_over_f16(orc_frame16 *out, orc_frame16 *const *layers, int 
         graded[k] = *layers[k];
         graded[k].data = malloc(n * sizeof(orc_px16));
         memcpy(graded[k].data, layers[k]->data, n * sizeof(orc_px16));
-        orc_color_matrix_f16(&graded[k], m, pre_lut, post_lut);
+        if (m) orc_color_matrix_f16(&graded[k], m, pre_lut, post_lut);     /* m == NULL: the layers go to the stack as they are */
         ls[k].frame = &graded[k];
         srcs[k].obj = &ls[k]; srcs[k].funcs = &lf;
         items[k].x = 0; items[k].length = 1; items[k].z = k; items[k].offset = 0; items[k].source = &srcs[k];

@@ -731,3 +731,101 @@ def test_config4_8k_three_layer_properties(cvs, orc):
     want = orc.chain_color_over(heads, ident, None, None)
     assert_same_f16(two[:rows], want.array, "8K head rows")
     del rng
+
+
+# ------------------------------------------------------------------ config 5 pieces: plain stack, out-of-place colour, f16 blur
+
+@pytest.mark.parametrize("nlayers", [1, 2, 4, 5])
+@pytest.mark.parametrize("translucent", [False, True])
+def test_plain_over_stack_matches_oracle(cvs, orc, nlayers, translucent):
+    """m == NULL: no colour node, just the workspace stack of f16 layers."""
+    w, h = 71, 23
+    full = (0, 0, w - 1, h - 1)
+    if translucent:
+        rng = np.random.default_rng(300 + nlayers)
+        from canvas_amd.synth import truncate_to_half
+        layers = [HostFrame(full, np.uint16, truncate_to_half(rand_f32_frame(rng, full, full, alpha="mixed", lo=-0.25, hi=1.5).array))
+                  for _ in range(nlayers)]
+    else:
+        layers = _synth_layers(w, h, nlayers)
+    want = orc.chain_color_over(layers, None)
+    dl = [DeviceFrame.from_host(l) for l in layers]
+    out = DeviceFrame(full, np.uint16)
+    chain_color_over([(out, dl)], None)
+    _lib.check(cvs.cvs_stream_sync(None))
+    assert cvs.cvs_chain_last_was_fused() == 1
+    assert_same_f16(out.download().array, want.array, "plain stack, %d layers" % nlayers)
+
+
+def test_plain_stack_rejects_tables_and_takes_ragged_windows(cvs, orc):
+    full = (0, 0, 47, 19)
+    rng = np.random.default_rng(13)
+    layers = [rand_f16_frame(rng, full, full, alpha="one"), rand_f16_frame(rng, full, (5, 3, 30, 15))]
+    dl = [DeviceFrame.from_host(l) for l in layers]
+    out = DeviceFrame(full, np.uint16)
+    with pytest.raises(RuntimeError):
+        chain_color_over([(out, dl)], None, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE)
+    want = orc.chain_color_over(layers, None)
+    chain_color_over([(out, dl)], None)
+    assert cvs.cvs_chain_last_was_fused() == 0
+    got = out.download()
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f16(got.window_view(), want.window_view(), "plain stack, node by node")
+
+
+@pytest.mark.parametrize("pre,post", [(-1, -1), (0, -1), (0, 2)])
+@pytest.mark.parametrize("geom", [((0, 0, 63, 35), (0, 0, 63, 35), (0, 0, 63, 35)),          # whole frame: flat kernel
+                                  ((0, 0, 62, 34), (0, 0, 62, 34), (0, 0, 62, 34)),          # odd pixel count
+                                  ((-2, -2, 50, 30), (0, 0, 63, 35), (3, 1, 60, 33))])       # windows differ: rect kernel
+def test_colour_matrix_out_of_place(cvs, orc, pre, post, geom):
+    out_full, in_full, in_cur = geom
+    rng = np.random.default_rng(7)
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    src = rand_f16_frame(rng, in_full, in_cur)
+    src.array[4, 4] = [0x8400, 0x0001, 0x7BFF, 0xC000]
+    # reference sequence: video_copy_frame_f16 into the output, then the filter in place
+    want = HostFrame(out_full, np.uint16)
+    orc.lib().orc_copy_frame_f16(want.ref(), src.ref())
+    orc.lib().orc_color_matrix_f16(want.ref(), f32p(m), None if pre < 0 else u16p(orc.transfer_table(pre)),
+                                   None if post < 0 else u16p(orc.transfer_table(post)))
+    d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(out_full, np.uint16)
+    _lib.check(cvs.cvs_color_matrix_f16_to_dev(d_out.ref(), d_src.ref(), f32p(m), pre, post, None))
+    got = d_out.download()
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f16(got.window_view(), want.window_view(), "colour matrix out of place")
+    assert np.array_equal(d_src.download().array, src.array)          # the source is left alone
+
+
+@pytest.mark.parametrize("scur", [(0, 0, 47, 26), (5, 3, 40, 20)])
+@pytest.mark.parametrize("ntaps", [9, 1, 4])
+def test_fir_blur_f16(cvs, orc, scur, ntaps):
+    rng = np.random.default_rng(52)
+    full = (0, 0, 47, 26)
+    src = rand_f16_frame(rng, full, scur)
+    taps = synth.gaussian_taps(ntaps, 1.5)
+    src32 = HostFrame(full, np.float32, orc.half_to_float(src.array), src.current_window)
+    want32 = HostFrame(full, np.float32)
+    orc.lib().orc_fir_blur_f32(want32.ref(), src32.ref(), f32p(taps), ntaps)
+    want = HostFrame(full, np.uint16, orc.float_to_half(want32.array), want32.current_window)
+    d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(full, np.uint16)
+    _lib.check(cvs.cvs_fir_blur_f16_dev(d_out.ref(), d_src.ref(), f32p(taps), ntaps, None))
+    got = d_out.download()
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f16(got.window_view(), want.window_view(), "f16 blur")
+
+
+@pytest.mark.parametrize("size", [(96, 54), (131, 37)])
+def test_config5_graph_stream_against_oracle(cvs, orc, size):
+    """colour -> blur -> 4x over on three stream frames, every pixel, against the oracle's node-by-node run."""
+    from canvas_amd.stream import GraphStream
+    from tests.util import oracle_graph
+    w, h = size
+    g = GraphStream(w, h, ring=3)
+    for frame in range(3):
+        out = g.render(frame)
+        _lib.check(cvs.cvs_stream_sync(None))
+        assert cvs.cvs_chain_last_was_fused() == 1
+        want = oracle_graph(orc, GraphStream.host_inputs(w, h, frame), g.matrix, orc.transfer_table(0), None, g.taps)
+        got = out.download()
+        assert same_window(got.current_window, want.current_window)
+        assert_same_f16(got.array, want.array, "config 5 graph, frame %d" % frame)

@@ -77,3 +77,18 @@ def f32p(a):
 
 def u16p(a):
     return a.ctypes.data_as(C.POINTER(C.c_uint16))
+
+
+def oracle_graph(orc, layers, matrix, pre_table, post_table, taps):
+    """BASELINE config 5 with the CPU oracle's nodes: colour filter on an f16 copy, blur pulled as f16
+    (widen, f32 passes, truncate), then the five-item workspace stack."""
+    src = layers[0]
+    graded = src.copy()
+    m = np.ascontiguousarray(matrix, np.float32).reshape(9)
+    taps = np.ascontiguousarray(taps, np.float32)
+    orc.lib().orc_color_matrix_f16(graded.ref(), f32p(m), None if pre_table is None else u16p(pre_table), None if post_table is None else u16p(post_table))
+    wide = HostFrame(graded.full_window, np.float32, orc.half_to_float(graded.array), graded.current_window)
+    blurred32 = HostFrame(graded.full_window, np.float32)
+    orc.lib().orc_fir_blur_f32(blurred32.ref(), wide.ref(), f32p(taps), len(taps))
+    blurred = HostFrame(graded.full_window, np.uint16, orc.float_to_half(blurred32.array), blurred32.current_window)
+    return orc.chain_color_over([blurred] + list(layers[1:]), None)
