@@ -55,7 +55,7 @@ class GraphStream:
 
     @staticmethod
     def host_inputs(width, height, frame, overlays=OVERLAYS):
-        """The synthetic inputs of stream frame `frame` as host frames (what the oracle is run on)."""
+        """The synthetic inputs of stream frame `frame` as host frames (for checking a rendered frame)."""
         return [synth.layer_frame(width, height, k, frame) for k in range(overlays + 1)]
 
     def render(self, slot, stream=None):
