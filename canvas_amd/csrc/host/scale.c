@@ -457,6 +457,23 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
 
 static int blur_fused(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
                       const box2i *win, const float *taps, int ntaps, hipStream_t s) {
+    /* one tap list for every line: the register-window kernel, when it has an instance for this length */
+    bool finite = true;
+    for (int k = 0; k < ntaps; k++) finite = finite && isfinite(taps[k]);
+    if (finite && cvk_blur_supported(ntaps) && !getenv("CVS_BLUR_GENERIC")) {
+        cvk_blur_params bp;
+        memset(&bp, 0, sizeof bp);
+        bp.target = cvs_view(tdata, tfull);
+        bp.source = cvs_view((void *)sdata, sfull);
+        bp.in_half = in_half; bp.out_half = out_half;
+        bp.tx0 = win->min.x; bp.ty0 = win->min.y; bp.tx1 = win->max.x; bp.ty1 = win->max.y;
+        bp.sx0 = sw->min.x; bp.sy0 = sw->min.y; bp.sx1 = sw->max.x; bp.sy1 = sw->max.y;
+        bp.ntaps = ntaps;
+        memcpy(bp.taps, taps, sizeof(float) * (size_t)ntaps);
+        int rc = cvk_blur(&bp, cvs_cus(), s);
+        if (rc != 0) { cvs_set_error("blur launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
+        return 0;
+    }
     const uint64_t th = fnv1a(taps, sizeof(float) * (size_t)ntaps);
     axis_key kh = make_key(1, 0, ntaps, th, win->min.x, win->max.x, sw->min.x, sw->max.x, CVK_FIR2D_TILE_X);
     axis_key kv = make_key(1, 0, ntaps, th, win->min.y, win->max.y, sw->min.y, sw->max.y, CVK_FIR2D_TILE_Y);

@@ -1,0 +1,192 @@
+// blur_ops.hip -- separable FIR blur with one fixed tap list, both passes in one sweep down the frame.
+//
+// The blur node (DESIGN.md "A11") is the video_scale.c FIR structure with the same taps for every line:
+//   target(x, y) = sum_k taps[k] * H(x, y - c + k),   H(x, y) = sum_k taps[k] * src(x - c + k, y),   c = ntaps / 2,
+// every sum started at 0.0f and taken in ascending k with separately rounded mul and add, taps that fall
+// outside the source's current window skipped.  k_fir2d does this for arbitrary per-line tap tables with
+// LDS gathers on both axes; here the taps are uniform, so the vertical window can live in REGISTERS:
+//
+//   a workgroup owns a strip of W-(NT-1) target columns and marches down a segment of rows;
+//   per source row: one coalesced load per lane (f16 widened on the way in) -> LDS row buffer (double
+//   buffered, one barrier per row) -> each lane forms H for its column from NT neighbouring LDS pixels ->
+//   the H row is pushed into an NT-deep register ring -> the vertical sum of the ring is one output row,
+//   stored coalesced (f16 targets truncated here).
+//
+// A skipped tap and a tap on a zero pixel give the same sum when the tap is finite (acc + 0*w == acc; the
+// sign of a zero result is not pinned by the reference build, -fno-signed-zeros), so pixels outside the
+// source window are fed in as zeros; the host sends non-finite tap lists to k_fir2d instead.
+// Source pixels are read once per segment (+ NT-1 halo rows, + NT-1 halo columns per strip, both served
+// by L2), LDS traffic is 1 write + NT reads per pixel, no intermediate frame exists.
+// Bound: HBM.  Algorithmic bytes: source pixel size + target pixel size per target pixel.
+#include <type_traits>
+#include <utility>
+#include "kernels.h"
+#include "pixel_math.hpp"
+
+namespace {
+
+using cvs::f32x2;
+
+struct Px { f32x2 rg, ba; };
+
+template <bool INH> struct Raw;
+template <> struct Raw<true> { uint2 v; };
+template <> struct Raw<false> { float4 v; };
+
+template <bool INH>
+__device__ __forceinline__ Raw<INH> fetch(const char *base, size_t row_bytes, int ys, int fy0, bool live) {
+    Raw<INH> r;
+    if constexpr (INH) r.v = make_uint2(0u, 0u); else r.v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (live) {
+        const char *p = base + (size_t)(ys - fy0) * row_bytes;
+        if constexpr (INH) r.v = *reinterpret_cast<const uint2 *>(p); else r.v = *reinterpret_cast<const float4 *>(p);
+    }
+    return r;
+}
+
+template <bool INH>
+__device__ __forceinline__ float4 widen(const Raw<INH> &r) {
+    if constexpr (INH) return make_float4(cvs::h2f(r.v.x & 0xFFFFu), cvs::h2f(r.v.x >> 16), cvs::h2f(r.v.y & 0xFFFFu), cvs::h2f(r.v.y >> 16));
+    else return r.v;
+}
+
+template <class F, int... Js>
+__device__ __forceinline__ void each_slot(F &f, std::integer_sequence<int, Js...>) {
+    (void)(f(std::integral_constant<int, Js>{}) && ...);
+}
+
+template <int NT, int W, bool INH>
+__global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
+    constexpr int C = NT / 2, OUTW = W - (NT - 1), PITCH = W + 16;
+    __shared__ float4 rowbuf[2][PITCH];
+    const int lane = threadIdx.x;
+    const int xo = bp.tx0 + (int)blockIdx.x * OUTW;          // first target column of the strip
+    const int scol = xo - C + lane;                          // the source column this lane loads
+    const int tcol = xo + lane;                              // the target column this lane produces
+    const bool col_live = scol >= bp.sx0 && scol <= bp.sx1;
+    const bool out_live = lane < OUTW && tcol <= bp.tx1;
+    const int ta = bp.ty0 + (int)blockIdx.y * bp.rows_per_wg;
+    const int tb = min(ta + bp.rows_per_wg - 1, bp.ty1);
+    const int ys0 = ta - C;                                  // first source row the segment needs
+    const int steps = (tb - ta + 1) + NT - 1;
+
+    float w[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) w[k] = bp.taps[k];
+
+    constexpr size_t SPX = INH ? 8 : 16;
+    const size_t srow = (size_t)bp.source.pitch * SPX;
+    const char *sbase = reinterpret_cast<const char *>(bp.source.data) + (ptrdiff_t)(scol - bp.source.fx0) * (ptrdiff_t)SPX;
+    const size_t tpx = bp.out_half ? 8 : 16;
+    char *tbase = reinterpret_cast<char *>(bp.target.data) + (ptrdiff_t)(tcol - bp.target.fx0) * (ptrdiff_t)tpx;
+    const size_t trow = (size_t)bp.target.pitch * tpx;
+
+    if (lane < 16) { rowbuf[0][W + lane] = make_float4(0.f, 0.f, 0.f, 0.f); rowbuf[1][W + lane] = make_float4(0.f, 0.f, 0.f, 0.f); }
+
+    Px ring[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) ring[k].rg = ring[k].ba = f32x2{ 0.0f, 0.0f };
+
+    auto row_live = [&](int ys) { return col_live && ys >= bp.sy0 && ys <= bp.sy1; };
+    Raw<INH> cur = fetch<INH>(sbase, srow, ys0, bp.source.fy0, row_live(ys0));
+    Raw<INH> nxt = fetch<INH>(sbase, srow, ys0 + 1, bp.source.fy0, steps > 1 && row_live(ys0 + 1));
+
+    for (int i0 = 0; i0 < steps; i0 += NT) {
+        // NT steps with the ring slot as a compile-time constant (a runtime index would send the ring to scratch)
+        auto step = [&](auto jc) -> bool {
+            constexpr int j = decltype(jc)::value;
+            const int i = i0 + j;
+            if (i >= steps) return false;                     // uniform over the workgroup
+            const int ys = ys0 + i;
+            // two rows ahead goes out now; this row's data was requested two steps ago
+            const Raw<INH> far = fetch<INH>(sbase, srow, ys + 2, bp.source.fy0, i + 2 < steps && row_live(ys + 2));
+            float4 *buf = rowbuf[i & 1];
+            buf[lane] = widen<INH>(cur);
+            cur = nxt;
+            nxt = far;
+            __syncthreads();
+            float4 v[NT];
+#pragma unroll
+            for (int k = 0; k < NT; k++) v[k] = buf[lane + k];
+            f32x2 rg = { 0.0f, 0.0f }, ba = { 0.0f, 0.0f };
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                rg = rg + f32x2{ v[k].x, v[k].y } * w[k];
+                ba = ba + f32x2{ v[k].z, v[k].w } * w[k];
+            }
+            ring[j].rg = rg;
+            ring[j].ba = ba;
+            if (i >= NT - 1) {
+                // ring[(j+1) % NT] is the oldest row = tap 0
+                f32x2 org = { 0.0f, 0.0f }, oba = { 0.0f, 0.0f };
+#pragma unroll
+                for (int k = 0; k < NT; k++) {
+                    const Px &p = ring[(j + 1 + k) % NT];
+                    org = org + p.rg * w[k];
+                    oba = oba + p.ba * w[k];
+                }
+                if (out_live) {
+                    const int t = ys + C - (NT - 1);
+                    char *o = tbase + (size_t)(t - bp.target.fy0) * trow;
+                    if (bp.out_half) *reinterpret_cast<uint2 *>(o) = make_uint2(cvs::f2h_rz2(org.x, org.y), cvs::f2h_rz2(oba.x, oba.y));
+                    else *reinterpret_cast<float4 *>(o) = make_float4(org.x, org.y, oba.x, oba.y);
+                }
+            }
+            return true;
+        };
+        each_slot(step, std::make_integer_sequence<int, NT>{});
+    }
+}
+
+template <int NT, int W>
+int launch(const cvk_blur_params *bp, hipStream_t s) {
+    constexpr int OUTW = W - (NT - 1);
+    const int cols = bp->tx1 - bp->tx0 + 1, rows = bp->ty1 - bp->ty0 + 1;
+    dim3 grid((unsigned)((cols + OUTW - 1) / OUTW), (unsigned)((rows + bp->rows_per_wg - 1) / bp->rows_per_wg));
+    if (bp->in_half) hipLaunchKernelGGL((k_blur<NT, W, true>), grid, dim3(W), 0, s, *bp);
+    else             hipLaunchKernelGGL((k_blur<NT, W, false>), grid, dim3(W), 0, s, *bp);
+    return (int)hipGetLastError();
+}
+
+template <int W>
+int pick(const cvk_blur_params *bp, hipStream_t s) {
+    switch (bp->ntaps) {
+    case 3:  return launch<3, W>(bp, s);
+    case 5:  return launch<5, W>(bp, s);
+    case 7:  return launch<7, W>(bp, s);
+    case 9:  return launch<9, W>(bp, s);
+    case 11: return launch<11, W>(bp, s);
+    case 13: return launch<13, W>(bp, s);
+    case 15: return launch<15, W>(bp, s);
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+extern "C" int cvk_blur_supported(int ntaps) { return ntaps >= 3 && ntaps <= 15 && (ntaps & 1); }
+
+extern "C" int cvk_blur(const cvk_blur_params *bp_in, int cus, void *stream) {
+    if (bp_in->tx1 < bp_in->tx0 || bp_in->ty1 < bp_in->ty0) return 0;
+    if (!cvk_blur_supported(bp_in->ntaps)) return (int)hipErrorInvalidValue;
+    cvk_blur_params bp = *bp_in;
+    const int cols = bp.tx1 - bp.tx0 + 1, rows = bp.ty1 - bp.ty0 + 1;
+    // strip width: 256 lanes unless the frame is so narrow that 128 wastes fewer lanes
+    static int env_w = -1, env_rows = -1;
+    if (env_w < 0) { const char *e = getenv("CVS_BLUR_WIDTH"); env_w = e ? atoi(e) : 0; }
+    if (env_rows < 0) { const char *e = getenv("CVS_BLUR_ROWS"); env_rows = e ? atoi(e) : 0; }
+    int width = env_w ? env_w : (cols <= 128 ? 128 : 256);
+    if (bp.rows_per_wg <= 0) {
+        // aim at ~4 workgroups per CU; never fewer than 2*(ntaps-1) rows (halo cost <= 50 %) nor more than the frame
+        const int outw = width - (bp.ntaps - 1);
+        const int strips = (cols + outw - 1) / outw;
+        int segs = (4 * cus + strips - 1) / strips;
+        if (segs < 1) segs = 1;
+        int r = (rows + segs - 1) / segs;
+        const int lo = 2 * (bp.ntaps - 1);
+        if (r < lo) r = lo;
+        if (r > rows) r = rows;
+        bp.rows_per_wg = env_rows ? env_rows : r;
+    }
+    return width == 128 ? pick<128>(&bp, (hipStream_t)stream) : pick<256>(&bp, (hipStream_t)stream);
+}

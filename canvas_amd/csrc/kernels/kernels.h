@@ -107,6 +107,20 @@ typedef struct {
 size_t cvk_fir2d_lds_bytes(const cvk_fir2d_params *fp);     /* dynamic LDS the launch would need */
 int cvk_fir2d(const cvk_fir2d_params *fp, void *stream);
 
+/* separable blur with one tap list (odd, 3..15 taps, all finite): both passes in one sweep, the vertical
+ * window in registers.  Source pixels outside (sx0..sx1, sy0..sy1) count as skipped taps. */
+typedef struct {
+    cvk_view target, source;
+    int in_half, out_half;     /* 0: rgba_f32 pixels, 1: rgba_f16 pixels */
+    int tx0, ty0, tx1, ty1;    /* target rectangle */
+    int sx0, sy0, sx1, sy1;    /* the source's current window */
+    int ntaps;
+    int rows_per_wg;           /* 0: let the launcher choose */
+    float taps[16];
+} cvk_blur_params;
+int cvk_blur_supported(int ntaps);
+int cvk_blur(const cvk_blur_params *bp, int cus, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
