@@ -31,6 +31,7 @@ class chain_job(C.Structure):
 
 
 P = C.POINTER
+rgba_frame_f16_t = rgba_frame_f16
 _u16p, _f32p, _vp = P(C.c_uint16), P(C.c_float), C.c_void_p
 _F16, _F32 = P(rgba_frame_f16), P(rgba_frame_f32)
 
@@ -126,6 +127,7 @@ SIGNATURES = {
     "cvs_scale_bilinear_f32_dev": (C.c_int, [_F32, v2f, _F32, v2f, v2f, _vp]),
     "cvs_fir_blur_f32_dev": (C.c_int, [_F32, _F32, _f32p, C.c_int, _vp]),
     "cvs_fir_blur_f16_dev": (C.c_int, [_F16, _F16, _f32p, C.c_int, _vp]),
+    "cvs_blur_over_f16_dev": (C.c_int, [_F16, _F16, _f32p, C.c_int, P(_F16), C.c_int, _vp]),
     "cvs_resample_lanczos_f32_dev": (C.c_int, [_F32, _F32, C.c_float, C.c_float, C.c_int, _vp]),
     "cvs_blur_lanczos_f16_dev": (C.c_int, [_F16, _F16, _f32p, C.c_int, C.c_float, C.c_float, C.c_int, _vp]),
     # (3) fused chain

@@ -455,14 +455,21 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
     return 0;
 }
 
-static int blur_fused(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
-                      const box2i *win, const float *taps, int ntaps, hipStream_t s) {
-    /* one tap list for every line: the register-window kernel, when it has an instance for this length */
+static bool blur_has_fast_kernel(const float *taps, int ntaps) {
     bool finite = true;
     for (int k = 0; k < ntaps; k++) finite = finite && isfinite(taps[k]);
-    if (finite && cvk_blur_supported(ntaps) && !getenv("CVS_BLUR_GENERIC")) {
+    return finite && cvk_blur_supported(ntaps) && !getenv("CVS_BLUR_GENERIC");
+}
+
+/* `over`: nover f16 buffers with the target's layout, blended over the blur result before the store (f16 in/out only) */
+static int blur_fused_over(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
+                           const box2i *win, const float *taps, int ntaps, const void *const *over, int nover, hipStream_t s) {
+    /* one tap list for every line: the register-window kernel, when it has an instance for this length */
+    if (blur_has_fast_kernel(taps, ntaps)) {
         cvk_blur_params bp;
         memset(&bp, 0, sizeof bp);
+        bp.nover = nover;
+        for (int l = 0; l < nover; l++) bp.over[l] = over[l];
         bp.target = cvs_view(tdata, tfull);
         bp.source = cvs_view((void *)sdata, sfull);
         bp.in_half = in_half; bp.out_half = out_half;
@@ -474,12 +481,18 @@ static int blur_fused(void *tdata, const box2i *tfull, int out_half, const void 
         if (rc != 0) { cvs_set_error("blur launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
         return 0;
     }
+    if (nover > 0) return 1;        /* the gather kernel has no epilogue: the caller goes node by node */
     const uint64_t th = fnv1a(taps, sizeof(float) * (size_t)ntaps);
     axis_key kh = make_key(1, 0, ntaps, th, win->min.x, win->max.x, sw->min.x, sw->max.x, CVK_FIR2D_TILE_X);
     axis_key kv = make_key(1, 0, ntaps, th, win->min.y, win->max.y, sw->min.y, sw->max.y, CVK_FIR2D_TILE_Y);
     cvk_fir_axis h, v; int hf, vf;
     if (axis_get(&kh, taps, 0.0f, &h, &hf) != 0 || axis_get(&kv, taps, 0.0f, &v, &vf) != 0) return -1;
     return fir2d_launch(tdata, tfull, out_half, sdata, sfull, in_half, win, &h, hf, &v, vf, s);
+}
+
+static int blur_fused(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
+                      const box2i *win, const float *taps, int ntaps, hipStream_t s) {
+    return blur_fused_over(tdata, tfull, out_half, sdata, sfull, sw, in_half, win, taps, ntaps, NULL, 0, s);
 }
 
 static int lanczos_fused(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
@@ -528,6 +541,57 @@ CVS_EXPORT int cvs_fir_blur_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16
         cvs_pool_free(wide.data, s); cvs_pool_free(out.data, s);
     }
     if (rc != 0) box2i_set_empty(&target->current_window);
+    return rc;
+}
+
+/* A workspace whose lowest item is a blur node on an f16 source and whose higher items are f16 frames, pulled as
+ * f16: workspace.c:530-544 fetches the base as f32 (the blur's own format, no rounding), blends every higher
+ * item over it with video_mix_over_f32 at mix 1.0, and main.c:43-71 truncates the result.  One launch when every
+ * window is the whole output frame; otherwise the same nodes one by one on f32 frames. */
+CVS_EXPORT int cvs_blur_over_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *source, const float *taps, int ntaps,
+                                     const rgba_frame_f16 *const *overlays, int noverlays, cvs_stream_t stream) {
+    if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
+    if (ntaps < 1 || !taps || noverlays < 0 || (noverlays > 0 && !overlays)) { cvs_set_error("blur+over: bad arguments"); box2i_set_empty(&out->current_window); return -1; }
+    hipStream_t s = cvs_pick_stream(stream);
+    const box2i *full = &out->full_window;
+    if (box2i_is_empty(full)) { box2i_set_empty(&out->current_window); return 0; }
+    box2i win;
+    box2i_intersect(&win, &source->current_window, full);
+    bool whole = noverlays <= CVK_BLUR_MAX_OVER && memcmp(&win, full, sizeof win) == 0;
+    const void *bufs[CVK_BLUR_MAX_OVER];
+    for (int l = 0; whole && l < noverlays; l++) {
+        whole = memcmp(&overlays[l]->full_window, full, sizeof *full) == 0 && memcmp(&overlays[l]->current_window, full, sizeof *full) == 0;
+        bufs[l] = overlays[l]->data;
+    }
+    int rc = 1;
+    if (whole && noverlays > 0)
+        rc = blur_fused_over(out->data, full, 1, source->data, &source->full_window, &source->current_window, 1, &win, taps, ntaps, bufs, noverlays, s);
+    if (rc == 0) { out->current_window = *full; return 0; }
+    if (rc < 0) { box2i_set_empty(&out->current_window); return rc; }
+
+    rgba_frame_f32 acc = { cvs_pool_malloc(cvs_box_pixels(full) * sizeof(rgba_f32), s), *full, *full };
+    rgba_frame_f32 tmp = { noverlays > 0 ? cvs_pool_malloc(cvs_box_pixels(full) * sizeof(rgba_f32), s) : NULL, *full, *full };
+    rc = (acc.data && (tmp.data || noverlays == 0)) ? 0 : -1;
+    if (rc == 0) {
+        box2i_set_empty(&acc.current_window);
+        if (!box2i_is_empty(&win)) {
+            acc.current_window = win;
+            rc = blur_fused(acc.data, full, 0, source->data, &source->full_window, &source->current_window, 1, &win, taps, ntaps, s);
+            if (rc == 1) {
+                rgba_frame_f32 wide = { cvs_pool_malloc(cvs_box_pixels(&source->full_window) * sizeof(rgba_f32), s), source->full_window, source->full_window };
+                rc = wide.data ? cvs_frame_f16_to_f32_dev(&wide, source, s) : -1;
+                if (rc == 0) rc = blur_two_pass(&acc, &wide, taps, ntaps, s);
+                cvs_pool_free(wide.data, s);
+            }
+        }
+    }
+    for (int l = 0; rc == 0 && l < noverlays; l++) {
+        rc = cvs_frame_f16_to_f32_dev(&tmp, overlays[l], s);
+        if (rc == 0) rc = cvs_mix_over_f32_dev(&acc, &tmp, 1.0f, s);
+    }
+    if (rc == 0) rc = cvs_frame_f32_to_f16_dev(out, &acc, s);
+    cvs_pool_free(acc.data, s); cvs_pool_free(tmp.data, s);
+    if (rc != 0) box2i_set_empty(&out->current_window);
     return rc;
 }
 

@@ -55,7 +55,10 @@ __device__ __forceinline__ void each_slot(F &f, std::integer_sequence<int, Js...
     (void)(f(std::integral_constant<int, Js>{}) && ...);
 }
 
-template <int NT, int W, bool INH>
+// EPI: the blurred pixel is the bottom layer of a workspace stack -- bp.nover f16 frames (same geometry as the
+// target) are blended over it with video_mix.c:323-337 at mix 1.0 before the truncating store, so the f32 blur
+// result never leaves the registers (a workspace pulls its items as f32: no rounding between blur and over).
+template <int NT, int W, bool INH, bool EPI>
 __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
     constexpr int C = NT / 2, OUTW = W - (NT - 1), PITCH = W + 16;
     __shared__ float4 rowbuf[2][PITCH];
@@ -100,6 +103,17 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
             const int ys = ys0 + i;
             // two rows ahead goes out now; this row's data was requested two steps ago
             const Raw<INH> far = fetch<INH>(sbase, srow, ys + 2, bp.source.fy0, i + 2 < steps && row_live(ys + 2));
+            // the upper layers of this step's output pixel: requested before the barrier, used after the sums
+            uint2 ov[CVK_BLUR_MAX_OVER];
+            if constexpr (EPI) {
+                const int t = ys + C - (NT - 1);
+                const size_t o = (size_t)(t - bp.target.fy0) * (size_t)bp.target.pitch + (size_t)(tcol - bp.target.fx0);
+#pragma unroll
+                for (int l = 0; l < CVK_BLUR_MAX_OVER; l++) {
+                    ov[l] = make_uint2(0u, 0u);
+                    if (l < bp.nover && i >= NT - 1 && out_live) ov[l] = reinterpret_cast<const uint2 *>(bp.over[l])[o];
+                }
+            }
             float4 *buf = rowbuf[i & 1];
             buf[lane] = widen<INH>(cur);
             cur = nxt;
@@ -125,6 +139,17 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
                     org = org + p.rg * w[k];
                     oba = oba + p.ba * w[k];
                 }
+                if constexpr (EPI) {
+                    cvs::px32 acc = { org.x, org.y, oba.x, oba.y };
+#pragma unroll
+                    for (int l = 0; l < CVK_BLUR_MAX_OVER; l++)
+                        if (l < bp.nover) {
+                            const cvs::px32 b = { cvs::h2f(ov[l].x & 0xFFFFu), cvs::h2f(ov[l].x >> 16), cvs::h2f(ov[l].y & 0xFFFFu), cvs::h2f(ov[l].y >> 16) };
+                            acc = cvs::blend_over(acc, b, 1.0f);
+                        }
+                    org = f32x2{ acc.r, acc.g };
+                    oba = f32x2{ acc.b, acc.a };
+                }
                 if (out_live) {
                     const int t = ys + C - (NT - 1);
                     char *o = tbase + (size_t)(t - bp.target.fy0) * trow;
@@ -143,8 +168,9 @@ int launch(const cvk_blur_params *bp, hipStream_t s) {
     constexpr int OUTW = W - (NT - 1);
     const int cols = bp->tx1 - bp->tx0 + 1, rows = bp->ty1 - bp->ty0 + 1;
     dim3 grid((unsigned)((cols + OUTW - 1) / OUTW), (unsigned)((rows + bp->rows_per_wg - 1) / bp->rows_per_wg));
-    if (bp->in_half) hipLaunchKernelGGL((k_blur<NT, W, true>), grid, dim3(W), 0, s, *bp);
-    else             hipLaunchKernelGGL((k_blur<NT, W, false>), grid, dim3(W), 0, s, *bp);
+    if (bp->nover > 0)    hipLaunchKernelGGL((k_blur<NT, W, true, true>), grid, dim3(W), 0, s, *bp);      // f16 in, f16 out
+    else if (bp->in_half) hipLaunchKernelGGL((k_blur<NT, W, true, false>), grid, dim3(W), 0, s, *bp);
+    else                  hipLaunchKernelGGL((k_blur<NT, W, false, false>), grid, dim3(W), 0, s, *bp);
     return (int)hipGetLastError();
 }
 
@@ -169,6 +195,7 @@ extern "C" int cvk_blur_supported(int ntaps) { return ntaps >= 3 && ntaps <= 15 
 extern "C" int cvk_blur(const cvk_blur_params *bp_in, int cus, void *stream) {
     if (bp_in->tx1 < bp_in->tx0 || bp_in->ty1 < bp_in->ty0) return 0;
     if (!cvk_blur_supported(bp_in->ntaps)) return (int)hipErrorInvalidValue;
+    if (bp_in->nover < 0 || bp_in->nover > CVK_BLUR_MAX_OVER || (bp_in->nover > 0 && !(bp_in->in_half && bp_in->out_half))) return (int)hipErrorInvalidValue;
     cvk_blur_params bp = *bp_in;
     const int cols = bp.tx1 - bp.tx0 + 1, rows = bp.ty1 - bp.ty0 + 1;
     // strip width: 256 lanes unless the frame is so narrow that 128 wastes fewer lanes

@@ -109,6 +109,7 @@ int cvk_fir2d(const cvk_fir2d_params *fp, void *stream);
 
 /* separable blur with one tap list (odd, 3..15 taps, all finite): both passes in one sweep, the vertical
  * window in registers.  Source pixels outside (sx0..sx1, sy0..sy1) count as skipped taps. */
+#define CVK_BLUR_MAX_OVER 4
 typedef struct {
     cvk_view target, source;
     int in_half, out_half;     /* 0: rgba_f32 pixels, 1: rgba_f16 pixels */
@@ -117,6 +118,9 @@ typedef struct {
     int ntaps;
     int rows_per_wg;           /* 0: let the launcher choose */
     float taps[16];
+    int nover;                 /* f16 frames blended over the blur result before the (f16) store; 0..CVK_BLUR_MAX_OVER */
+    int pad;
+    const void *over[CVK_BLUR_MAX_OVER];       /* rgba_f16 device buffers laid out exactly like `target` */
 } cvk_blur_params;
 int cvk_blur_supported(int ntaps);
 int cvk_blur(const cvk_blur_params *bp, int cus, void *stream);

@@ -1,16 +1,19 @@
 """BASELINE config 5: a 10-node graph over a synthetic frame stream, on device frames.
 
-    stream input S ─ colour(Rec.709 LUT + RGB→Y'PbPr) ─ blur(9-tap separable Gaussian) ─┐
-    overlay sources O1..O4 ─────────────────────────────────────────────────────────────┴ over ×4 → output
+    S0 ─ colour(Rec.709 LUT + RGB→Y'PbPr) ─ blur(9-tap separable Gaussian) ─┐
+    S1, S2, S3 ─────────────────────────────────────────────────────────────┴ workspace stack → output
 
-Ten nodes = colour + blur + four overlay sources + four alpha-over steps (the stream input is what
-feeds the graph).  In the reference this is a colour filter on an f16 source (color.c structure), a blur
-node pulled through video_get_frame_f16 (main.c:43-71 widen/truncate), and a workspace whose five items
-are stacked with video_mix_over_f32(mix 1.0) (workspace.c:530-544).  Here it is three launches per frame:
+Ten nodes = four sources + colour(S0) + blur(colour) + four composite steps (the base fetch and three
+overs, as workspace.c:530-544 counts them).  In the reference this is a colour filter on an f16 source
+(color.c structure), a blur node that pulls it as f32 (main.c:105-144 widening) and is itself the lowest
+workspace item (fetched as f32, no rounding), three f16 sources blended over it with
+video_mix_over_f32(mix 1.0), and a consumer that pulls f16 (main.c:43-71 truncation).
+
+Node-by-node compulsory traffic: colour 8+8, blur 8+8, composite 4x8+8 = 72 B per output pixel.
+Here it is two launches per frame:
 
     cvs_color_matrix_f16_to_dev   8 B read + 8 B written per pixel
-    cvs_fir_blur_f16_dev          8 B read + 8 B written
-    cvs_chain_color_over (m=NULL) 5 x 8 B read + 8 B written          => 80 B per output pixel
+    cvs_blur_over_f16_dev         8 B (graded) + 3 x 8 B (upper layers) read + 8 B written   => 56 B per pixel
 
 Frames are independent, so frame g belongs to rank g % world (shard.frames_of_rank); nothing is
 exchanged on the data path.
@@ -20,11 +23,12 @@ import ctypes as C
 import numpy as np
 
 from . import _lib, synth
-from .device import DeviceFrame, chain_color_over
+from .device import DeviceFrame
 from .shard import frames_of_rank
 
-BYTES_PER_PIXEL = 16 + 16 + 48
-OVERLAYS = 4
+NODE_BYTES_PER_PIXEL = 16 + 16 + 40      # per-node compulsory traffic (the survey's denominator)
+BYTES_PER_PIXEL = 16 + 40                 # what the two launches move
+OVERLAYS = 3
 
 
 class GraphStream:
@@ -48,8 +52,9 @@ class GraphStream:
                 o = DeviceFrame(self.full, np.uint16)
                 o.upload(synth.layer_pixels(width, height, k, first_frame + slot))
                 over.append(o)
-            self.slots.append({"src": src, "over": over, "graded": DeviceFrame(self.full, np.uint16),
-                               "blurred": DeviceFrame(self.full, np.uint16), "out": DeviceFrame(self.full, np.uint16)})
+            refs = (C.POINTER(_lib.rgba_frame_f16_t) * overlays)(*[C.pointer(o.c) for o in over])
+            self.slots.append({"src": src, "over": over, "over_refs": refs, "graded": DeviceFrame(self.full, np.uint16),
+                               "out": DeviceFrame(self.full, np.uint16)})
         self._m = self.matrix.ctypes.data_as(C.POINTER(C.c_float))
         self._t = self.taps.ctypes.data_as(C.POINTER(C.c_float))
 
@@ -59,11 +64,11 @@ class GraphStream:
         return [synth.layer_frame(width, height, k, frame) for k in range(overlays + 1)]
 
     def render(self, slot, stream=None):
-        """Enqueue the three launches of one frame on `stream`; returns the output DeviceFrame."""
+        """Enqueue the two launches of one frame on `stream`; returns the output DeviceFrame."""
         s, lib = self.slots[slot % self.ring], self.lib
         _lib.check(lib.cvs_color_matrix_f16_to_dev(s["graded"].ref(), s["src"].ref(), self._m, self.pre_lut, self.post_lut, stream), "colour")
-        _lib.check(lib.cvs_fir_blur_f16_dev(s["blurred"].ref(), s["graded"].ref(), self._t, len(self.taps), stream), "blur")
-        chain_color_over([(s["out"], [s["blurred"]] + s["over"])], None, stream=stream)
+        _lib.check(lib.cvs_blur_over_f16_dev(s["out"].ref(), s["graded"].ref(), self._t, len(self.taps), s["over_refs"],
+                                             self.overlays, stream), "blur+over")
         return s["out"]
 
     def run(self, frames, rank=0, world=1, stream=None):

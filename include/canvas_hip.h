@@ -281,6 +281,10 @@ CVS_EXPORT int cvs_scale_bilinear_f32_dev(rgba_frame_f32 *target, v2f target_poi
 CVS_EXPORT int cvs_fir_blur_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, const float *taps_host, int ntaps, cvs_stream_t s);
 /* blur node between two f16 frames (widen on load, f32 passes, truncate on store), one launch */
 CVS_EXPORT int cvs_fir_blur_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, const float *taps, int ntaps, cvs_stream_t stream);
+/* f16 pull of a workspace whose lowest item is a blur node on `source` and whose higher items are `overlays`
+ * (bottom first); the blur result stays f32 until the final truncation, as workspace.c:530-544 would have it */
+CVS_EXPORT int cvs_blur_over_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *source, const float *taps, int ntaps,
+                                     const rgba_frame_f16 *const *overlays, int noverlays, cvs_stream_t stream);
 CVS_EXPORT int cvs_resample_lanczos_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, float factor_x, float factor_y, int kernel_size, cvs_stream_t s);
 /* BASELINE config 3 on f16 frames: widen -> blur -> Lanczos resample -> truncate, f32 in between, two launches */
 CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, const float *taps_host, int ntaps,

@@ -816,7 +816,7 @@ def test_fir_blur_f16(cvs, orc, scur, ntaps):
 
 @pytest.mark.parametrize("size", [(96, 54), (131, 37)])
 def test_config5_graph_stream_against_oracle(cvs, orc, size):
-    """colour -> blur -> 4x over on three stream frames, every pixel, against the oracle's node-by-node run."""
+    """4 sources, colour -> blur -> 4-step composite on three stream frames, every pixel, against the oracle's node-by-node run."""
     from canvas_amd.stream import GraphStream
     from tests.util import oracle_graph
     w, h = size
@@ -824,8 +824,55 @@ def test_config5_graph_stream_against_oracle(cvs, orc, size):
     for frame in range(3):
         out = g.render(frame)
         _lib.check(cvs.cvs_stream_sync(None))
-        assert cvs.cvs_chain_last_was_fused() == 1
         want = oracle_graph(orc, GraphStream.host_inputs(w, h, frame), g.matrix, orc.transfer_table(0), None, g.taps)
         got = out.download()
         assert same_window(got.current_window, want.current_window)
         assert_same_f16(got.array, want.array, "config 5 graph, frame %d" % frame)
+
+
+def _blur_over(cvs, out_full, src, taps, overlays):
+    d_src = DeviceFrame.from_host(src)
+    d_ov = [DeviceFrame.from_host(o) for o in overlays]
+    refs = (C.POINTER(_lib.rgba_frame_f16_t) * max(len(d_ov), 1))(*[C.pointer(o.c) for o in d_ov])
+    d_out = DeviceFrame(out_full, np.uint16)
+    _lib.check(cvs.cvs_blur_over_f16_dev(d_out.ref(), d_src.ref(), f32p(taps), len(taps), refs, len(d_ov), None))
+    return d_out.download()
+
+
+@pytest.mark.parametrize("nover", [1, 3, 4])
+@pytest.mark.parametrize("ntaps", [9, 3, 15])
+@pytest.mark.parametrize("size", [(300, 41), (64, 36)])         # two strips / one narrow strip
+def test_blur_over_fused(cvs, orc, nover, ntaps, size):
+    """Blur node as the lowest workspace item, f16 layers above it, f16 pull: one launch."""
+    from tests.util import oracle_blur_over
+    from canvas_amd.synth import truncate_to_half
+    w, h = size
+    full = (0, 0, w - 1, h - 1)
+    rng = np.random.default_rng(700 + nover + ntaps)
+    src = rand_f16_frame(rng, full, full)
+    overlays = [HostFrame(full, np.uint16, truncate_to_half(rand_f32_frame(rng, full, full, alpha="mixed", lo=-0.25, hi=1.5).array))
+                for _ in range(nover)]
+    overlays[0].array[2, 3] = [0x7BFF, 0xFBFF, 0x7BFF, 0x3800]
+    taps = synth.gaussian_taps(ntaps, 1.5)
+    want = oracle_blur_over(orc, src, taps, overlays)
+    got = _blur_over(cvs, full, src, taps, overlays)
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f16(got.array, want.array, "blur+over fused")
+
+
+@pytest.mark.parametrize("case", ["ragged", "even_taps", "five_layers", "no_layers", "small_source"])
+def test_blur_over_node_by_node(cvs, orc, case):
+    from tests.util import oracle_blur_over
+    full = (0, 0, 59, 33)
+    rng = np.random.default_rng(800)
+    src_cur = (4, 2, 50, 30) if case == "small_source" else full
+    src = rand_f16_frame(rng, full, src_cur)
+    nover = {"five_layers": 5, "no_layers": 0}.get(case, 2)
+    # windows: see test_chain_ragged_windows for why the upper layers sit where they do
+    wins = [(5, 3, 40, 25), (20, 2, 59, 20)] if case == "ragged" else [full] * nover
+    overlays = [rand_f16_frame(rng, full, wins[k]) for k in range(nover)]
+    taps = synth.gaussian_taps(4 if case == "even_taps" else 9, 1.5)
+    want = oracle_blur_over(orc, src, taps, overlays)
+    got = _blur_over(cvs, full, src, taps, overlays)
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f16(got.window_view(), want.window_view(), "blur+over %s" % case)

@@ -80,15 +80,23 @@ def u16p(a):
 
 
 def oracle_graph(orc, layers, matrix, pre_table, post_table, taps):
-    """BASELINE config 5 with the CPU oracle's nodes: colour filter on an f16 copy, blur pulled as f16
-    (widen, f32 passes, truncate), then the five-item workspace stack."""
-    src = layers[0]
-    graded = src.copy()
+    """BASELINE config 5 with the CPU oracle's nodes: colour filter on an f16 copy of layer 0, blur node pulling it
+    as f32, workspace stack (base fetched as f32, every further layer widened and blended over at mix 1.0),
+    f16 pull of the result."""
+    graded = layers[0].copy()
     m = np.ascontiguousarray(matrix, np.float32).reshape(9)
     taps = np.ascontiguousarray(taps, np.float32)
-    orc.lib().orc_color_matrix_f16(graded.ref(), f32p(m), None if pre_table is None else u16p(pre_table), None if post_table is None else u16p(post_table))
-    wide = HostFrame(graded.full_window, np.float32, orc.half_to_float(graded.array), graded.current_window)
-    blurred32 = HostFrame(graded.full_window, np.float32)
-    orc.lib().orc_fir_blur_f32(blurred32.ref(), wide.ref(), f32p(taps), len(taps))
-    blurred = HostFrame(graded.full_window, np.uint16, orc.float_to_half(blurred32.array), blurred32.current_window)
-    return orc.chain_color_over([blurred] + list(layers[1:]), None)
+    orc.lib().orc_color_matrix_f16(graded.ref(), f32p(m), None if pre_table is None else u16p(pre_table),
+                                   None if post_table is None else u16p(post_table))
+    return oracle_blur_over(orc, graded, taps, layers[1:])
+
+
+def oracle_blur_over(orc, source, taps, overlays, out_full=None):
+    full = out_full or source.full_window
+    wide = HostFrame(source.full_window, np.float32, orc.half_to_float(source.array), source.current_window)
+    acc = HostFrame(full, np.float32)
+    orc.lib().orc_fir_blur_f32(acc.ref(), wide.ref(), f32p(taps), len(taps))
+    for ov in overlays:
+        ov32 = HostFrame(ov.full_window, np.float32, orc.half_to_float(ov.array), ov.current_window)
+        orc.lib().orc_mix_over_f32(acc.ref(), ov32.ref(), C.c_float(1.0))
+    return HostFrame(full, np.uint16, orc.float_to_half(acc.array), acc.current_window)
