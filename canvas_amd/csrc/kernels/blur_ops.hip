@@ -207,7 +207,9 @@ extern "C" int cvk_blur(const cvk_blur_params *bp_in, int cus, void *stream) {
         // aim at ~4 workgroups per CU; never fewer than 2*(ntaps-1) rows (halo cost <= 50 %) nor more than the frame
         const int outw = width - (bp.ntaps - 1);
         const int strips = (cols + outw - 1) / outw;
-        int segs = (4 * cus + strips - 1) / strips;
+        static int per_cu = -1;
+        if (per_cu < 0) { const char *e = getenv("CVS_BLUR_WGS_PER_CU"); per_cu = e ? atoi(e) : 4; }
+        int segs = (per_cu * cus + strips - 1) / strips;
         if (segs < 1) segs = 1;
         int r = (rows + segs - 1) / segs;
         const int lo = 2 * (bp.ntaps - 1);
