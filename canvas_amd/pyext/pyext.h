@@ -35,6 +35,7 @@ PyObject *py_get_frame_f32(PyObject *self, PyObject *args, PyObject *kw);
 
 int init_frames(PyObject *module);
 int init_framefuncs(PyObject *module);
+int init_animation(PyObject *module);
 int init_sources(PyObject *module);
 int init_workspace(PyObject *module);
 

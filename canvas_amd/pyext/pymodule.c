@@ -338,7 +338,7 @@ PyMODINIT_FUNC PyInit_process(void) {
     if (!m) return NULL;
     if (import_basetypes() != 0) { Py_DECREF(m); return NULL; }
     init_half();
-    if (pyext_add_type(m, "VideoSource", &py_type_VideoSource) < 0 || init_framefuncs(m) < 0 || init_frames(m) < 0 ||
+    if (pyext_add_type(m, "VideoSource", &py_type_VideoSource) < 0 || init_framefuncs(m) < 0 || init_animation(m) < 0 || init_frames(m) < 0 ||
         init_sources(m) < 0 || init_workspace(m) < 0) {
         Py_DECREF(m);
         return NULL;

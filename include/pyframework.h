@@ -59,6 +59,7 @@ CVS_EXPORT void framefunc_get_box2i(box2i *result, FrameFunctionHolder *holder, 
 CVS_EXPORT void framefunc_get_rgba_f32(rgba_f32 *result, FrameFunctionHolder *holder, double frame);
 CVS_EXPORT void framefunc_init(FrameFunctionHolder *holder, double c0, double c1, double c2, double c3);
 CVS_EXPORT extern PyTypeObject py_type_FrameFunction;
+CVS_EXPORT extern PyTypeObject py_type_AnimationFunc;      /* src/process/AnimationFunc.c:349 */
 
 #if defined(__cplusplus)
 }

@@ -25,6 +25,7 @@ def test_surface_is_complete(process):
     for name in ["VideoSource", "RgbaFrameF16", "RgbaFrameF32", "SolidColorVideoSource", "EmptyVideoSource",
                  "VideoGainOffsetFilter", "VideoMixFilter", "VideoScaler", "VideoPassThroughFilter", "VideoSequence",
                  "VideoWorkspace", "VideoPullQueue", "FrameFunction", "LerpFunc", "LinearFrameFunc",
+                 "AnimationFunc", "AnimationPoint", "POINT_HOLD", "POINT_LINEAR",
                  "get_frame_time", "get_time_frame", "time_get_frame", "enable_glib_logging",
                  "create_offscreen_gl_context", "set_current_gl_context", "check_context_supported"]:
         assert hasattr(process, name), name
@@ -135,6 +136,67 @@ def test_passthrough_is_subclassable_and_has_properties(process):
     assert (g.gain, g.offset) == (1.0, 0.0) and g.source is red
     g.gain = process.LinearFrameFunc(1, 0)
     assert isinstance(g.gain, process.LinearFrameFunc)
+
+
+def test_animation_func_key_points(process):
+    """The curve of tests/process/frame_func.py:33-66 (hold 4 @0, linear 2 @1, linear 6 @2), asked in order and
+    out of order -- lookups keep no cursor here, so order cannot matter -- plus the edge rules of
+    AnimationFunc.c:408-463."""
+    f = process.AnimationFunc()
+    assert len(f) == 0 and f.get_values(7.0)[0] == (0.0, 0.0, 0.0, 0.0)
+    f.add(process.AnimationPoint(process.POINT_HOLD, 0.0, 4.0))
+    f.add(process.AnimationPoint(process.POINT_LINEAR, 1.0, 2.0))
+    f.add(process.AnimationPoint(process.POINT_LINEAR, 2.0, 6.0))
+    want = {-0.5: 4.0, 0.0: 4.0, 0.25: 4.0, 0.5: 4.0, 0.75: 4.0, 1.0: 2.0, 1.25: 3.0, 1.5: 4.0, 1.75: 5.0, 2.0: 6.0, 2.5: 6.0}
+    for frame in list(want) + [-0.5, 0.75, 1.25, 2.5, 0.0, 2.0, 0.25, 1.75, 0.5, 1.0, 1.5]:
+        assert f.get_values(frame)[0][0] == pytest.approx(want[frame])
+    assert [v[0] for v in f.get_values([2.5, 1.25, -0.5])] == pytest.approx([6.0, 3.0, 4.0])
+    # four slots, tuples shorter than four are zero-filled
+    g = process.AnimationFunc()
+    g.add(process.POINT_LINEAR, 10, (1.0, 2.0))
+    g.add(process.POINT_LINEAR, 20, (5.0, 0.0, 0.0, 8.0))
+    assert g.get_values(15)[0] == pytest.approx((3.0, 1.0, 0.0, 4.0))
+    with pytest.raises(ValueError):
+        g.add(process.POINT_HOLD, 1, ())
+    with pytest.raises(ValueError):
+        g.add(process.POINT_HOLD, 1, (1, 2, 3, 4, 5))
+    with pytest.raises(Exception):
+        process.AnimationPoint(7, 0.0, 1.0)
+
+
+def test_animation_points_move_and_leave(process):
+    """tests/process/frame_func.py:68-83: points stay sorted when a frame is reassigned."""
+    f = process.AnimationFunc()
+    p1 = f.add(process.POINT_HOLD, 0.0, 4.0)
+    p2 = f.add(process.POINT_LINEAR, 2.0, 6.0)
+    p3 = f.add(process.POINT_LINEAR, 1.0, 2.0)
+    assert (f[0], f[1], f[2]) == (p1, p3, p2)
+    p3.frame = 3.0
+    assert (f[0], f[1], f[2]) == (p1, p2, p3) and p3.frame == 3.0 and p3.type == process.POINT_LINEAR
+    assert p3.value == (2.0, 0.0, 0.0, 0.0)
+    with pytest.raises(Exception):
+        process.AnimationFunc().add(p3)            # already owned
+    f.remove(p2)
+    assert len(f) == 2 and f.get_values(2.0)[0][0] == 4.0          # p1 holds until p3
+    f.remove(p2)                                   # not ours any more: ignored
+    other = process.AnimationFunc()
+    assert other.add(p2) is p2 and other[0] is p2
+    with pytest.raises(IndexError):
+        f[2]
+
+
+def test_animation_func_drives_filter_parameters(process):
+    """The editor's crossfade curve (fluggo/editor/graph/video.py:154-159) plugs into VideoMixFilter / gain."""
+    mix = process.AnimationFunc()
+    mix.add(process.POINT_HOLD, -1.0, 0.0)
+    fade = mix.add(process.POINT_LINEAR, 0.0, 0.0)
+    out = mix.add(process.POINT_HOLD, 0.0, 1.0)
+    fade.frame, out.frame = 10.0, 20.0
+    assert [v[0] for v in mix.get_values([0, 10, 15, 20, 30])] == pytest.approx([0.0, 0.0, 0.5, 1.0, 1.0])
+    a, b = process.SolidColorVideoSource((1, 0, 0, 1)), process.SolidColorVideoSource((0, 1, 0, 1))
+    process.VideoMixFilter(a, b, mix)
+    process.VideoGainOffsetFilter(a, gain=mix, offset=0.0)
+    assert hasattr(mix, "_frame_function_funcs")
 
 
 def test_without_a_gpu_pulls_are_empty_and_loud(process):

@@ -121,6 +121,33 @@ def test_sequence_cut_cut_crossfade(process, bt):
     assert getcolor(seq, -1, bt) is None
 
 
+def test_sequence_crossfade_driven_by_animation_points(process, bt):
+    """The same cut/cut/crossfade, with mix_b built the way the editor builds it
+    (fluggo/editor/graph/video.py:154-159: hold 0 until the fade point, linear to the out point, hold 1)."""
+    red, green, blue = ramp(process, 0), ramp(process, 1), ramp(process, 2)
+    mix_b = process.AnimationFunc()
+    mix_b.add(process.POINT_HOLD, -1.0, 0.0)
+    fade_point = mix_b.add(process.POINT_LINEAR, 0.0, 0.0)
+    out_point = mix_b.add(process.POINT_HOLD, 0.0, 1.0)
+    out_point.frame = 5.0
+    assert (mix_b[1], mix_b[2]) == (fade_point, out_point)
+    fade = process.VideoMixFilter(src_a=process.VideoPassThroughFilter(green, offset=6),
+                                  src_b=process.VideoPassThroughFilter(blue, offset=1), mix_b=mix_b)
+    seq = process.VideoSequence()
+    seq.append((red, 1, 10))
+    seq.append((green, 1, 5))
+    seq.append((fade, 0, 5))
+    seq.append((blue, 6, 5))
+    for i in range(15, 20):
+        m = (i - 15) / 5.0
+        almost(getcolor(seq, i, bt), (0.0, (i - 10 + 1.0) * (1.0 - m), (i - 15 + 1.0) * m, 1.0), 6)
+    # moving the fade point re-times the transition without touching the graph
+    fade_point.frame = 2.0
+    almost(getcolor(seq, 16, bt), (0.0, 7.0, 0.0, 1.0), 6)            # still holding source a
+    m = (4 - 2.0) / 3.0
+    almost(getcolor(seq, 19, bt), (0.0, 10.0 * (1.0 - m), 5.0 * m, 1.0), 5)
+
+
 # ---------------------------------------------------------------- VideoWorkspace.py
 
 def test_workspace_random_operations(process, bt):
