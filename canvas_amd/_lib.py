@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcanvas_hip.so")
 
 CHAIN_MAX_LAYERS = 8
+DISPLAY_RGBA8, DISPLAY_ARGB32_PREMUL = 0, 1
 LUT_NONE, LUT_REC709_TO_LINEAR_SCENE, LUT_REC709_TO_LINEAR_DISPLAY, LUT_LINEAR_TO_REC709, LUT_LINEAR_TO_SRGB = -1, 0, 1, 2, 3
 
 
@@ -126,6 +127,8 @@ SIGNATURES = {
     "cvs_fill_solid_f32_dev": (C.c_int, [_F32, P(box2i), P(rgba_f32), _vp]),
     "cvs_scale_bilinear_f32_dev": (C.c_int, [_F32, v2f, _F32, v2f, v2f, _vp]),
     "cvs_fir_blur_f32_dev": (C.c_int, [_F32, _F32, _f32p, C.c_int, _vp]),
+    "cvs_frame_to_bytes_dev": (C.c_int, [_vp, _F16, C.c_int, C.c_int, _vp]),
+    "video_frame_to_bytes": (C.c_int, [_vp, _F16, C.c_int, C.c_int]),
     "cvs_fir_blur_f16_dev": (C.c_int, [_F16, _F16, _f32p, C.c_int, _vp]),
     "cvs_blur_over_f16_dev": (C.c_int, [_F16, _F16, _f32p, C.c_int, P(_F16), C.c_int, _vp]),
     "cvs_resample_lanczos_f32_dev": (C.c_int, [_F32, _F32, C.c_float, C.c_float, C.c_int, _vp]),

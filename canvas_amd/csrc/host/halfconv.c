@@ -121,6 +121,7 @@ static float tf_linear_to_srgb(float in) {                            /* gammata
 static pthread_mutex_t lut_lock = PTHREAD_MUTEX_INITIALIZER;
 static half *lut_host[CVS_LUT_COUNT];
 static half *lut_dev[CVS_LUT_COUNT];
+static unsigned lut_gen[CVS_LUT_COUNT];
 static uint8_t *ramp45;
 static float *codes_as_float;       /* h2f of 0..65535, computed once on the GPU */
 
@@ -143,8 +144,11 @@ static int install_locked(int which, const half *table) {
     if (table != lut_host[which]) memcpy(lut_host[which], table, HALF_COUNT * sizeof(half));
     if (!lut_dev[which]) CVS_HIP(hipMalloc((void **)&lut_dev[which], HALF_COUNT * sizeof(half)));
     CVS_HIP(hipMemcpy(lut_dev[which], lut_host[which], HALF_COUNT * sizeof(half), hipMemcpyHostToDevice));
+    lut_gen[which]++;
     return 0;
 }
+
+unsigned cvs_lut_generation(int which) { return (which >= 0 && which < CVS_LUT_COUNT) ? __atomic_load_n(&lut_gen[which], __ATOMIC_ACQUIRE) : 0; }
 
 static int ensure_lut(int which) {
     if (which < 0 || which >= CVS_LUT_COUNT) { cvs_set_error("no such transfer table: %d", which); return -1; }

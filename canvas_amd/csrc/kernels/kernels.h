@@ -125,6 +125,11 @@ typedef struct {
 int cvk_blur_supported(int ntaps);
 int cvk_blur(const cvk_blur_params *bp, int cus, void *stream);
 
+/* display / export edge: f16 RGBA -> 4 bytes per pixel through a 65536-entry half->u8 table (device pointer,
+ * 16-byte aligned); dst is packed over the rectangle */
+enum { CVK_DISPLAY_RGBA8 = 0, CVK_DISPLAY_ARGB32_PREMUL = 1 };
+int cvk_display(void *dst, cvk_view src, cvk_rect r, const uint8_t *table, int mode, int cus, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

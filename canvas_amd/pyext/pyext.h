@@ -32,6 +32,8 @@ PyObject *py_RgbaFrameF16_new(box2i *full_window, rgba_frame_f16 **frame);
 PyObject *py_RgbaFrameF32_new(box2i *full_window, rgba_frame_f32 **frame);
 PyObject *py_get_frame_f16(PyObject *self, PyObject *args, PyObject *kw);
 PyObject *py_get_frame_f32(PyObject *self, PyObject *args, PyObject *kw);
+PyObject *py_get_frame_argb32(PyObject *self, PyObject *args, PyObject *kw);
+PyObject *py_get_frame_rgba8(PyObject *self, PyObject *args, PyObject *kw);
 
 int init_frames(PyObject *module);
 int init_framefuncs(PyObject *module);

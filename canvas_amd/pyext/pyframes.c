@@ -85,6 +85,55 @@ PyObject *py_get_frame_f32(PyObject *self, PyObject *args, PyObject *kw) {
     return result;
 }
 
+/* Preview / thumbnail pulls: render on the device, convert to bytes on the device (cvs_frame_to_bytes_dev), and
+ * bring back 4 bytes per pixel of the current window instead of the 8-byte halfs.  Returns
+ * (bytearray or None, current_window).  The two conversions are the reference's display edges:
+ * RgbaFrameF16.to_argb32_bytes (RgbaFrameF16.c:114-149) and the software widget's rgba_u8 (widget_gl.c:291-307). */
+static PyObject *pull_bytes(PyObject *self, PyObject *args, PyObject *kw, int mode, int pre_lut) {
+    int frame_index; box2i window;
+    if (!parse_pull_args(args, kw, &frame_index, &window)) return NULL;
+    video_source *source = NULL;
+    if (!py_video_take_source(self, &source)) return NULL;
+    PyObject *bytes = NULL, *result = NULL;
+    rgba_frame_dev d = { NULL, CVS_FORMAT_F16, window, window, NULL };
+    void *packed = NULL;
+    const size_t fbytes = frame_bytes(&window, CVS_FORMAT_F16);
+    int rc = -1;
+    if (!box2i_is_empty(&window)) {
+        Py_BEGIN_ALLOW_THREADS
+        d.data = cvs_pool_malloc(fbytes ? fbytes : 1, NULL);
+        if (d.data) { video_get_frame_dev(source, frame_index, &d); rc = 0; }
+        Py_END_ALLOW_THREADS
+    } else { box2i_set_empty(&d.current_window); rc = 0; }
+    if (rc == 0 && !box2i_is_empty(&d.current_window)) {
+        v2i size;
+        box2i_get_size(&d.current_window, &size);
+        const size_t out = (size_t)size.x * (size_t)size.y * 4;
+        bytes = PyByteArray_FromStringAndSize(NULL, (Py_ssize_t)out);
+        if (bytes) {
+            rgba_frame_f16 f = { d.data, d.full_window, d.current_window };
+            char *host = PyByteArray_AS_STRING(bytes);
+            Py_BEGIN_ALLOW_THREADS
+            packed = cvs_pool_malloc(out, NULL);
+            rc = packed ? cvs_frame_to_bytes_dev(packed, &f, pre_lut, mode, NULL) : -1;
+            if (rc == 0) rc = cvs_memcpy_d2h(host, packed, out, NULL);
+            Py_END_ALLOW_THREADS
+        } else rc = -2;
+    }
+    cvs_pool_free(packed, NULL);
+    cvs_pool_free(d.data, NULL);
+    py_video_take_source(NULL, &source);
+    if (rc == -2) return NULL;                       /* Python error already set */
+    if (rc != 0) { Py_XDECREF(bytes); PyErr_SetString(PyExc_RuntimeError, cvs_last_error()); return NULL; }
+    PyObject *win = py_make_box2i(&d.current_window);
+    if (win) result = Py_BuildValue("(ON)", bytes ? bytes : Py_None, win);
+    Py_XDECREF(bytes);
+    return result;
+}
+
+PyObject *py_get_frame_argb32(PyObject *self, PyObject *args, PyObject *kw) { return pull_bytes(self, args, kw, CVS_DISPLAY_ARGB32_PREMUL, CVS_LUT_NONE); }
+PyObject *py_get_frame_rgba8(PyObject *self, PyObject *args, PyObject *kw) { return pull_bytes(self, args, kw, CVS_DISPLAY_RGBA8, CVS_LUT_LINEAR_TO_SRGB); }
+
 static PyObject *frame16_full(py_frame16 *self, void *c) { return py_make_box2i(&self->frame.full_window); }
 static PyObject *frame16_current(py_frame16 *self, void *c) { return py_make_box2i(&self->frame.current_window); }
 static PyObject *frame32_full(py_frame32 *self, void *c) { return py_make_box2i(&self->frame.full_window); }
@@ -128,19 +177,15 @@ static PyObject *frame32_pixel(py_frame32 *self, PyObject *args) {
 static PyObject *frame16_to_argb32(py_frame16 *self, PyObject *args) {
     const box2i *w = &self->frame.current_window;
     if (box2i_is_empty(w)) Py_RETURN_NONE;
-    const uint8_t *ramp = video_get_gamma45_ramp();
-    if (!ramp) { PyErr_SetString(PyExc_RuntimeError, cvs_last_error()); return NULL; }
     v2i size;
     box2i_get_size(w, &size);
     PyObject *result = PyByteArray_FromStringAndSize(NULL, (Py_ssize_t)size.x * size.y * 4);
     if (!result) return NULL;
-    uint32_t *out = (uint32_t *)PyByteArray_AS_STRING(result);
-    for (int y = w->min.y; y <= w->max.y; y++) {
-        const rgba_f16 *row = video_get_pixel_f16(&self->frame, w->min.x, y);
-        for (int x = 0; x < size.x; x++) {
-            uint32_t a = ramp[row[x].a];
-            *out++ = (a << 24) | (((ramp[row[x].r] * a >> 8) & 0xFF) << 16) | (((ramp[row[x].g] * a >> 8) & 0xFF) << 8) | ((ramp[row[x].b] * a >> 8) & 0xFF);
-        }
+    /* ramp + premultiplied packing run on the device (RgbaFrameF16.c:114-149 semantics) */
+    if (video_frame_to_bytes(PyByteArray_AS_STRING(result), &self->frame, CVS_LUT_NONE, CVS_DISPLAY_ARGB32_PREMUL) != 0) {
+        Py_DECREF(result);
+        PyErr_SetString(PyExc_RuntimeError, cvs_last_error());
+        return NULL;
     }
     return result;
 }

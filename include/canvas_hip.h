@@ -279,6 +279,16 @@ CVS_EXPORT int cvs_scale_bilinear_f32_dev(rgba_frame_f32 *target, v2f target_poi
 /* separable FIR blur at factor 1 (absent from the reference; defined in DESIGN.md) and the Lanczos
  * gather resampler built on filter_createLanczos */
 CVS_EXPORT int cvs_fir_blur_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, const float *taps_host, int ntaps, cvs_stream_t s);
+/* Display / export edge: the current window of an f16 frame as 4 bytes per pixel, packed row by row.
+ * pre_lut: a transfer table applied to all four halfs first (CVS_LUT_NONE for none); then the half->u8 ramp of
+ * video_get_gamma45_ramp().  CVS_DISPLAY_RGBA8: bytes r,g,b,a -- with CVS_LUT_LINEAR_TO_SRGB the software
+ * widget's conversion (src/cprocess/widget_gl.c:291-307), without a table the exporter's (src/libav/
+ * writeVideo.c:328-340).  CVS_DISPLAY_ARGB32_PREMUL: a<<24 | (r*a>>8)<<16 | (g*a>>8)<<8 | (b*a>>8), what
+ * RgbaFrameF16.to_argb32_bytes returns (src/process/RgbaFrameF16.c:114-149). */
+enum { CVS_DISPLAY_RGBA8 = 0, CVS_DISPLAY_ARGB32_PREMUL = 1 };
+CVS_EXPORT int cvs_frame_to_bytes_dev(void *dst_dev, const rgba_frame_f16 *frame, int pre_lut, int mode, cvs_stream_t stream);
+CVS_EXPORT int video_frame_to_bytes(void *dst_host, const rgba_frame_f16 *host_frame, int pre_lut, int mode);
+
 /* blur node between two f16 frames (widen on load, f32 passes, truncate on store), one launch */
 CVS_EXPORT int cvs_fir_blur_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, const float *taps, int ntaps, cvs_stream_t stream);
 /* f16 pull of a workspace whose lowest item is a blur node on `source` and whose higher items are `overlays`

@@ -66,6 +66,7 @@ def _bind(lib):
         "orc_fir_blur_f32": (None, [P(rgba_frame_f32), P(rgba_frame_f32), f32p, C.c_int]),
         "orc_resample_lanczos_f32": (None, [P(rgba_frame_f32), P(rgba_frame_f32), C.c_float, C.c_float, C.c_int]),
         "orc_workspace_get_frame_f32": (None, [P(ws_item), C.c_int, C.c_int, P(rgba_frame_f32)]),
+        "orc_frame_to_bytes": (None, [P(C.c_uint32), P(rgba_frame_f16), u16p, C.c_int]),
         "orc_chain_color_over_f16": (None, [P(rgba_frame_f16), P(P(rgba_frame_f16)), C.c_int, f32p, u16p, u16p]),
     }
     for name, (res, args) in sig.items():

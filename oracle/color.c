@@ -143,3 +143,31 @@ void orc_chain_color_over_f16(orc_frame16 *out, orc_frame16 *const *layers, int 
     for (int k = 0; k < nlayers; k++) free(graded[k].data);
     free(graded); free(ls); free(srcs); free(items);
 }
+
+/* ---- display / export edge ----
+ * mode 0: bytes r,g,b,a.  With `pre` = the linear->sRGB table this is the software widget's conversion
+ *   (src/cprocess/widget_gl.c:291-307: the table over all four halfs of the row, then the ramp); with pre == NULL
+ *   the exporter's (src/libav/writeVideo.c:328-340).
+ * mode 1: premultiplied ARGB32 (src/process/RgbaFrameF16.c:114-149).
+ * dst is packed over current_window. */
+void orc_frame_to_bytes(uint32_t *dst, const orc_frame16 *frame, const orc_half *pre, int mode) {
+    const orc_box2i *w = &frame->current_window;
+    if (w->max.x < w->min.x || w->max.y < w->min.y) return;
+    const uint8_t *ramp = orc_gamma45_ramp();
+    const int width = w->max.x - w->min.x + 1;
+    for (int y = w->min.y; y <= w->max.y; y++) {
+        const orc_px16 *row = PX((orc_frame16 *)frame, w->min.x, y);
+        for (int x = 0; x < width; x++) {
+            orc_px16 p = row[x];
+            if (pre) { p.r = pre[p.r]; p.g = pre[p.g]; p.b = pre[p.b]; p.a = pre[p.a]; }
+            const uint32_t r = ramp[p.r], g = ramp[p.g], b = ramp[p.b], a = ramp[p.a];
+            uint32_t *o = &dst[(size_t)(y - w->min.y) * (size_t)width + (size_t)x];
+            if (mode == 0) {
+                uint8_t bytes[4] = { (uint8_t)r, (uint8_t)g, (uint8_t)b, (uint8_t)a };    /* rgba_u8 in memory order */
+                memcpy(o, bytes, 4);
+            } else {
+                *o = (a << 24) | (((r * a >> 8) & 0xFF) << 16) | (((g * a >> 8) & 0xFF) << 8) | ((b * a >> 8) & 0xFF);
+            }
+        }
+    }
+}

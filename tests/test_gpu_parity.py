@@ -876,3 +876,64 @@ def test_blur_over_node_by_node(cvs, orc, case):
     got = _blur_over(cvs, full, src, taps, overlays)
     assert same_window(got.current_window, want.current_window)
     assert_same_f16(got.window_view(), want.window_view(), "blur+over %s" % case)
+
+
+# ------------------------------------------------------------------ display / export edge (survey N2)
+
+def _all_codes_frame(full, cur):
+    """Every half code appears in every channel position at least once."""
+    f = HostFrame(full, np.uint16, current_window=cur)
+    h, w = f.array.shape[:2]
+    n = h * w * 4
+    codes = (np.arange(n, dtype=np.uint64) * 40503 % 65536).astype(np.uint16)      # odd multiplier: a permutation, repeated
+    f.array[...] = codes.reshape(h, w, 4)
+    return f
+
+
+@pytest.mark.parametrize("mode", [_lib.DISPLAY_RGBA8, _lib.DISPLAY_ARGB32_PREMUL])
+@pytest.mark.parametrize("pre", [_lib.LUT_NONE, _lib.LUT_LINEAR_TO_SRGB])
+@pytest.mark.parametrize("geom", [((0, 0, 255, 71), (0, 0, 255, 71)),        # whole frame: pair kernel
+                                  ((0, 0, 254, 70), (0, 0, 254, 70)),        # odd pixel count
+                                  ((-3, -2, 200, 90), (5, 1, 150, 77)),      # a window inside the buffer
+                                  ((0, 0, 9, 9), (4, 4, 4, 4))])             # one pixel
+def test_frame_to_bytes(cvs, orc, mode, pre, geom):
+    full, cur = geom
+    frame = _all_codes_frame(full, cur)
+    w, h = cur[2] - cur[0] + 1, cur[3] - cur[1] + 1
+    want = np.zeros((h, w), np.uint32)
+    table = None if pre == _lib.LUT_NONE else orc.transfer_table(pre)
+    orc.lib().orc_frame_to_bytes(want.ctypes.data_as(C.POINTER(C.c_uint32)), frame.ref(), None if table is None else u16p(table), mode)
+    # device frame -> device bytes
+    dev = DeviceFrame.from_host(frame)
+    out = cvs.cvs_malloc(w * h * 4)
+    try:
+        _lib.check(cvs.cvs_frame_to_bytes_dev(out, dev.ref(), pre, mode, None))
+        got = np.zeros((h, w), np.uint32)
+        _lib.check(cvs.cvs_memcpy_d2h(got.ctypes.data, out, w * h * 4, None))
+    finally:
+        cvs.cvs_free(out)
+    assert np.array_equal(got, want)
+    # host frame -> host bytes
+    got2 = np.zeros((h, w), np.uint32)
+    _lib.check(cvs.video_frame_to_bytes(got2.ctypes.data, frame.ref(), pre, mode))
+    assert np.array_equal(got2, want)
+
+
+def test_frame_to_bytes_follows_an_installed_table(cvs, orc):
+    """cvs_lut_install replaces a transfer table: the byte table composed from it must follow."""
+    frame = _all_codes_frame((0, 0, 63, 63), (0, 0, 63, 63))
+    original = orc.transfer_table(_lib.LUT_LINEAR_TO_SRGB)
+    swapped = orc.transfer_table(_lib.LUT_LINEAR_TO_REC709)
+    got = np.zeros((64, 64), np.uint32)
+    want = np.zeros((64, 64), np.uint32)
+    try:
+        _lib.check(cvs.video_frame_to_bytes(got.ctypes.data, frame.ref(), _lib.LUT_LINEAR_TO_SRGB, _lib.DISPLAY_RGBA8))
+        _lib.check(cvs.cvs_lut_install(_lib.LUT_LINEAR_TO_SRGB, u16p(swapped)))
+        _lib.check(cvs.video_frame_to_bytes(got.ctypes.data, frame.ref(), _lib.LUT_LINEAR_TO_SRGB, _lib.DISPLAY_RGBA8))
+        orc.lib().orc_frame_to_bytes(want.ctypes.data_as(C.POINTER(C.c_uint32)), frame.ref(), u16p(swapped), 0)
+        assert np.array_equal(got, want)
+    finally:
+        _lib.check(cvs.cvs_lut_install(_lib.LUT_LINEAR_TO_SRGB, u16p(original)))
+    empty = HostFrame((0, 0, 3, 3), np.uint16, current_window=(0, 0, -1, -1))
+    assert cvs.video_frame_to_bytes(got.ctypes.data, empty.ref(), _lib.LUT_NONE, _lib.DISPLAY_RGBA8) == 0
+    assert cvs.video_frame_to_bytes(got.ctypes.data, frame.ref(), _lib.LUT_NONE, 7) != 0

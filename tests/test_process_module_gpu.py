@@ -283,3 +283,32 @@ def test_pull_queue_delivers_frames(process, bt):
     cancelled = q.enqueue(source=solid, frame_index=99, window=bt.box2i(0, 0, 1, 1), callback=callback, user_data=None)
     cancelled.cancel()
     del items
+
+
+def test_preview_pulls_convert_on_the_device(process, bt, orc):
+    """get_frame_argb32 equals get_frame_f16(...).to_argb32_bytes() (RgbaFrameF16.c:114-149 against the oracle);
+    get_frame_rgba8 is the software widget's sRGB bytes (widget_gl.c:291-307)."""
+    from canvas_amd.abi import HostFrame
+    ws = process.VideoWorkspace()
+    ws.add(source=process.SolidColorVideoSource((0.25, 0.5, 0.75, 1.0), bt.box2i(0, 0, 30, 20)), x=0, length=10, z=0)
+    ws.add(source=process.SolidColorVideoSource((0.9, 0.1, 0.3, 0.4), bt.box2i(8, 5, 40, 30)), x=0, length=10, z=1)
+    window = bt.box2i(-2, -2, 35, 25)
+    frame = ws.get_frame_f16(3, window)
+    raw, cur = ws.get_frame_argb32(3, window)
+    assert cur == frame.current_window and bytes(raw) == bytes(frame.to_argb32_bytes())
+    # against the oracle, from the pulled halfs
+    cw = frame.current_window
+    w, h = cw.max.x - cw.min.x + 1, cw.max.y - cw.min.y + 1
+    host = HostFrame((cw.min.x, cw.min.y, cw.max.x, cw.max.y), np.uint16)
+    for y in range(h):
+        for x in range(w):
+            host.array[y, x] = orc.float_to_half(np.array(frame.pixel(cw.min.x + x, cw.min.y + y), np.float32))
+    want = np.zeros((h, w), np.uint32)
+    orc.lib().orc_frame_to_bytes(want.ctypes.data_as(C.POINTER(C.c_uint32)), host.ref(), None, 1)
+    assert bytes(raw) == want.tobytes()
+    rgba, cur2 = ws.get_frame_rgba8(3, window)
+    table = orc.transfer_table(3)
+    orc.lib().orc_frame_to_bytes(want.ctypes.data_as(C.POINTER(C.c_uint32)), host.ref(), table.ctypes.data_as(C.POINTER(C.c_uint16)), 0)
+    assert cur2 == cur and bytes(rgba) == want.tobytes()
+    nothing, cur3 = process.EmptyVideoSource().get_frame_argb32(0, window)
+    assert nothing is None and cur3.empty()
