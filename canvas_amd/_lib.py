@@ -31,6 +31,10 @@ class chain_job(C.Structure):
                 ("nlayers", C.c_int)]
 
 
+class coded_image(C.Structure):
+    _fields_ = [("data", C.c_void_p * 4), ("stride", C.c_int * 4), ("line_count", C.c_int * 4), ("free_func", C.c_void_p)]
+
+
 P = C.POINTER
 rgba_frame_f16_t = rgba_frame_f16
 _u16p, _f32p, _vp = P(C.c_uint16), P(C.c_float), C.c_void_p
@@ -127,6 +131,12 @@ SIGNATURES = {
     "cvs_fill_solid_f32_dev": (C.c_int, [_F32, P(box2i), P(rgba_f32), _vp]),
     "cvs_scale_bilinear_f32_dev": (C.c_int, [_F32, v2f, _F32, v2f, v2f, _vp]),
     "cvs_fir_blur_f32_dev": (C.c_int, [_F32, _F32, _f32p, C.c_int, _vp]),
+    "coded_image_alloc": (P(coded_image), [P(C.c_int), P(C.c_int), C.c_int]),
+    "coded_image_alloc0": (P(coded_image), [P(C.c_int), P(C.c_int), C.c_int]),
+    "video_reconstruct_dv": (None, [_F16, P(coded_image)]),
+    "video_subsample_dv": (P(coded_image), [_F16]),
+    "cvs_reconstruct_dv_dev": (C.c_int, [_F16, P(coded_image), _vp]),
+    "cvs_subsample_dv_dev": (C.c_int, [P(coded_image), _F16, C.c_int, _vp]),
     "cvs_frame_to_bytes_dev": (C.c_int, [_vp, _F16, C.c_int, C.c_int, _vp]),
     "video_frame_to_bytes": (C.c_int, [_vp, _F16, C.c_int, C.c_int]),
     "cvs_fir_blur_f16_dev": (C.c_int, [_F16, _F16, _f32p, C.c_int, _vp]),

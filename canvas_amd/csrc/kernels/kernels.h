@@ -130,6 +130,12 @@ int cvk_blur(const cvk_blur_params *bp, int cus, void *stream);
 enum { CVK_DISPLAY_RGBA8 = 0, CVK_DISPLAY_ARGB32_PREMUL = 1 };
 int cvk_display(void *dst, cvk_view src, cvk_rect r, const uint8_t *table, int mode, int cus, void *stream);
 
+/* DV 4:1:1 edge (video_reconstruct.c:50-137, video_subsample.c:99-187): device planes + strides in bytes */
+typedef struct { uint8_t *y, *cb, *cr; int sy, scb, scr; } cvk_dv_planes;
+typedef struct { float coeff[16]; int width, center; } cvk_dv_taps;
+int cvk_dv_reconstruct(cvk_view frame, cvk_rect cur, const cvk_dv_planes *pl, const cvk_dv_taps *tri, const uint16_t *lut, void *stream);
+int cvk_dv_subsample(const cvk_dv_planes *pl, cvk_view frame, cvk_rect w, const cvk_dv_taps *tri, const uint16_t *lut, int encode_in_place, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

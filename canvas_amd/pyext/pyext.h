@@ -38,6 +38,7 @@ PyObject *py_get_frame_rgba8(PyObject *self, PyObject *args, PyObject *kw);
 int init_frames(PyObject *module);
 int init_framefuncs(PyObject *module);
 int init_animation(PyObject *module);
+int init_dv(PyObject *module);
 int init_sources(PyObject *module);
 int init_workspace(PyObject *module);
 

@@ -345,7 +345,7 @@ PyMODINIT_FUNC PyInit_process(void) {
     if (import_basetypes() != 0) { Py_DECREF(m); return NULL; }
     init_half();
     if (pyext_add_type(m, "VideoSource", &py_type_VideoSource) < 0 || init_framefuncs(m) < 0 || init_animation(m) < 0 || init_frames(m) < 0 ||
-        init_sources(m) < 0 || init_workspace(m) < 0) {
+        init_sources(m) < 0 || init_workspace(m) < 0 || init_dv(m) < 0) {
         Py_DECREF(m);
         return NULL;
     }

@@ -279,6 +279,23 @@ CVS_EXPORT int cvs_scale_bilinear_f32_dev(rgba_frame_f32 *target, v2f target_poi
 /* separable FIR blur at factor 1 (absent from the reference; defined in DESIGN.md) and the Lanczos
  * gather resampler built on filter_createLanczos */
 CVS_EXPORT int cvs_fir_blur_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, const float *taps_host, int ntaps, cvs_stream_t s);
+/* DV 4:1:1 edge: planar 8-bit Y'CbCr (Y 720x480, Cb and Cr 180x480) <-> half RGBA on the fixed NTSC DV raster
+ * whose first line sits at y = -1.  coded_image: include/framework.h:468-476; alloc: video_subsample.c:23-68. */
+#define CODED_IMAGE_MAX_PLANES 4
+typedef struct {
+    void *data[CODED_IMAGE_MAX_PLANES];
+    int stride[CODED_IMAGE_MAX_PLANES];
+    int line_count[CODED_IMAGE_MAX_PLANES];
+    void (*free_func)(void *image);          /* GFreeFunc */
+} coded_image;
+CVS_EXPORT coded_image *coded_image_alloc(const int *strides, const int *line_counts, int count);
+CVS_EXPORT coded_image *coded_image_alloc0(const int *strides, const int *line_counts, int count);
+CVS_EXPORT void video_reconstruct_dv(rgba_frame_f16 *frame, coded_image *planar);       /* video_reconstruct.c:50-137 */
+CVS_EXPORT coded_image *video_subsample_dv(rgba_frame_f16 *frame);                      /* video_subsample.c:99-187; encodes the frame's rows in place, as there */
+/* device frame + device planes (planar->data[] are device pointers) */
+CVS_EXPORT int cvs_reconstruct_dv_dev(rgba_frame_f16 *frame, const coded_image *planar, cvs_stream_t stream);
+CVS_EXPORT int cvs_subsample_dv_dev(coded_image *planar, rgba_frame_f16 *frame, int encode_input_in_place, cvs_stream_t stream);
+
 /* Display / export edge: the current window of an f16 frame as 4 bytes per pixel, packed row by row.
  * pre_lut: a transfer table applied to all four halfs first (CVS_LUT_NONE for none); then the half->u8 ramp of
  * video_get_gamma45_ramp().  CVS_DISPLAY_RGBA8: bytes r,g,b,a -- with CVS_LUT_LINEAR_TO_SRGB the software

@@ -61,6 +61,15 @@ CVS_EXPORT void framefunc_init(FrameFunctionHolder *holder, double c0, double c1
 CVS_EXPORT extern PyTypeObject py_type_FrameFunction;
 CVS_EXPORT extern PyTypeObject py_type_AnimationFunc;      /* src/process/AnimationFunc.c:349 */
 
+/* coded images (pyframework.h:121-132, framework.h:510-523) */
+#define CODED_IMAGE_SOURCE_FUNCS "_coded_image_source_funcs"
+typedef coded_image *(*coded_image_getFrameFunc)(void *self, int frame, int quality_hint);
+typedef struct { int flags; coded_image_getFrameFunc getFrame; } coded_image_source_funcs;
+typedef struct { void *obj; coded_image_source_funcs *funcs; } coded_image_source;     /* obj: the PyObject, a strong reference */
+typedef struct { coded_image_source source; PyObject *csource; } CodedImageSourceHolder;
+CVS_EXPORT bool py_coded_image_take_source(PyObject *source, CodedImageSourceHolder *holder);
+CVS_EXPORT extern PyTypeObject py_type_CodedImageSource;
+
 #if defined(__cplusplus)
 }
 #endif

@@ -20,7 +20,7 @@ _SO = os.path.join(_HERE, "liboracle.so")
 def build(force=False, arch="", out=None):
     """Compile the C restatement.  `out` lets bench.py build a -march=native copy elsewhere."""
     out = out or _SO
-    srcs = [os.path.join(_HERE, f) for f in ("tables.c", "mix.c", "scale.c", "color.c", "oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("tables.c", "mix.c", "scale.c", "color.c", "dv.c", "oracle.h")]
     if not force and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(s) for s in srcs):
         return out
     cmd = ["make", "-C", _HERE, "-B", "OUT=" + out] + (["ARCH=" + arch] if arch else [])
@@ -66,6 +66,8 @@ def _bind(lib):
         "orc_fir_blur_f32": (None, [P(rgba_frame_f32), P(rgba_frame_f32), f32p, C.c_int]),
         "orc_resample_lanczos_f32": (None, [P(rgba_frame_f32), P(rgba_frame_f32), C.c_float, C.c_float, C.c_int]),
         "orc_workspace_get_frame_f32": (None, [P(ws_item), C.c_int, C.c_int, P(rgba_frame_f32)]),
+        "orc_reconstruct_dv": (None, [P(rgba_frame_f16), P(C.c_void_p), P(C.c_int)]),
+        "orc_subsample_dv": (None, [P(C.c_void_p), P(C.c_int), P(rgba_frame_f16)]),
         "orc_frame_to_bytes": (None, [P(C.c_uint32), P(rgba_frame_f16), u16p, C.c_int]),
         "orc_chain_color_over_f16": (None, [P(rgba_frame_f16), P(P(rgba_frame_f16)), C.c_int, f32p, u16p, u16p]),
     }

@@ -26,6 +26,7 @@ def test_surface_is_complete(process):
                  "VideoGainOffsetFilter", "VideoMixFilter", "VideoScaler", "VideoPassThroughFilter", "VideoSequence",
                  "VideoWorkspace", "VideoPullQueue", "FrameFunction", "LerpFunc", "LinearFrameFunc",
                  "AnimationFunc", "AnimationPoint", "POINT_HOLD", "POINT_LINEAR",
+                 "CodedImageSource", "CodedImage", "DVReconstructionFilter", "DVSubsampleFilter",
                  "get_frame_time", "get_time_frame", "time_get_frame", "enable_glib_logging",
                  "create_offscreen_gl_context", "set_current_gl_context", "check_context_supported"]:
         assert hasattr(process, name), name
@@ -197,6 +198,35 @@ def test_animation_func_drives_filter_parameters(process):
     process.VideoMixFilter(a, b, mix)
     process.VideoGainOffsetFilter(a, gain=mix, offset=0.0)
     assert hasattr(mix, "_frame_function_funcs")
+
+
+def test_coded_image_sources(process):
+    """CodedImageSource.c:53-102,118-223: a Python subclass feeds planes through the capsule; the base has nothing."""
+    class Planes(process.CodedImageSource):
+        def get_frame(self, frame):
+            if frame < 0:
+                return None
+            return [process.CodedImage(bytearray([frame % 256]) * (720 * 480), 720, 480),
+                    process.CodedImage(bytearray(180 * 480), 180, 480), process.CodedImage(bytearray(180 * 480), 180, 480)]
+
+    class Short(process.CodedImageSource):
+        def get_frame(self, frame):
+            return [process.CodedImage(bytearray(10), 720, 480)]          # wrong size: refused, like the reference's warning
+
+    src = Planes()
+    out = process.CodedImageSource.get_frame(src, 7)                       # base method -> capsule -> the override
+    assert [(p.stride, p.line_count) for p in out] == [(720, 480), (180, 480), (180, 480)] and out[0].data[:2] == b"\x07\x07"
+    assert process.CodedImageSource.get_frame(src, -1) is None
+    assert process.CodedImageSource().get_frame(0) is None
+    assert process.CodedImageSource.get_frame(Short(), 0) is None
+    recon = process.DVReconstructionFilter(src)
+    assert isinstance(recon, process.VideoSource) and hasattr(recon, "_video_frame_source_funcs")
+    sub = process.DVSubsampleFilter(process.SolidColorVideoSource((0.2, 0.3, 0.4, 1.0)))
+    assert isinstance(sub, process.CodedImageSource) and hasattr(sub, "_coded_image_source_funcs")
+    with pytest.raises(Exception):
+        process.DVReconstructionFilter(process.EmptyVideoSource())
+    with pytest.raises(Exception):
+        process.DVSubsampleFilter(src)
 
 
 def test_without_a_gpu_pulls_are_empty_and_loud(process):

@@ -312,3 +312,35 @@ def test_preview_pulls_convert_on_the_device(process, bt, orc):
     assert cur2 == cur and bytes(rgba) == want.tobytes()
     nothing, cur3 = process.EmptyVideoSource().get_frame_argb32(0, window)
     assert nothing is None and cur3.empty()
+
+
+def test_dv_nodes_against_oracle(process, bt, orc):
+    """Solid colour + window -> DVSubsampleFilter -> planes (oracle: orc_subsample_dv) -> a Python coded-image
+    source -> DVReconstructionFilter -> frame (oracle: orc_reconstruct_dv)."""
+    from canvas_amd.abi import HostFrame
+    solid = process.SolidColorVideoSource((0.2, 0.45, 0.7, 1.0), bt.box2i(40, 30, 650, 400))
+    planes = process.DVSubsampleFilter(solid).get_frame(0)
+    assert [(p.stride, p.line_count) for p in planes] == [(720, 480), (180, 480), (180, 480)]
+    full = (0, -1, 719, 478)
+    host = HostFrame(full, np.uint16, current_window=(40, 30, 650, 400))
+    host.array[...] = orc.float_to_half(np.array([0.2, 0.45, 0.7, 1.0], np.float32))
+    want = [np.zeros((480, s), np.uint8) for s in (720, 180, 180)]
+    orc.lib().orc_subsample_dv((C.c_void_p * 3)(*[w.ctypes.data for w in want]), (C.c_int * 3)(720, 180, 180), host.ref())
+    for p in range(3):
+        assert bytes(planes[p].data) == want[p].tobytes(), "plane %d" % p
+
+    class Fixed(process.CodedImageSource):
+        def get_frame(self, frame):
+            return planes
+
+    recon = process.DVReconstructionFilter(Fixed())
+    window = bt.box2i(-4, -3, 725, 481)
+    frame = recon.get_frame_f16(0, window)
+    assert frame.current_window == bt.box2i(0, -1, 719, 478)
+    theirs = HostFrame((-4, -3, 725, 481), np.uint16)
+    orc.lib().orc_reconstruct_dv(theirs.ref(), (C.c_void_p * 3)(*[w.ctypes.data for w in want]), (C.c_int * 3)(720, 180, 180))
+    for x, y in [(0, -1), (40, 30), (41, 30), (43, 31), (300, 200), (650, 400), (651, 401), (719, 478)]:
+        got = orc.float_to_half(np.array(frame.pixel(x, y), np.float32))
+        assert np.array_equal(got, theirs.array[y + 3, x + 4]), (x, y)
+    # inside the solid's window the round trip lands near the colour it started from
+    almost(frame.pixel(300, 200), (0.2, 0.45, 0.7, 1.0), 1)
