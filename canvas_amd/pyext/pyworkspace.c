@@ -199,7 +199,7 @@ typedef struct {
     pthread_mutex_t mutex;
     pthread_cond_t wake;
     py_pq_item *head, *tail;
-    pthread_t workers[2];
+    pthread_t workers[16];
     int nworkers, quit;
 } py_pullqueue;
 
@@ -232,10 +232,17 @@ static void *pq_worker(void *arg) {
     }
 }
 
+/* VideoPullQueue(workers=2): each worker thread pulls on its own HIP stream (the library binds one stream per
+ * thread), so `workers` frames are in flight on the device at a time; 2 is the reference's pool size
+ * (VideoPullQueue.c:110). */
 static int pq_init(py_pullqueue *self, PyObject *args, PyObject *kw) {
+    static char *kwlist[] = { "workers", NULL };
+    int workers = 2;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "|i", kwlist, &workers)) return -1;
+    if (workers < 1 || workers > 16) { PyErr_SetString(PyExc_ValueError, "workers must be between 1 and 16"); return -1; }
     pthread_mutex_init(&self->mutex, NULL);
     pthread_cond_init(&self->wake, NULL);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < workers; i++)
         if (pthread_create(&self->workers[i], NULL, pq_worker, self) == 0) self->nworkers++;
     if (!self->nworkers) { PyErr_SetString(PyExc_RuntimeError, "could not start worker threads"); return -1; }
     return 0;

@@ -200,6 +200,13 @@ def test_animation_func_drives_filter_parameters(process):
     assert hasattr(mix, "_frame_function_funcs")
 
 
+def test_pull_queue_worker_count(process):
+    process.VideoPullQueue(workers=4)
+    for bad in (0, 17):
+        with pytest.raises(ValueError):
+            process.VideoPullQueue(workers=bad)
+
+
 def test_coded_image_sources(process):
     """CodedImageSource.c:53-102,118-223: a Python subclass feeds planes through the capsule; the base has nothing."""
     class Planes(process.CodedImageSource):

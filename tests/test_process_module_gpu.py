@@ -265,8 +265,9 @@ def test_foreign_host_only_source_plugs_in(process, bt):
     almost(px, (14.0, 1.0, 0.5, 1.0), 6)
 
 
-def test_pull_queue_delivers_frames(process, bt):
-    q = process.VideoPullQueue()
+@pytest.mark.parametrize("workers", [None, 1, 6])
+def test_pull_queue_delivers_frames(process, bt, workers):
+    q = process.VideoPullQueue() if workers is None else process.VideoPullQueue(workers=workers)
     solid = ramp(process, 0)
     done, seen = threading.Event(), {}
 
