@@ -458,7 +458,7 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
 static bool blur_has_fast_kernel(const float *taps, int ntaps) {
     bool finite = true;
     for (int k = 0; k < ntaps; k++) finite = finite && isfinite(taps[k]);
-    return finite && cvk_blur_supported(ntaps) && !getenv("CVS_BLUR_GENERIC");
+    return finite && cvk_blur_supported(ntaps, 1) && !getenv("CVS_BLUR_GENERIC");
 }
 
 /* `over`: nover f16 buffers with the target's layout, blended over the blur result before the store (f16 in/out only) */
@@ -497,6 +497,31 @@ static int blur_fused(void *tdata, const box2i *tfull, int out_half, const void 
 
 static int lanczos_fused(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
                          float fx, float fy, int ksize, hipStream_t s) {
+    /* Halving on both axes: every line centre t / 0.5 is an integer, so every line gets the taps of offset 0 and
+     * reads source lines 2t - centre + k (plan_lanczos with frac == 0): the decimating register-window kernel. */
+    if (fx == 0.5f && fy == 0.5f && !getenv("CVS_BLUR_GENERIC")) {
+        fir_filter f = { NULL, 0, 0 };
+        filter_createLanczos(0.5f, ksize, 0.0f, &f);
+        bool usable = f.coeff && cvk_blur_supported(f.width, 2) && f.center == f.width / 2 &&
+                      tfull->min.x > -(1 << 22) && tfull->max.x < (1 << 22) && tfull->min.y > -(1 << 22) && tfull->max.y < (1 << 22);
+        for (int k = 0; usable && k < f.width; k++) usable = isfinite(f.coeff[k]);
+        if (usable) {
+            cvk_blur_params bp;
+            memset(&bp, 0, sizeof bp);
+            bp.target = cvs_view(tdata, tfull);
+            bp.source = cvs_view((void *)sdata, sfull);
+            bp.in_half = in_half; bp.out_half = out_half;
+            bp.tx0 = tfull->min.x; bp.ty0 = tfull->min.y; bp.tx1 = tfull->max.x; bp.ty1 = tfull->max.y;
+            bp.sx0 = sw->min.x; bp.sy0 = sw->min.y; bp.sx1 = sw->max.x; bp.sy1 = sw->max.y;
+            bp.ntaps = f.width; bp.step = 2;
+            memcpy(bp.taps, f.coeff, sizeof(float) * (size_t)f.width);
+            filter_free(&f);
+            int rc = cvk_blur(&bp, cvs_cus(), s);
+            if (rc != 0) { cvs_set_error("resample launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
+            return 0;
+        }
+        filter_free(&f);
+    }
     uint32_t bx, by;
     memcpy(&bx, &fx, 4); memcpy(&by, &fy, 4);
     axis_key kh = make_key(2, bx, ksize, 0, tfull->min.x, tfull->max.x, sw->min.x, sw->max.x, CVK_FIR2D_TILE_X);

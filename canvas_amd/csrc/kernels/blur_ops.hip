@@ -58,20 +58,27 @@ __device__ __forceinline__ void each_slot(F &f, std::integer_sequence<int, Js...
 // EPI: the blurred pixel is the bottom layer of a workspace stack -- bp.nover f16 frames (same geometry as the
 // target) are blended over it with video_mix.c:323-337 at mix 1.0 before the truncating store, so the f32 blur
 // result never leaves the registers (a workspace pulls its items as f32: no rounding between blur and over).
-template <int NT, int W, bool INH, bool EPI>
+//
+// STEP > 1: the same sweep as a decimating resampler -- target line t reads source lines STEP*t - c + k.  That
+// is what the Lanczos gather degenerates to when the scale factor is 1/STEP with STEP a power of two: every
+// line centre t / factor is an integer, every fractional offset is 0, every line gets the same taps
+// (scale.c plan_lanczos).  A lane then loads STEP source columns per row, the LDS row is kept de-interleaved
+// (one array per column phase, so tap reads stay contiguous across lanes), H is formed for target columns only,
+// every source row is pushed into the ring, and an output row leaves every STEP-th step.
+template <int NT, int W, bool INH, bool EPI, int STEP>
 __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
-    constexpr int C = NT / 2, OUTW = W - (NT - 1), PITCH = W + 16;
-    __shared__ float4 rowbuf[2][PITCH];
+    constexpr int C = NT / 2, OUTW = (STEP * W - NT) / STEP + 1, PITCH = W + 16;
+    static_assert(!(EPI && STEP != 1), "the over epilogue is for the 1:1 blur");
+    __shared__ float4 rowbuf[2][STEP][PITCH];
     const int lane = threadIdx.x;
     const int xo = bp.tx0 + (int)blockIdx.x * OUTW;          // first target column of the strip
-    const int scol = xo - C + lane;                          // the source column this lane loads
+    const int sfirst = STEP * xo - C;                        // first source column of the strip
     const int tcol = xo + lane;                              // the target column this lane produces
-    const bool col_live = scol >= bp.sx0 && scol <= bp.sx1;
     const bool out_live = lane < OUTW && tcol <= bp.tx1;
     const int ta = bp.ty0 + (int)blockIdx.y * bp.rows_per_wg;
     const int tb = min(ta + bp.rows_per_wg - 1, bp.ty1);
-    const int ys0 = ta - C;                                  // first source row the segment needs
-    const int steps = (tb - ta + 1) + NT - 1;
+    const int ys0 = STEP * ta - C;                           // first source row the segment needs
+    const int steps = STEP * (tb - ta) + NT;
 
     float w[NT];
 #pragma unroll
@@ -79,20 +86,38 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
 
     constexpr size_t SPX = INH ? 8 : 16;
     const size_t srow = (size_t)bp.source.pitch * SPX;
-    const char *sbase = reinterpret_cast<const char *>(bp.source.data) + (ptrdiff_t)(scol - bp.source.fx0) * (ptrdiff_t)SPX;
+    // lane loads source columns sfirst + lane + r * W, r < STEP
+    const char *sbase[STEP];
+    bool col_live[STEP];
+#pragma unroll
+    for (int r = 0; r < STEP; r++) {
+        const int scol = sfirst + lane + r * W;
+        col_live[r] = scol >= bp.sx0 && scol <= bp.sx1;
+        sbase[r] = reinterpret_cast<const char *>(bp.source.data) + (ptrdiff_t)(scol - bp.source.fx0) * (ptrdiff_t)SPX;
+    }
     const size_t tpx = bp.out_half ? 8 : 16;
     char *tbase = reinterpret_cast<char *>(bp.target.data) + (ptrdiff_t)(tcol - bp.target.fx0) * (ptrdiff_t)tpx;
     const size_t trow = (size_t)bp.target.pitch * tpx;
 
-    if (lane < 16) { rowbuf[0][W + lane] = make_float4(0.f, 0.f, 0.f, 0.f); rowbuf[1][W + lane] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    if (lane < 16) {
+#pragma unroll
+        for (int r = 0; r < STEP; r++) { rowbuf[0][r][W + lane] = make_float4(0.f, 0.f, 0.f, 0.f); rowbuf[1][r][W + lane] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
 
     Px ring[NT];
 #pragma unroll
     for (int k = 0; k < NT; k++) ring[k].rg = ring[k].ba = f32x2{ 0.0f, 0.0f };
 
-    auto row_live = [&](int ys) { return col_live && ys >= bp.sy0 && ys <= bp.sy1; };
-    Raw<INH> cur = fetch<INH>(sbase, srow, ys0, bp.source.fy0, row_live(ys0));
-    Raw<INH> nxt = fetch<INH>(sbase, srow, ys0 + 1, bp.source.fy0, steps > 1 && row_live(ys0 + 1));
+    struct Row { Raw<INH> v[STEP]; };
+    auto fetch_row = [&](int ys, bool wanted) {
+        Row row;
+        const bool live = wanted && ys >= bp.sy0 && ys <= bp.sy1;
+#pragma unroll
+        for (int r = 0; r < STEP; r++) row.v[r] = fetch<INH>(sbase[r], srow, ys, bp.source.fy0, live && col_live[r]);
+        return row;
+    };
+    Row cur = fetch_row(ys0, true);
+    Row nxt = fetch_row(ys0 + 1, steps > 1);
 
     for (int i0 = 0; i0 < steps; i0 += NT) {
         // NT steps with the ring slot as a compile-time constant (a runtime index would send the ring to scratch)
@@ -101,27 +126,32 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
             const int i = i0 + j;
             if (i >= steps) return false;                     // uniform over the workgroup
             const int ys = ys0 + i;
+            const bool emits = i >= NT - 1 && (STEP == 1 || (i - (NT - 1)) % STEP == 0);     // uniform
+            const int t = ta + (i - (NT - 1)) / STEP;         // the target row this step completes
             // two rows ahead goes out now; this row's data was requested two steps ago
-            const Raw<INH> far = fetch<INH>(sbase, srow, ys + 2, bp.source.fy0, i + 2 < steps && row_live(ys + 2));
+            const Row far = fetch_row(ys + 2, i + 2 < steps);
             // the upper layers of this step's output pixel: requested before the barrier, used after the sums
             uint2 ov[CVK_BLUR_MAX_OVER];
             if constexpr (EPI) {
-                const int t = ys + C - (NT - 1);
                 const size_t o = (size_t)(t - bp.target.fy0) * (size_t)bp.target.pitch + (size_t)(tcol - bp.target.fx0);
 #pragma unroll
                 for (int l = 0; l < CVK_BLUR_MAX_OVER; l++) {
                     ov[l] = make_uint2(0u, 0u);
-                    if (l < bp.nover && i >= NT - 1 && out_live) ov[l] = reinterpret_cast<const uint2 *>(bp.over[l])[o];
+                    if (l < bp.nover && emits && out_live) ov[l] = reinterpret_cast<const uint2 *>(bp.over[l])[o];
                 }
             }
-            float4 *buf = rowbuf[i & 1];
-            buf[lane] = widen<INH>(cur);
+            float4 (*buf)[PITCH] = rowbuf[i & 1];
+#pragma unroll
+            for (int r = 0; r < STEP; r++) {
+                const int q = lane + r * W;                   // offset from sfirst; phase q % STEP, slot q / STEP
+                buf[q % STEP][q / STEP] = widen<INH>(cur.v[r]);
+            }
             cur = nxt;
             nxt = far;
             __syncthreads();
             float4 v[NT];
 #pragma unroll
-            for (int k = 0; k < NT; k++) v[k] = buf[lane + k];
+            for (int k = 0; k < NT; k++) v[k] = buf[k % STEP][lane + k / STEP];
             f32x2 rg = { 0.0f, 0.0f }, ba = { 0.0f, 0.0f };
 #pragma unroll
             for (int k = 0; k < NT; k++) {
@@ -130,7 +160,7 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
             }
             ring[j].rg = rg;
             ring[j].ba = ba;
-            if (i >= NT - 1) {
+            if (emits) {
                 // ring[(j+1) % NT] is the oldest row = tap 0
                 f32x2 org = { 0.0f, 0.0f }, oba = { 0.0f, 0.0f };
 #pragma unroll
@@ -151,7 +181,6 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
                     oba = f32x2{ acc.b, acc.a };
                 }
                 if (out_live) {
-                    const int t = ys + C - (NT - 1);
                     char *o = tbase + (size_t)(t - bp.target.fy0) * trow;
                     if (bp.out_half) *reinterpret_cast<uint2 *>(o) = make_uint2(cvs::f2h_rz2(org.x, org.y), cvs::f2h_rz2(oba.x, oba.y));
                     else *reinterpret_cast<float4 *>(o) = make_float4(org.x, org.y, oba.x, oba.y);
@@ -163,59 +192,90 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
     }
 }
 
-template <int NT, int W>
-int launch(const cvk_blur_params *bp, hipStream_t s) {
-    constexpr int OUTW = W - (NT - 1);
-    const int cols = bp->tx1 - bp->tx0 + 1, rows = bp->ty1 - bp->ty0 + 1;
-    dim3 grid((unsigned)((cols + OUTW - 1) / OUTW), (unsigned)((rows + bp->rows_per_wg - 1) / bp->rows_per_wg));
-    if (bp->nover > 0)    hipLaunchKernelGGL((k_blur<NT, W, true, true>), grid, dim3(W), 0, s, *bp);      // f16 in, f16 out
-    else if (bp->in_half) hipLaunchKernelGGL((k_blur<NT, W, true, false>), grid, dim3(W), 0, s, *bp);
-    else                  hipLaunchKernelGGL((k_blur<NT, W, false, false>), grid, dim3(W), 0, s, *bp);
+// rows per workgroup: as many workgroups as the chip holds at once (occupancy of this instance x CUs), all in
+// one wave of the grid -- a second, partly filled wave costs more than the halo rows a shorter segment adds
+template <class K>
+int resident_per_cu(K kernel, int block) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, 0) != hipSuccess || n < 1) n = 1;
+    static int cap = -1;
+    if (cap < 0) { const char *e = getenv("CVS_BLUR_WGS_PER_CU"); cap = e ? atoi(e) : 0; }
+    return cap > 0 ? cap : n;
+}
+
+template <int NT, int W, int STEP>
+int launch(cvk_blur_params bp, int cus, hipStream_t s) {
+    constexpr int OUTW = (STEP * W - NT) / STEP + 1;
+    const int cols = bp.tx1 - bp.tx0 + 1, rows = bp.ty1 - bp.ty0 + 1;
+    const int strips = (cols + OUTW - 1) / OUTW;
+    const bool epi = STEP == 1 && bp.nover > 0;
+    static int occ[3] = { 0, 0, 0 };               // per instance: [epilogue, f16 in, f32 in]
+    int &mine = occ[epi ? 0 : bp.in_half ? 1 : 2];
+    if (!mine) {
+        if constexpr (STEP == 1) { if (epi) mine = resident_per_cu(k_blur<NT, W, true, true, 1>, W); }
+        if (!mine) mine = bp.in_half ? resident_per_cu(k_blur<NT, W, true, false, STEP>, W) : resident_per_cu(k_blur<NT, W, false, false, STEP>, W);
+    }
+    if (bp.rows_per_wg <= 0) {
+        int segs = (mine * cus) / strips;
+        if (segs < 1) segs = 1;
+        int r = (rows + segs - 1) / segs;
+        const int lo = (NT - 1) / STEP;            // halo rows cost at most as much as the rows produced
+        if (r < lo) r = lo;
+        if (r > rows) r = rows;
+        bp.rows_per_wg = r;
+    }
+    dim3 grid((unsigned)strips, (unsigned)((rows + bp.rows_per_wg - 1) / bp.rows_per_wg));
+    if constexpr (STEP == 1) {
+        if (epi) { hipLaunchKernelGGL((k_blur<NT, W, true, true, 1>), grid, dim3(W), 0, s, bp); return (int)hipGetLastError(); }     // f16 in, f16 out
+    }
+    if (bp.in_half) hipLaunchKernelGGL((k_blur<NT, W, true, false, STEP>), grid, dim3(W), 0, s, bp);
+    else            hipLaunchKernelGGL((k_blur<NT, W, false, false, STEP>), grid, dim3(W), 0, s, bp);
     return (int)hipGetLastError();
 }
 
 template <int W>
-int pick(const cvk_blur_params *bp, hipStream_t s) {
+int pick(const cvk_blur_params *bp, int cus, hipStream_t s) {
+    if (bp->step == 2) {
+        switch (bp->ntaps) {                       // Lanczos-k at 1/2: 4k - 1 taps
+        case 3:  return launch<3, W, 2>(*bp, cus, s);
+        case 7:  return launch<7, W, 2>(*bp, cus, s);
+        case 11: return launch<11, W, 2>(*bp, cus, s);
+        case 15: return launch<15, W, 2>(*bp, cus, s);
+        default: return (int)hipErrorInvalidValue;
+        }
+    }
     switch (bp->ntaps) {
-    case 3:  return launch<3, W>(bp, s);
-    case 5:  return launch<5, W>(bp, s);
-    case 7:  return launch<7, W>(bp, s);
-    case 9:  return launch<9, W>(bp, s);
-    case 11: return launch<11, W>(bp, s);
-    case 13: return launch<13, W>(bp, s);
-    case 15: return launch<15, W>(bp, s);
+    case 3:  return launch<3, W, 1>(*bp, cus, s);
+    case 5:  return launch<5, W, 1>(*bp, cus, s);
+    case 7:  return launch<7, W, 1>(*bp, cus, s);
+    case 9:  return launch<9, W, 1>(*bp, cus, s);
+    case 11: return launch<11, W, 1>(*bp, cus, s);
+    case 13: return launch<13, W, 1>(*bp, cus, s);
+    case 15: return launch<15, W, 1>(*bp, cus, s);
     default: return (int)hipErrorInvalidValue;
     }
 }
 
 }  // namespace
 
-extern "C" int cvk_blur_supported(int ntaps) { return ntaps >= 3 && ntaps <= 15 && (ntaps & 1); }
+extern "C" int cvk_blur_supported(int ntaps, int step) {
+    if (step == 1) return ntaps >= 3 && ntaps <= 15 && (ntaps & 1);
+    if (step == 2) return ntaps == 3 || ntaps == 7 || ntaps == 11 || ntaps == 15;
+    return 0;
+}
 
 extern "C" int cvk_blur(const cvk_blur_params *bp_in, int cus, void *stream) {
     if (bp_in->tx1 < bp_in->tx0 || bp_in->ty1 < bp_in->ty0) return 0;
-    if (!cvk_blur_supported(bp_in->ntaps)) return (int)hipErrorInvalidValue;
-    if (bp_in->nover < 0 || bp_in->nover > CVK_BLUR_MAX_OVER || (bp_in->nover > 0 && !(bp_in->in_half && bp_in->out_half))) return (int)hipErrorInvalidValue;
     cvk_blur_params bp = *bp_in;
-    const int cols = bp.tx1 - bp.tx0 + 1, rows = bp.ty1 - bp.ty0 + 1;
+    if (bp.step <= 0) bp.step = 1;
+    if (!cvk_blur_supported(bp.ntaps, bp.step)) return (int)hipErrorInvalidValue;
+    if (bp.nover < 0 || bp.nover > CVK_BLUR_MAX_OVER || (bp.nover > 0 && !(bp.in_half && bp.out_half && bp.step == 1))) return (int)hipErrorInvalidValue;
+    const int cols = bp.tx1 - bp.tx0 + 1;
     // strip width: 256 lanes unless the frame is so narrow that 128 wastes fewer lanes
     static int env_w = -1, env_rows = -1;
     if (env_w < 0) { const char *e = getenv("CVS_BLUR_WIDTH"); env_w = e ? atoi(e) : 0; }
     if (env_rows < 0) { const char *e = getenv("CVS_BLUR_ROWS"); env_rows = e ? atoi(e) : 0; }
-    int width = env_w ? env_w : (cols <= 128 ? 128 : 256);
-    if (bp.rows_per_wg <= 0) {
-        // aim at ~4 workgroups per CU; never fewer than 2*(ntaps-1) rows (halo cost <= 50 %) nor more than the frame
-        const int outw = width - (bp.ntaps - 1);
-        const int strips = (cols + outw - 1) / outw;
-        static int per_cu = -1;
-        if (per_cu < 0) { const char *e = getenv("CVS_BLUR_WGS_PER_CU"); per_cu = e ? atoi(e) : 4; }
-        int segs = (per_cu * cus + strips - 1) / strips;
-        if (segs < 1) segs = 1;
-        int r = (rows + segs - 1) / segs;
-        const int lo = 2 * (bp.ntaps - 1);
-        if (r < lo) r = lo;
-        if (r > rows) r = rows;
-        bp.rows_per_wg = env_rows ? env_rows : r;
-    }
-    return width == 128 ? pick<128>(&bp, (hipStream_t)stream) : pick<256>(&bp, (hipStream_t)stream);
+    const int width = env_w ? env_w : (cols <= 128 ? 128 : 256);
+    if (bp.rows_per_wg <= 0 && env_rows > 0) bp.rows_per_wg = env_rows;
+    return width == 128 ? pick<128>(&bp, cus, (hipStream_t)stream) : pick<256>(&bp, cus, (hipStream_t)stream);
 }

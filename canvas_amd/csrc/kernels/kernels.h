@@ -107,8 +107,8 @@ typedef struct {
 size_t cvk_fir2d_lds_bytes(const cvk_fir2d_params *fp);     /* dynamic LDS the launch would need */
 int cvk_fir2d(const cvk_fir2d_params *fp, void *stream);
 
-/* separable blur with one tap list (odd, 3..15 taps, all finite): both passes in one sweep, the vertical
- * window in registers.  Source pixels outside (sx0..sx1, sy0..sy1) count as skipped taps. */
+/* separable FIR with one tap list for every line (odd, 3..15 taps, all finite), optionally decimating by 2:
+ * both passes in one sweep, the vertical window in registers.  Source pixels outside (sx0..sx1, sy0..sy1) count as skipped taps. */
 #define CVK_BLUR_MAX_OVER 4
 typedef struct {
     cvk_view target, source;
@@ -117,12 +117,13 @@ typedef struct {
     int sx0, sy0, sx1, sy1;    /* the source's current window */
     int ntaps;
     int rows_per_wg;           /* 0: let the launcher choose */
+    int step;                  /* target line t reads source lines step*t - ntaps/2 + k; 0 or 1: blur, 2: halving resampler */
     float taps[16];
     int nover;                 /* f16 frames blended over the blur result before the (f16) store; 0..CVK_BLUR_MAX_OVER */
     int pad;
     const void *over[CVK_BLUR_MAX_OVER];       /* rgba_f16 device buffers laid out exactly like `target` */
 } cvk_blur_params;
-int cvk_blur_supported(int ntaps);
+int cvk_blur_supported(int ntaps, int step);
 int cvk_blur(const cvk_blur_params *bp, int cus, void *stream);
 
 /* display / export edge: f16 RGBA -> 4 bytes per pixel through a 65536-entry half->u8 table (device pointer,

@@ -1038,3 +1038,20 @@ def test_dv_device_round_trip_and_untouched_input(cvs, orc):
     finally:
         for p in dev + out:
             cvs.cvs_free(p)
+
+
+@pytest.mark.parametrize("ksize", [1, 2, 3, 4, 5])                       # 5: 19 taps, no register-window instance -> gather kernel
+@pytest.mark.parametrize("geom", [((0, 0, 1099, 39), (0, 0, 1099, 39), (0, 0, 549, 19)),         # three strips wide
+                                  ((-7, -3, 200, 90), (3, 5, 180, 77), (-4, -2, 110, 50)),       # windows with origins, source window inside its buffer
+                                  ((0, 0, 63, 35), (0, 0, 63, 35), (0, 0, 40, 30))])             # target reaches past the source
+def test_lanczos_halving_uniform_taps(cvs, orc, ksize, geom):
+    sfull, scur, tfull = geom
+    rng = np.random.default_rng(62 + ksize)
+    src = rand_f32_frame(rng, sfull, scur, lo=-0.5, hi=1.5)
+    want = HostFrame(tfull, np.float32)
+    orc.lib().orc_resample_lanczos_f32(want.ref(), src.ref(), C.c_float(0.5), C.c_float(0.5), ksize)
+    d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(tfull, np.float32)
+    _lib.check(cvs.cvs_resample_lanczos_f32_dev(d_out.ref(), d_src.ref(), C.c_float(0.5), C.c_float(0.5), ksize, None))
+    got = d_out.download()
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f32(got.array, want.array, "lanczos halving, kernel size %d" % ksize)
