@@ -61,6 +61,51 @@ __device__ __forceinline__ px32x2 grade_pair(u32x4 p, const Mat &mat, const uint
     return o;
 }
 
+// ---- three IEEE quotients by one denominator, for both pixels of a pair --------------------------------------
+// hipcc expands an f32 '/' into v_div_scale x2, v_rcp, 2 FMAs refining the reciprocal, a multiply, 3 FMAs refining
+// the quotient with exact residuals, v_div_fmas, v_div_fixup: 11 instructions per quotient, 66 per blended pair.
+// When neither operand needs the scaling step (the scale instructions return their input, fmas is a plain FMA,
+// fixup passes its input through) the same arithmetic can share the reciprocal among the three channels and run
+// on both pixels at once as v_pk_fma_f32: 2 rcp + 2 + 3 * 5 packed instructions per pair.  The condition is
+// checked per wave (every operand normal with magnitude in [2^-60, 2^60): quotients, products and residuals all
+// stay normal); any zero, denormal, Inf or extreme value sends the wave through the plain '/' instead.
+// Same instructions on the same values => the same bits as '/', which is what the reference's IEEE divide gives.
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+__device__ __forceinline__ bool div_band(f32x2 n0, f32x2 n1, f32x2 n2, f32x2 d) {
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(n0.x), __builtin_fabsf(n0.y)), __builtin_fmaxf(__builtin_fabsf(n1.x), __builtin_fabsf(n1.y))),
+                                     __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(n2.x), __builtin_fabsf(n2.y)), __builtin_fmaxf(__builtin_fabsf(d.x), __builtin_fabsf(d.y))));
+    const float lo = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fabsf(n0.x), __builtin_fabsf(n0.y)), __builtin_fminf(__builtin_fabsf(n1.x), __builtin_fabsf(n1.y))),
+                                     __builtin_fminf(__builtin_fminf(__builtin_fabsf(n2.x), __builtin_fabsf(n2.y)), __builtin_fminf(__builtin_fabsf(d.x), __builtin_fabsf(d.y))));
+    // fmax/fmin drop a NaN operand, so a NaN can slip through: harmless, both forms then give NaN (rcp(NaN), NaN*r
+    // and fma(.., NaN) are NaN; payload and sign of a NaN are not pinned)
+    return lo >= 0x1p-60f && hi < 0x1p60f;
+}
+
+__device__ __forceinline__ void div3_pair(f32x2 &n0, f32x2 &n1, f32x2 &n2, f32x2 d) {
+#ifdef CVS_DIV_ALWAYS_FAST
+    if (true) {
+#else
+    if (!wave_any(!div_band(n0, n1, n2, d))) {          // every active lane is inside the band
+#endif
+        f32x2 r = { __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y) };
+        const f32x2 nd = -d;
+        r = fma2(fma2(nd, r, f32x2{ 1.0f, 1.0f }), r, r);
+        f32x2 *n[3] = { &n0, &n1, &n2 };
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const f32x2 x = *n[c];
+            f32x2 q = x * r;
+            q = fma2(fma2(nd, q, x), r, q);
+            *n[c] = fma2(fma2(nd, q, x), r, q);
+        }
+    } else {
+        n0 = f32x2{ n0.x / d.x, n0.y / d.y };
+        n1 = f32x2{ n1.x / d.x, n1.y / d.y };
+        n2 = f32x2{ n2.x / d.x, n2.y / d.y };
+    }
+}
+
 // video_mix.c:323-337 with mix_b == 1.0f (workspace.c:543)
 __device__ __forceinline__ px32x2 over_pair(px32x2 lo, px32x2 b) {
     const f32x2 alpha_b = b.a;                       // b.a * 1.0f
@@ -72,9 +117,7 @@ __device__ __forceinline__ px32x2 over_pair(px32x2 lo, px32x2 b) {
     o.b = lo.b * alpha_a + b.b * alpha_b;
     o.a = a;
     if (!(a.x == 1.0f && a.y == 1.0f)) {             // x / 1.0f == x: nothing to do for unit alpha
-        o.r = f32x2{ o.r.x / a.x, o.r.y / a.y };
-        o.g = f32x2{ o.g.x / a.x, o.g.y / a.y };
-        o.b = f32x2{ o.b.x / a.x, o.b.y / a.y };
+        div3_pair(o.r, o.g, o.b, a);
         if (a.x == 0.0f) { o.r.x = 0.0f; o.g.x = 0.0f; o.b.x = 0.0f; o.a.x = 0.0f; }
         if (a.y == 0.0f) { o.r.y = 0.0f; o.g.y = 0.0f; o.b.y = 0.0f; o.a.y = 0.0f; }
     }
