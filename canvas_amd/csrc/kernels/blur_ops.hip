@@ -21,7 +21,7 @@
 #include <type_traits>
 #include <utility>
 #include "kernels.h"
-#include "pixel_math.hpp"
+#include "chain_math.hpp"
 
 namespace {
 
@@ -118,6 +118,10 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
     };
     Row cur = fetch_row(ys0, true);
     Row nxt = fetch_row(ys0 + 1, steps > 1);
+    uint2 ov_next[CVK_BLUR_MAX_OVER];
+#pragma unroll
+    for (int l = 0; l < CVK_BLUR_MAX_OVER; l++) ov_next[l] = make_uint2(0u, 0u);
+    // (NT >= 3: the first emitting step is never step 0, so the first request always has a step to travel)
 
     for (int i0 = 0; i0 < steps; i0 += NT) {
         // NT steps with the ring slot as a compile-time constant (a runtime index would send the ring to scratch)
@@ -130,14 +134,16 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
             const int t = ta + (i - (NT - 1)) / STEP;         // the target row this step completes
             // two rows ahead goes out now; this row's data was requested two steps ago
             const Row far = fetch_row(ys + 2, i + 2 < steps);
-            // the upper layers of this step's output pixel: requested before the barrier, used after the sums
+            // the upper layers of the NEXT step's output pixel go out now; this step's were requested a step ago
             uint2 ov[CVK_BLUR_MAX_OVER];
             if constexpr (EPI) {
-                const size_t o = (size_t)(t - bp.target.fy0) * (size_t)bp.target.pitch + (size_t)(tcol - bp.target.fx0);
+                const bool next_emits = i + 1 >= NT - 1 && i + 1 < steps;
+                const size_t o = (size_t)(t + 1 - bp.target.fy0) * (size_t)bp.target.pitch + (size_t)(tcol - bp.target.fx0);
 #pragma unroll
                 for (int l = 0; l < CVK_BLUR_MAX_OVER; l++) {
-                    ov[l] = make_uint2(0u, 0u);
-                    if (l < bp.nover && emits && out_live) ov[l] = reinterpret_cast<const uint2 *>(bp.over[l])[o];
+                    ov[l] = ov_next[l];
+                    ov_next[l] = make_uint2(0u, 0u);
+                    if (l < bp.nover && next_emits && out_live) ov_next[l] = reinterpret_cast<const uint2 *>(bp.over[l])[o];
                 }
             }
             float4 (*buf)[PITCH] = rowbuf[i & 1];
@@ -170,14 +176,14 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
                     oba = oba + p.ba * w[k];
                 }
                 if constexpr (EPI) {
-                    cvs::px32 acc = { org.x, org.y, oba.x, oba.y };
+                    cvs::px1 acc = { org, oba.x, oba.y };
 #pragma unroll
                     for (int l = 0; l < CVK_BLUR_MAX_OVER; l++)
                         if (l < bp.nover) {
-                            const cvs::px32 b = { cvs::h2f(ov[l].x & 0xFFFFu), cvs::h2f(ov[l].x >> 16), cvs::h2f(ov[l].y & 0xFFFFu), cvs::h2f(ov[l].y >> 16) };
-                            acc = cvs::blend_over(acc, b, 1.0f);
+                            const cvs::px1 up = { f32x2{ cvs::h2f(ov[l].x & 0xFFFFu), cvs::h2f(ov[l].x >> 16) }, cvs::h2f(ov[l].y & 0xFFFFu), cvs::h2f(ov[l].y >> 16) };
+                            acc = cvs::over_px(acc, up);
                         }
-                    org = f32x2{ acc.r, acc.g };
+                    org = acc.rg;
                     oba = f32x2{ acc.b, acc.a };
                 }
                 if (out_live) {

@@ -124,6 +124,39 @@ __device__ __forceinline__ px32x2 over_pair(px32x2 lo, px32x2 b) {
     return o;
 }
 
+// The same blend for ONE pixel per lane (the FIR epilogue): (r, g) ride as a packed pair, b and alpha as scalars;
+// the three quotients share one refined reciprocal under the same band rule as div3_pair.
+struct px1 { f32x2 rg; float b, a; };
+
+__device__ __forceinline__ px1 over_px(px1 lo, px1 up) {
+    const float alpha_b = up.a;                      // up.a * 1.0f
+    const float alpha_a = lo.a * (1.0f - up.a);
+    const float a = alpha_a + alpha_b;
+    f32x2 nrg = lo.rg * alpha_a + up.rg * alpha_b;
+    float nb = lo.b * alpha_a + up.b * alpha_b;
+    if (a != 1.0f) {
+        const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(nrg.x), __builtin_fabsf(nrg.y)), __builtin_fmaxf(__builtin_fabsf(nb), __builtin_fabsf(a)));
+        const float lw = __builtin_fminf(__builtin_fminf(__builtin_fabsf(nrg.x), __builtin_fabsf(nrg.y)), __builtin_fminf(__builtin_fabsf(nb), __builtin_fabsf(a)));
+        if (!wave_any(!(lw >= 0x1p-60f && hi < 0x1p60f))) {
+            float r = __builtin_amdgcn_rcpf(a);
+            r = __builtin_fmaf(__builtin_fmaf(-a, r, 1.0f), r, r);
+            const f32x2 nd = { -a, -a }, rr = { r, r };
+            f32x2 q = nrg * rr;
+            q = fma2(fma2(nd, q, nrg), rr, q);
+            nrg = fma2(fma2(nd, q, nrg), rr, q);
+            float qb = nb * r;
+            qb = __builtin_fmaf(__builtin_fmaf(-a, qb, nb), r, qb);
+            nb = __builtin_fmaf(__builtin_fmaf(-a, qb, nb), r, qb);
+        } else {
+            nrg = f32x2{ nrg.x / a, nrg.y / a };
+            nb = nb / a;
+        }
+    }
+    px1 o = { nrg, nb, a };
+    if (a == 0.0f) { o.rg = f32x2{ 0.0f, 0.0f }; o.b = 0.0f; o.a = 0.0f; }
+    return o;
+}
+
 // main.c:43-71: the stack's f32 result, truncated
 __device__ __forceinline__ u32x4 narrow_pair(px32x2 v) {
     const float big = __builtin_fmaxf(

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--ring", type=int, default=4)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--streams", type=int, default=1, help="HIP streams the frames alternate over (tails of one frame overlap the next)")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the frames alternate over (tails of one frame overlap the next)")
     a = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
