@@ -12,3 +12,8 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_fetch -- $B --steps 6 --warmup 2 > gpurun_out/prof_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/prof_write -- $B --steps 6 --warmup 2 > gpurun_out/prof_write.log 2>&1
 find gpurun_out -name "*.csv" | head -40
+# the other configs' kernels, kernel-trace only (per-kernel average durations for DESIGN.md section 4.2)
+rm -rf gpurun_out/prof_stream gpurun_out/prof_configs
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_stream -- python tools/bench_stream.py --frames 300 > gpurun_out/prof_stream.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_configs -- python tools/bench_configs.py --which 3,4 > gpurun_out/prof_configs.log 2>&1
+find gpurun_out/prof_stream gpurun_out/prof_configs -name "*kernel_stats.csv" | head
