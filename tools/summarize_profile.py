@@ -6,11 +6,12 @@ import collections, csv, glob, json, os, shutil, sys
 rnd, tag, desc = sys.argv[1], sys.argv[2], sys.argv[3]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.makedirs(os.path.join(root, "profiles", rnd), exist_ok=True)
-stats = sorted(glob.glob(os.path.join(root, "gpurun_out/prof_trace/*/*_kernel_stats.csv")))[-1]
+newest = lambda pattern: max(glob.glob(os.path.join(root, pattern)), key=os.path.getmtime)   # gpurun merges keep older runs beside the new one
+stats = newest("gpurun_out/prof_trace/*/*_kernel_stats.csv")
 shutil.copy(stats, os.path.join(root, "profiles", rnd, tag + "_kernel_stats.csv"))
 out = {}
 for d in ["prof_pmc1", "prof_pmc2", "prof_fetch", "prof_write"]:
-    f = sorted(glob.glob(os.path.join(root, "gpurun_out", d, "*/*_counter_collection.csv")))[-1]
+    f = newest("gpurun_out/%s/*/*_counter_collection.csv" % d)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "k_chain" in r["Kernel_Name"]:
