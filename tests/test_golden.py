@@ -60,3 +60,39 @@ def test_library_reproduces_golden_chain_and_tables(golden):
     _lib.check(lib.cvs_blur_lanczos_f16_dev(small.ref(), src.ref(), taps.ctypes.data_as(C.POINTER(C.c_float)), 9,
                                             C.c_float(0.5), C.c_float(0.5), 3, None))
     assert_same_f16(small.download().array, golden["config3_96x54"], "config 3")
+
+
+@pytest.mark.gpu
+def test_library_reproduces_golden_graph_and_edges(golden):
+    from canvas_amd import _lib, synth
+    from canvas_amd.abi import HostFrame
+    from canvas_amd.stream import GraphStream
+    lib = _lib.load()
+    assert lib.cvs_init(0) == 0
+    lib.init_half()
+    g = GraphStream(96, 54, ring=1, first_frame=1)
+    out = g.render(0)
+    _lib.check(lib.cvs_stream_sync(None))
+    assert_same_f16(out.download().array, golden["config5_96x54"], "config 5 graph")
+    disp = HostFrame((0, 0, 31, 15), np.uint16, golden["display_in"])
+    for tag, pre, mode in [("rgba8_srgb", _lib.LUT_LINEAR_TO_SRGB, _lib.DISPLAY_RGBA8), ("argb32", _lib.LUT_NONE, _lib.DISPLAY_ARGB32_PREMUL)]:
+        got = np.zeros((16, 32), np.uint32)
+        _lib.check(lib.video_frame_to_bytes(got.ctypes.data, disp.ref(), pre, mode))
+        assert np.array_equal(got, golden["display_" + tag]), tag
+    img = _lib.coded_image()
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_golden
+    planes = make_golden.dv_planes()
+    for p, s in enumerate((720, 180, 180)):
+        img.data[p], img.stride[p], img.line_count[p] = planes[p].ctypes.data, s, 480
+    dv = HostFrame((0, -1, 719, 478), np.uint16)
+    lib.video_reconstruct_dv(dv.ref(), C.byref(img))
+    assert_same_f16(dv.array[101:105], golden["dv_frame_rows_100_103"], "DV reconstruct")
+    back = lib.video_subsample_dv(dv.ref())
+    try:
+        for p, (key, s) in enumerate((("dv_back_y_rows", 720), ("dv_back_cb_rows", 180), ("dv_back_cr_rows", 180))):
+            plane = np.ctypeslib.as_array(C.cast(back.contents.data[p], C.POINTER(C.c_uint8)), shape=(480, s))
+            assert np.array_equal(plane[101:105], golden[key]), key
+    finally:
+        C.CFUNCTYPE(None, C.c_void_p)(back.contents.free_func)(C.cast(back, C.c_void_p))
