@@ -142,6 +142,10 @@ static int run_table(const tap_table *tb, cvk_view target, cvk_view source, int 
     return rc;
 }
 
+/* device-resident, cached form of plan_triangle's table (defined with the table cache below) */
+static int triangle_table_cached(float tmin, float smin, float factor, int s0, int s1, int t0, int t1, bool count_touch,
+                                 cvk_fir_axis *axis, int *used_lo, int *used_hi);
+
 /* one pass of video_scale.c:34-127 (axis 0) or :129-229 (axis 1) on device frames */
 static int triangle_pass(rgba_frame_f32 *target, float tmin, const rgba_frame_f32 *source, float smin, float factor, int axis, hipStream_t s) {
     const box2i srect = source->current_window, trect = target->full_window;
@@ -154,15 +158,26 @@ static int triangle_pass(rgba_frame_f32 *target, float tmin, const rgba_frame_f3
     CVS_KERNEL(cvk_zero_f32(tv, s));
     if (factor == 1.0f && tmin == smin) return cvs_copy_frame_alpha_f32_dev(target, source, 1.0f, s);
 
-    tap_table tb;
-    int rc = plan_triangle(&tb, tmin, smin, factor, s0, s1, t0, t1, axis == 0 || lo <= hi);
-    if (rc != 0) { cvs_set_error("scale: out of memory planning taps"); return rc; }
-    /* the gather reads source lines named in the table; they must be inside the source buffer */
-    rc = run_table(&tb, tv, sv, axis, lo, hi, s);
-    if (axis) box2i_set(&target->current_window, tb.used_lo, lo, tb.used_hi, hi);
-    else      box2i_set(&target->current_window, lo, tb.used_lo, hi, tb.used_hi);
-    table_free(&tb);
-    return rc;
+    /* the per-line taps depend only on the geometry, which repeats from frame to frame: planned once, kept on the
+     * device; steady state is the zero fill and one gather launch, nothing synchronous */
+    cvk_fir_axis table;
+    int used_lo, used_hi;
+    int rc = triangle_table_cached(tmin, smin, factor, s0, s1, t0, t1, axis == 0 || lo <= hi, &table, &used_lo, &used_hi);
+    if (rc != 0) return rc;
+    if (used_hi >= used_lo && hi >= lo) {
+        /* the gather reads source lines named in the table; they lie inside the source window by construction */
+        const size_t first = (size_t)(used_lo - t0);
+        cvk_fir_params fp;
+        memset(&fp, 0, sizeof fp);
+        fp.target = tv; fp.source = sv; fp.axis = axis;
+        fp.t0 = used_lo; fp.t1 = used_hi; fp.lo = lo; fp.hi = hi;
+        fp.ntaps = table.ntaps + first; fp.tap_src = table.src + first * (size_t)table.stride; fp.taps = table.taps + first * (size_t)table.stride;
+        fp.stride = table.stride;
+        CVS_KERNEL(cvk_fir_gather(&fp, s));
+    }
+    if (axis) box2i_set(&target->current_window, used_lo, lo, used_hi, hi);
+    else      box2i_set(&target->current_window, lo, used_lo, hi, used_hi);
+    return 0;
 }
 
 CVS_EXPORT int cvs_scale_bilinear_f32_dev(rgba_frame_f32 *target, v2f tp, const rgba_frame_f32 *source, v2f sp, v2f fac, cvs_stream_t stream) {
@@ -186,13 +201,12 @@ CVS_EXPORT int cvs_scale_bilinear_f32_dev(rgba_frame_f32 *target, v2f tp, const 
     box2i_intersect(&mid.full_window, &mid.full_window, tf);
     mid.current_window = mid.full_window;
     size_t n = cvs_box_pixels(&mid.full_window);
-    mid.data = cvs_malloc(sizeof(rgba_f32) * (n ? n : 1));
+    mid.data = cvs_pool_malloc(sizeof(rgba_f32) * (n ? n : 1), s);
     if (!mid.data) { box2i_set_empty(&target->current_window); return -1; }
     int rc;
     if (x_first) { rc = triangle_pass(&mid, tp.x, source, sp.x, fac.x, 1, s); if (rc == 0) rc = triangle_pass(target, tp.y, &mid, sp.y, fac.y, 0, s); }
     else         { rc = triangle_pass(&mid, tp.y, source, sp.y, fac.y, 0, s); if (rc == 0) rc = triangle_pass(target, tp.x, &mid, sp.x, fac.x, 1, s); }
-    if (rc == 0) rc = cvs_stream_sync(s);
-    cvs_free(mid.data);
+    cvs_pool_free(mid.data, s);
     if (rc != 0) box2i_set_empty(&target->current_window);
     return rc;
 }
@@ -324,10 +338,10 @@ static int lanczos_two_pass(rgba_frame_f32 *target, const rgba_frame_f32 *source
 #include <pthread.h>
 
 typedef struct {
-    int kind;                 /* 1 = blur taps, 2 = lanczos */
-    uint32_t fbits;           /* lanczos: factor bits */
-    int ksize;                /* lanczos: kernel size; blur: tap count */
-    uint64_t taps_hash;       /* blur: FNV-1a of the tap values */
+    int kind;                 /* 1 = blur taps, 2 = lanczos, 3 = triangle resample */
+    uint32_t fbits;           /* lanczos, triangle: factor bits */
+    int ksize;                /* lanczos: kernel size; blur: tap count; triangle: count_touch */
+    uint64_t taps_hash;       /* blur: FNV-1a of the tap values; triangle: tmin bits << 32 | smin bits */
     int t0, t1, s0, s1;
     int tile;                 /* tile edge along this axis */
 } axis_key;
@@ -339,7 +353,10 @@ typedef struct {
     char *dev;                /* one block: ntaps | src | taps | foot */
     cvk_fir_axis axis;
     int max_foot;
+    int used_lo, used_hi;     /* target lines that receive at least one tap (the window the pass reports) */
 } axis_entry;
+
+typedef struct { const float *taps; float factor, tmin, smin; } axis_plan;    /* what the planner of the key's kind needs */
 
 #define AXIS_CACHE 16
 static axis_entry g_axis[AXIS_CACHE];
@@ -406,14 +423,15 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     return 0;
 }
 
-/* cached table for one axis; `taps` only for kind 1 */
-static int axis_get(const axis_key *key, const float *taps, float factor, cvk_fir_axis *out, int *max_foot) {
+/* cached table for one axis */
+static int axis_get_ex(const axis_key *key, const axis_plan *pl, cvk_fir_axis *out, int *max_foot, int *used_lo, int *used_hi) {
     pthread_mutex_lock(&g_axis_lock);
     int victim = 0;
     for (int i = 0; i < AXIS_CACHE; i++) {
         if (g_axis[i].valid && memcmp(&g_axis[i].key, key, sizeof *key) == 0) {
             g_axis[i].stamp = ++g_axis_clock;
             *out = g_axis[i].axis; *max_foot = g_axis[i].max_foot;
+            if (used_lo) { *used_lo = g_axis[i].used_lo; *used_hi = g_axis[i].used_hi; }
             pthread_mutex_unlock(&g_axis_lock);
             return 0;
         }
@@ -421,20 +439,38 @@ static int axis_get(const axis_key *key, const float *taps, float factor, cvk_fi
         else if (g_axis[victim].valid && g_axis[i].stamp < g_axis[victim].stamp) victim = i;
     }
     tap_table tb;
-    int rc = key->kind == 1 ? plan_blur(&tb, key->t0, key->t1, key->s0, key->s1, taps, key->ksize)
-                            : plan_lanczos(&tb, key->t0, key->t1, key->s0, key->s1, factor, key->ksize);
+    int rc = key->kind == 1 ? plan_blur(&tb, key->t0, key->t1, key->s0, key->s1, pl->taps, key->ksize)
+           : key->kind == 2 ? plan_lanczos(&tb, key->t0, key->t1, key->s0, key->s1, pl->factor, key->ksize)
+                            : plan_triangle(&tb, pl->tmin, pl->smin, pl->factor, key->s0, key->s1, key->t0, key->t1, key->ksize != 0);
     axis_entry fresh;
     memset(&fresh, 0, sizeof fresh);
-    if (rc == 0) { rc = axis_upload(&tb, key->tile, &fresh); table_free(&tb); }
+    if (rc == 0) { fresh.used_lo = tb.used_lo; fresh.used_hi = tb.used_hi; rc = axis_upload(&tb, key->tile, &fresh); table_free(&tb); }
+    else cvs_set_error("FIR planning: out of memory");
     if (rc == 0) {
         axis_entry *e = &g_axis[victim];
         if (e->valid && e->dev) { hipDeviceSynchronize(); hipFree(e->dev); }     /* eviction is rare; nothing may still read it */
         fresh.key = *key; fresh.valid = 1; fresh.stamp = ++g_axis_clock;
         *e = fresh;
         *out = e->axis; *max_foot = e->max_foot;
+        if (used_lo) { *used_lo = e->used_lo; *used_hi = e->used_hi; }
     }
     pthread_mutex_unlock(&g_axis_lock);
     return rc;
+}
+
+static int axis_get(const axis_key *key, const float *taps, float factor, cvk_fir_axis *out, int *max_foot) {
+    const axis_plan pl = { taps, factor, 0.0f, 0.0f };
+    return axis_get_ex(key, &pl, out, max_foot, NULL, NULL);
+}
+
+static int triangle_table_cached(float tmin, float smin, float factor, int s0, int s1, int t0, int t1, bool count_touch,
+                                 cvk_fir_axis *axis, int *used_lo, int *used_hi) {
+    uint32_t fb, tb, sb;
+    memcpy(&fb, &factor, 4); memcpy(&tb, &tmin, 4); memcpy(&sb, &smin, 4);
+    const axis_key key = make_key(3, fb, count_touch ? 1 : 0, ((uint64_t)tb << 32) | sb, t0, t1, s0, s1, CVK_FIR2D_TILE_X);
+    const axis_plan pl = { NULL, factor, tmin, smin };
+    int foot;
+    return axis_get_ex(&key, &pl, axis, &foot, used_lo, used_hi);
 }
 
 /* 0 = launched, 1 = does not fit an LDS tile (caller falls back), <0 = error */
