@@ -90,11 +90,10 @@ static int chain_unfused(const cvs_chain_job *j, const float m[9], int pre_lut, 
     rgba_frame_f32 acc = { NULL, *fw, *fw }, tmp = { NULL, *fw, *fw };
     int rc = 0;
     if (!n) { box2i_set_empty(&j->out->current_window); return 0; }
-    CVS_HIP(hipMalloc((void **)&graded.data, n * sizeof(rgba_f16)));
-    if (hipMalloc((void **)&acc.data, n * sizeof(rgba_f32)) != hipSuccess || hipMalloc((void **)&tmp.data, n * sizeof(rgba_f32)) != hipSuccess) {
-        cvs_set_error("chain: out of device memory for f32 intermediates");
-        rc = -1;
-    }
+    graded.data = cvs_pool_malloc(n * sizeof(rgba_f16), s);
+    acc.data = cvs_pool_malloc(n * sizeof(rgba_f32), s);
+    tmp.data = cvs_pool_malloc(n * sizeof(rgba_f32), s);
+    if (!graded.data || !acc.data || !tmp.data) rc = -1;
     bool have_acc = false;
     for (int k = 0; rc == 0 && k < j->nlayers; k++) {
         /* the layer source: a graded copy of the input, clipped like video_copy_frame_f16 */
@@ -110,8 +109,7 @@ static int chain_unfused(const cvs_chain_job *j, const float m[9], int pre_lut, 
         }
     }
     if (rc == 0) rc = cvs_frame_f32_to_f16_dev(j->out, &acc, s);       /* main.c:43-71 */
-    if (rc == 0) rc = (int)hipStreamSynchronize(s);                    /* scratch is freed below */
-    hipFree(graded.data); hipFree(acc.data); hipFree(tmp.data);
+    cvs_pool_free(graded.data, s); cvs_pool_free(acc.data, s); cvs_pool_free(tmp.data, s);     /* stream-ordered: no wait */
     if (rc != 0) box2i_set_empty(&j->out->current_window);
     return rc;
 }

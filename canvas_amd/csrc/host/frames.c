@@ -131,32 +131,13 @@ CVS_EXPORT int cvs_gain_offset_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16
     return 0;
 }
 
-/* one colour -> one truncated rgba_f16, through the same GPU conversion as everything else
- * (SolidColorVideoSource.c:68-69 calls rgba_f32_to_f16 once per frame) */
-static int solid_bits(const rgba_f32 *color, uint64_t *bits, hipStream_t s) {
-    float *d32 = NULL;
-    uint16_t *d16 = NULL;
-    uint16_t h[4];
-    CVS_HIP(hipMalloc((void **)&d32, 64));
-    d16 = (uint16_t *)((char *)d32 + 32);
-    hipError_t e = hipMemcpyAsync(d32, color, 16, hipMemcpyHostToDevice, s);
-    int rc = e == hipSuccess ? cvk_float_to_half(d16, d32, 4, 0, s) : (int)e;
-    if (rc == 0) rc = (int)hipMemcpyAsync(h, d16, 8, hipMemcpyDeviceToHost, s);
-    if (rc == 0) rc = (int)hipStreamSynchronize(s);
-    hipFree(d32);
-    if (rc != 0) { cvs_set_error("solid colour conversion failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
-    *bits = (uint64_t)h[0] | ((uint64_t)h[1] << 16) | ((uint64_t)h[2] << 32) | ((uint64_t)h[3] << 48);
-    return 0;
-}
-
 CVS_EXPORT int cvs_fill_solid_f16_dev(rgba_frame_f16 *frame, const box2i *window, const rgba_f32 *color, cvs_stream_t s) {
     if (cvs_enter() != 0) { box2i_set_empty(&frame->current_window); return -1; }
     box2i_intersect(&frame->current_window, window, &frame->full_window);
     if (box2i_is_empty(&frame->current_window)) return 0;
-    uint64_t bits;
-    int rc = solid_bits(color, &bits, cvs_pick_stream(s));
-    if (rc != 0) { box2i_set_empty(&frame->current_window); return rc; }
-    CVS_KERNEL(cvk_fill_f16(cvs_view(frame->data, &frame->full_window), cvs_rect(&frame->current_window), bits, cvs_pick_stream(s)));
+    /* the colour is truncated to half inside the kernel (SolidColorVideoSource.c:68-69: once per frame, same rounding) */
+    const float c[4] = { color->r, color->g, color->b, color->a };
+    CVS_KERNEL(cvk_fill_f16(cvs_view(frame->data, &frame->full_window), cvs_rect(&frame->current_window), c, cvs_pick_stream(s)));
     return 0;
 }
 
@@ -321,12 +302,12 @@ CVS_EXPORT void video_get_frame_f16(video_source *source, int frame_index, rgba_
         /* device-only source: render into HBM, bring it back */
         if (cvs_enter() != 0) { box2i_set_empty(&frame->current_window); return; }
         size_t bytes = F16_BYTES(frame);
-        rgba_frame_dev d = { cvs_malloc(bytes), CVS_FORMAT_F16, frame->full_window, frame->full_window, NULL };
+        rgba_frame_dev d = { cvs_pool_malloc(bytes, NULL), CVS_FORMAT_F16, frame->full_window, frame->full_window, NULL };
         if (!d.data) { box2i_set_empty(&frame->current_window); return; }
         source->funcs->get_frame_dev(source->obj, frame_index, &d);
         if (!box2i_is_empty(&d.current_window) && cvs_memcpy_d2h(frame->data, d.data, bytes, NULL) != 0) box2i_set_empty(&d.current_window);
         frame->current_window = d.current_window;
-        cvs_free(d.data);
+        cvs_pool_free(d.data, NULL);
         return;
     }
     box2i_set_empty(&frame->current_window);                            /* the GL branch (main.c:73-75) is gone */
@@ -367,12 +348,12 @@ CVS_EXPORT void video_get_frame_f32(video_source *source, int frame_index, rgba_
     if ((source->funcs->flags & VIDEO_SOURCE_FLAG_DEVICE) && source->funcs->get_frame_dev) {
         if (cvs_enter() != 0) { box2i_set_empty(&frame->current_window); return; }
         size_t bytes = F32_BYTES(frame);
-        rgba_frame_dev d = { cvs_malloc(bytes), CVS_FORMAT_F32, frame->full_window, frame->full_window, NULL };
+        rgba_frame_dev d = { cvs_pool_malloc(bytes, NULL), CVS_FORMAT_F32, frame->full_window, frame->full_window, NULL };
         if (!d.data) { box2i_set_empty(&frame->current_window); return; }
         source->funcs->get_frame_dev(source->obj, frame_index, &d);
         if (!box2i_is_empty(&d.current_window) && cvs_memcpy_d2h(frame->data, d.data, bytes, NULL) != 0) box2i_set_empty(&d.current_window);
         frame->current_window = d.current_window;
-        cvs_free(d.data);
+        cvs_pool_free(d.data, NULL);
         return;
     }
     box2i_set_empty(&frame->current_window);

@@ -196,12 +196,12 @@ static void workspace_get_frame_dev(workspace_t *w, int frame_index, rgba_frame_
     rgba_frame_dev acc = { NULL, CVS_FORMAT_F32, frame->full_window, frame->full_window, frame->stream };
     rgba_frame_dev tmp = acc;
     bool own_acc = frame->format != CVS_FORMAT_F32;
-    acc.data = own_acc ? cvs_malloc(px * sizeof(rgba_f32)) : frame->data;
+    acc.data = own_acc ? cvs_pool_malloc(px * sizeof(rgba_f32), frame->stream) : frame->data;
     if (!acc.data) rc = -1;
 
     if (rc == 0) video_get_frame_dev((video_source *)live[0].source, live[0].frame, &acc);
     if (rc == 0 && n > 1) {
-        tmp.data = cvs_malloc(px * sizeof(rgba_f32));
+        tmp.data = cvs_pool_malloc(px * sizeof(rgba_f32), frame->stream);
         if (!tmp.data) rc = -1;
         for (int i = 1; rc == 0 && i < n; i++) {
             box2i_set_empty(&tmp.current_window);
@@ -219,9 +219,9 @@ static void workspace_get_frame_dev(workspace_t *w, int frame_index, rgba_frame_
         rc = cvs_frame_f32_to_f16_dev(&fo, &fa, frame->stream);
         acc.current_window = fo.current_window;
     }
-    if (rc == 0 && (own_acc || tmp.data)) rc = cvs_stream_sync(frame->stream);   /* temps are released below */
-    if (tmp.data) cvs_free(tmp.data);
-    if (own_acc && acc.data) cvs_free(acc.data);
+    /* scratch goes back to the stream-ordered pool: nothing waits here */
+    if (tmp.data) cvs_pool_free(tmp.data, frame->stream);
+    if (own_acc && acc.data) cvs_pool_free(acc.data, frame->stream);
     if (rc == 0) frame->current_window = acc.current_window;
     else box2i_set_empty(&frame->current_window);
     free(live);

@@ -120,9 +120,11 @@ __global__ __launch_bounds__(kBlock) void k_narrow(cvk_view out, cvk_view in, cv
     *at<uint2>(out, x, y) = narrow({ v.x, v.y, v.z, v.w });
 }
 
-__global__ __launch_bounds__(kBlock) void k_fill16(cvk_view out, cvk_rect r, uint2 bits) {
+// the colour arrives as four floats and is truncated here (SolidColorVideoSource.c:68-69 converts once per frame
+// with rgba_f32_to_f16: same truncation, no round trip to the host for the bits)
+__global__ __launch_bounds__(kBlock) void k_fill16(cvk_view out, cvk_rect r, float4 c) {
     CVK_PIXEL_XY(r)
-    *at<uint2>(out, x, y) = bits;
+    *at<uint2>(out, x, y) = make_uint2(cvs::f2h_rz2(c.x, c.y), cvs::f2h_rz2(c.z, c.w));
 }
 
 __global__ __launch_bounds__(kBlock) void k_fill32(cvk_view out, cvk_rect r, float4 c) {
@@ -204,9 +206,9 @@ extern "C" int cvk_narrow(cvk_view out16, cvk_view in32, cvk_rect r, void *strea
     LAUNCH(k_narrow, rect_grid(r), out16, in32, r)
 }
 
-extern "C" int cvk_fill_f16(cvk_view out, cvk_rect r, uint64_t pixel_bits, void *stream) {
+extern "C" int cvk_fill_f16(cvk_view out, cvk_rect r, const float c[4], void *stream) {
     if (rect_empty(r)) return 0;
-    LAUNCH(k_fill16, rect_grid(r), out, r, make_uint2((uint32_t)pixel_bits, (uint32_t)(pixel_bits >> 32)))
+    LAUNCH(k_fill16, rect_grid(r), out, r, make_float4(c[0], c[1], c[2], c[3]))
 }
 
 extern "C" int cvk_fill_f32(cvk_view out, cvk_rect r, const float c[4], void *stream) {

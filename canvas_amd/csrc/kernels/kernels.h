@@ -33,7 +33,7 @@ int cvk_copy_f16(cvk_view out, cvk_view in, cvk_rect r, void *stream);
 int cvk_copy_alpha_f32(cvk_view out, cvk_view in, cvk_rect r, float alpha, void *stream);
 int cvk_widen(cvk_view out32, cvk_view in16, cvk_rect r, void *stream);
 int cvk_narrow(cvk_view out16, cvk_view in32, cvk_rect r, void *stream);
-int cvk_fill_f16(cvk_view out, cvk_rect r, uint64_t pixel_bits, void *stream);
+int cvk_fill_f16(cvk_view out, cvk_rect r, const float rgba[4], void *stream);      /* truncates to half in the kernel */
 int cvk_fill_f32(cvk_view out, cvk_rect r, const float rgba[4], void *stream);
 int cvk_gain_offset_f16(cvk_view out, cvk_view in, cvk_rect r, float gain, float offset, void *stream);
 
