@@ -268,6 +268,19 @@ CVS_EXPORT void video_fill_solid_f32(rgba_frame_f32 *frame, const box2i *window,
 CVS_EXPORT void video_get_frame_f16(video_source *source, int frame_index, rgba_frame_f16 *frame) {
     if (!source || !source->funcs) { box2i_set_empty(&frame->current_window); return; }
     if (source->funcs->get_frame) { source->funcs->get_frame(source->obj, frame_index, frame); return; }
+    if ((source->funcs->flags & VIDEO_SOURCE_FLAG_DEVICE) && source->funcs->get_frame_dev) {
+        /* a source with a device slot and no f16 host slot: render in HBM as f16 (the node narrows there, the same
+         * truncation main.c:43-71 would apply to its f32 output) and bring back 8 B per pixel once */
+        if (cvs_enter() != 0) { box2i_set_empty(&frame->current_window); return; }
+        size_t bytes = F16_BYTES(frame);
+        rgba_frame_dev d = { cvs_pool_malloc(bytes, NULL), CVS_FORMAT_F16, frame->full_window, frame->full_window, NULL };
+        if (!d.data) { box2i_set_empty(&frame->current_window); return; }
+        source->funcs->get_frame_dev(source->obj, frame_index, &d);
+        if (!box2i_is_empty(&d.current_window) && cvs_memcpy_d2h(frame->data, d.data, bytes, NULL) != 0) box2i_set_empty(&d.current_window);
+        frame->current_window = d.current_window;
+        cvs_pool_free(d.data, NULL);
+        return;
+    }
     if (source->funcs->get_frame_32) {
         /* main.c:43-71: pull f32 into a temp covering the same full window, narrow current_window */
         rgba_frame_f32 tmp;
@@ -298,11 +311,16 @@ CVS_EXPORT void video_get_frame_f16(video_source *source, int frame_index, rgba_
         free(tmp.data);
         return;
     }
+    box2i_set_empty(&frame->current_window);                            /* the GL branch (main.c:73-75) is gone */
+}
+
+CVS_EXPORT void video_get_frame_f32(video_source *source, int frame_index, rgba_frame_f32 *frame) {
+    if (!source || !source->funcs) { box2i_set_empty(&frame->current_window); return; }
+    if (source->funcs->get_frame_32) { source->funcs->get_frame_32(source->obj, frame_index, frame); return; }
     if ((source->funcs->flags & VIDEO_SOURCE_FLAG_DEVICE) && source->funcs->get_frame_dev) {
-        /* device-only source: render into HBM, bring it back */
         if (cvs_enter() != 0) { box2i_set_empty(&frame->current_window); return; }
-        size_t bytes = F16_BYTES(frame);
-        rgba_frame_dev d = { cvs_pool_malloc(bytes, NULL), CVS_FORMAT_F16, frame->full_window, frame->full_window, NULL };
+        size_t bytes = F32_BYTES(frame);
+        rgba_frame_dev d = { cvs_pool_malloc(bytes, NULL), CVS_FORMAT_F32, frame->full_window, frame->full_window, NULL };
         if (!d.data) { box2i_set_empty(&frame->current_window); return; }
         source->funcs->get_frame_dev(source->obj, frame_index, &d);
         if (!box2i_is_empty(&d.current_window) && cvs_memcpy_d2h(frame->data, d.data, bytes, NULL) != 0) box2i_set_empty(&d.current_window);
@@ -310,12 +328,6 @@ CVS_EXPORT void video_get_frame_f16(video_source *source, int frame_index, rgba_
         cvs_pool_free(d.data, NULL);
         return;
     }
-    box2i_set_empty(&frame->current_window);                            /* the GL branch (main.c:73-75) is gone */
-}
-
-CVS_EXPORT void video_get_frame_f32(video_source *source, int frame_index, rgba_frame_f32 *frame) {
-    if (!source || !source->funcs) { box2i_set_empty(&frame->current_window); return; }
-    if (source->funcs->get_frame_32) { source->funcs->get_frame_32(source->obj, frame_index, frame); return; }
     if (source->funcs->get_frame) {
         rgba_frame_f16 tmp;                                             /* main.c:115-139 */
         size_t n = cvs_box_pixels(&frame->full_window);
@@ -343,17 +355,6 @@ CVS_EXPORT void video_get_frame_f32(video_source *source, int frame_index, rgba_
         }
         frame->current_window = tmp.current_window;
         free(tmp.data);
-        return;
-    }
-    if ((source->funcs->flags & VIDEO_SOURCE_FLAG_DEVICE) && source->funcs->get_frame_dev) {
-        if (cvs_enter() != 0) { box2i_set_empty(&frame->current_window); return; }
-        size_t bytes = F32_BYTES(frame);
-        rgba_frame_dev d = { cvs_pool_malloc(bytes, NULL), CVS_FORMAT_F32, frame->full_window, frame->full_window, NULL };
-        if (!d.data) { box2i_set_empty(&frame->current_window); return; }
-        source->funcs->get_frame_dev(source->obj, frame_index, &d);
-        if (!box2i_is_empty(&d.current_window) && cvs_memcpy_d2h(frame->data, d.data, bytes, NULL) != 0) box2i_set_empty(&d.current_window);
-        frame->current_window = d.current_window;
-        cvs_pool_free(d.data, NULL);
         return;
     }
     box2i_set_empty(&frame->current_window);

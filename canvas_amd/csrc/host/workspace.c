@@ -192,6 +192,39 @@ static void workspace_get_frame_dev(workspace_t *w, int frame_index, rgba_frame_
     const size_t px = cvs_box_pixels(&frame->full_window);
     int rc = 0;
 
+    /* Fast path.  A source that fills only the f16 slot is half-native: an f32 pull of it is "pull f16, widen"
+     * (main.c:105-144).  When every live item is such a source and the caller wants f16, the layers are pulled as
+     * f16 device frames and the whole stack -- widen, over at mix 1.0 per layer, truncate -- is one launch of the
+     * chain kernel without a colour stage (8 B per layer pixel + 8 B written instead of f32 frames through HBM);
+     * the chain entry itself goes node by node when a layer's window is not the whole frame. */
+    bool all_half = frame->format == CVS_FORMAT_F16 && n <= CVS_CHAIN_MAX_LAYERS && px > 0;
+    for (int i = 0; all_half && i < n; i++) {
+        const video_source *src = live[i].source;
+        all_half = src && src->funcs && src->funcs->get_frame && !src->funcs->get_frame_32;
+    }
+    if (all_half) {
+        rgba_frame_f16 layers[CVS_CHAIN_MAX_LAYERS];
+        rgba_frame_f16 out = { frame->data, frame->full_window, frame->full_window };
+        cvs_chain_job job;
+        memset(&job, 0, sizeof job);
+        memset(layers, 0, sizeof layers);
+        job.out = &out;
+        job.nlayers = n;
+        for (int i = 0; rc == 0 && i < n; i++) {
+            rgba_frame_dev d = { cvs_pool_malloc(px * sizeof(rgba_f16), frame->stream), CVS_FORMAT_F16, frame->full_window, frame->full_window, frame->stream };
+            if (!d.data) { rc = -1; break; }
+            video_get_frame_dev((video_source *)live[i].source, live[i].frame, &d);
+            layers[i].data = d.data; layers[i].full_window = d.full_window; layers[i].current_window = d.current_window;
+            job.layers[i] = &layers[i];
+        }
+        if (rc == 0) rc = cvs_chain_color_over_f16_dev(&job, 1, NULL, CVS_LUT_NONE, CVS_LUT_NONE, frame->stream);
+        for (int i = 0; i < n; i++) cvs_pool_free(layers[i].data, frame->stream);
+        if (rc == 0) frame->current_window = out.current_window;
+        else box2i_set_empty(&frame->current_window);
+        free(live);
+        return;
+    }
+
     /* the stack is computed in f32 whatever the caller's format is (workspace.c:530-544) */
     rgba_frame_dev acc = { NULL, CVS_FORMAT_F32, frame->full_window, frame->full_window, frame->stream };
     rgba_frame_dev tmp = acc;

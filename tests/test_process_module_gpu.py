@@ -345,3 +345,34 @@ def test_dv_nodes_against_oracle(process, bt, orc):
         assert np.array_equal(got, theirs.array[y + 3, x + 4]), (x, y)
     # inside the solid's window the round trip lands near the colour it started from
     almost(frame.pixel(300, 200), (0.2, 0.45, 0.7, 1.0), 1)
+
+
+@pytest.mark.parametrize("nlayers", [1, 3, 5])
+def test_workspace_of_half_native_clips_takes_the_fused_stack(process, bt, orc, nlayers):
+    """Half-native items (here gain/offset nodes over solids: f16 slot only) pulled as f16: the workspace hands the
+    stack to the chain kernel; results equal the oracle's widen -> over -> truncate, every pixel."""
+    from canvas_amd import _lib
+    from canvas_amd.abi import HostFrame
+    full = (0, 0, 95, 53)
+    colours = [(0.2, 0.4, 0.6, 1.0), (0.9, 0.1, 0.3, 0.5), (0.3, 0.8, 0.1, 0.25), (0.05, 0.5, 0.95, 0.75), (0.6, 0.6, 0.1, 0.1)]
+    ws = process.VideoWorkspace()
+    layers = []
+    for z in range(nlayers):
+        clip = process.VideoGainOffsetFilter(process.SolidColorVideoSource(colours[z]), gain=1.25, offset=0.03125)
+        ws.add(source=clip, x=0, length=4, z=z, offset=0)
+        # what the clip produces: truncate(colour) -> widen -> c * gain + offset (two rounded f32 ops) -> truncate
+        c = orc.half_to_float(orc.float_to_half(np.array(colours[z], np.float32)))
+        v = np.array([np.float32(np.float32(c[k] * np.float32(1.25)) + np.float32(0.03125)) for k in range(3)] + [c[3]], np.float32)
+        layers.append(HostFrame(full, np.uint16, np.broadcast_to(orc.float_to_half(v), (54, 96, 4)).copy()))
+    got = ws.get_frame_f16(1, bt.box2i(*full))
+    assert _lib.load().cvs_chain_last_was_fused() == 1
+    want = orc.chain_color_over(layers, None)
+    assert got.current_window == bt.box2i(*full)
+    for y in (0, 17, 53):
+        for x in (0, 40, 95):
+            assert np.array_equal(orc.float_to_half(np.array(got.pixel(x, y), np.float32)), want.array[y, x]), (x, y)
+    # a windowed item sends the same call node by node, with the reference's window behaviour
+    ws.add(source=process.VideoGainOffsetFilter(process.SolidColorVideoSource((1, 1, 1, 0.5), bt.box2i(10, 10, 30, 30))), x=0, length=4, z=99, offset=0)
+    got2 = ws.get_frame_f16(1, bt.box2i(*full))
+    assert _lib.load().cvs_chain_last_was_fused() == 0 and got2.current_window == bt.box2i(*full)
+    assert got2.pixel(5, 5) == got.pixel(5, 5) and got2.pixel(20, 20) != got.pixel(20, 20)
