@@ -115,7 +115,18 @@ __device__ __forceinline__ void wait_vm(u32x4 (&r)[P][L]) {
 __device__ __forceinline__ void stage_lut_any(uint16_t *lds, const uint16_t *__restrict__ table) {
     const uint4 *src = reinterpret_cast<const uint4 *>(table);
     uint4 *dst = reinterpret_cast<uint4 *>(lds);
-    for (int i = threadIdx.x; i < kLutHalfs * 2 / 16; i += blockDim.x) dst[i] = src[i];
+    constexpr int kWords = kLutHalfs * 2 / 16;           // 8192 16-byte words
+    if (kWords % blockDim.x == 0) {
+        // every workgroup reads the same 128 KiB at the same moment: start each one at a different slice so that
+        // the requests of the 32 workgroups behind one L2 spread over its channels instead of queueing on a few
+        const int slices = kWords / (int)blockDim.x, rot = (int)(blockIdx.x >> 3);
+        for (int it = 0; it < slices; it++) {
+            const int i = ((it + rot) % slices) * (int)blockDim.x + (int)threadIdx.x;
+            dst[i] = src[i];
+        }
+    } else {
+        for (int i = threadIdx.x; i < kWords; i += blockDim.x) dst[i] = src[i];
+    }
     __syncthreads();
 }
 
