@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU (one kernel launch; 32 = the most job records one launch carries)")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU (one kernel launch; 64 = the most job records one launch carries)")
     ap.add_argument("--ring", type=int, default=8, help="distinct frame sets resident per GPU")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)

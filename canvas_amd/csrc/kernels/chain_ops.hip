@@ -28,8 +28,14 @@ using namespace cvs;
 
 namespace {
 
-constexpr int kJobsPerLaunch = 32;
-struct Batch { cvk_chain_job jobs[kJobsPerLaunch]; };
+// Job records travel as kernel arguments (<= 4 KiB per launch).  The production kernel takes up to four layers, so
+// its records are compact (48 B) and a launch carries 64 frames: a launch costs ~24 us beyond its per-frame time
+// (table staging, ramp, drain), which is worth amortising.  The first version keeps the full 8-layer record.
+constexpr int kJobsPerLaunchV0 = 32, kJobsPerLaunch = 64, kFusedLayers = 4;
+struct BatchV0 { cvk_chain_job jobs[kJobsPerLaunchV0]; };
+struct JobC { void *out; const void *layer[kFusedLayers]; uint64_t npixels; };
+struct Batch { JobC jobs[kJobsPerLaunch]; };
+static_assert(sizeof(Batch) + 128 <= 4096, "kernel arguments must fit the 4 KiB segment");
 
 // ---------------------------------------------------------------- v0: first correct version (kept for A/B)
 
@@ -43,7 +49,7 @@ __device__ __forceinline__ uint2 chain_pixel(const uint2 (&px)[MAXL], int nl, co
 }
 
 template <int NL, bool PRE, bool POST>
-__global__ __launch_bounds__(kWG) void k_chain_v0(Batch batch, int njobs, Mat mat,
+__global__ __launch_bounds__(kWG) void k_chain_v0(BatchV0 batch, int njobs, Mat mat,
                                                   const uint16_t *__restrict__ pre, const uint16_t *__restrict__ post) {
     __shared__ uint16_t lut[(PRE || POST) ? kLutHalfs : 1];
     if (PRE) stage_lut(lut, pre);
@@ -146,7 +152,7 @@ __global__ __launch_bounds__(kWG) void k_chain(Batch batch, int njobs, Mat mat,
     u32x4 diag_acc = { 0, 0, 0, 0 };
     {
         // the first trip of the first frame goes out before the table is staged
-        const cvk_chain_job &job = batch.jobs[0];
+        const JobC &job = batch.jobs[0];
         const size_t last = job.npixels / 2 - 1;
         const size_t idx = lane < last ? lane : last;
 #pragma unroll
@@ -157,10 +163,10 @@ __global__ __launch_bounds__(kWG) void k_chain(Batch batch, int njobs, Mat mat,
     wait_vm<0>(A);
 
     for (int j = 0; j < njobs; j++) {
-        const cvk_chain_job &job = batch.jobs[j];
+        const JobC &job = batch.jobs[j];
         const size_t npairs = job.npixels / 2;
         const bool more_jobs = j + 1 < njobs;
-        const cvk_chain_job &njob = batch.jobs[more_jobs ? j + 1 : j];
+        const JobC &njob = batch.jobs[more_jobs ? j + 1 : j];
         const size_t nnpairs = njob.npixels / 2;
         // frame base pointers as wave-uniform values (scalar loads): the per-lane choice in the prefetch
         // is then a register select, not a vector load of the job record
@@ -238,7 +244,7 @@ int launch(const Batch &jobs, int njobs, const Mat &mat, const uint16_t *pre, co
 }
 
 template <int NL>
-int launch_v0(const Batch &jobs, int njobs, const Mat &mat, const uint16_t *pre, const uint16_t *post, unsigned grid, hipStream_t s) {
+int launch_v0(const BatchV0 &jobs, int njobs, const Mat &mat, const uint16_t *pre, const uint16_t *post, unsigned grid, hipStream_t s) {
     if (pre && post)  hipLaunchKernelGGL((k_chain_v0<NL, true, true>), dim3(grid), dim3(kWG), 0, s, jobs, njobs, mat, pre, post);
     else if (pre)     hipLaunchKernelGGL((k_chain_v0<NL, true, false>), dim3(grid), dim3(kWG), 0, s, jobs, njobs, mat, pre, post);
     else if (post)    hipLaunchKernelGGL((k_chain_v0<NL, false, true>), dim3(grid), dim3(kWG), 0, s, jobs, njobs, mat, pre, post);
@@ -262,25 +268,43 @@ extern "C" int cvk_chain_color_over(const cvk_chain_job *jobs, int njobs, int un
     const char *bl = getenv("CVS_CHAIN_BLOCK");
     unsigned block = bl ? (unsigned)atoi(bl) : 512u;
     if (block < 64 || block > (unsigned)kWG || (block & 63u)) block = 512u;
-    for (int first = 0; first < njobs; first += kJobsPerLaunch) {
-        const int n = njobs - first < kJobsPerLaunch ? njobs - first : kJobsPerLaunch;
-        Batch b;
-        memset(&b, 0, sizeof b);
-        memcpy(b.jobs, jobs + first, sizeof(cvk_chain_job) * (size_t)n);
+    const bool fused_kernel = variant != 0 && uniform_layers >= 1 && uniform_layers <= kFusedLayers;
+    const int per_launch = fused_kernel ? kJobsPerLaunch : kJobsPerLaunchV0;
+    for (int first = 0; first < njobs; first += per_launch) {
+        const int n = njobs - first < per_launch ? njobs - first : per_launch;
         int rc;
+        if (fused_kernel) {
+            Batch b;
+            memset(&b, 0, sizeof b);
+            for (int i = 0; i < n; i++) {
+                const cvk_chain_job &src = jobs[first + i];
+                b.jobs[i].out = src.out;
+                for (int k = 0; k < uniform_layers; k++) b.jobs[i].layer[k] = src.layer[k];
+                b.jobs[i].npixels = src.npixels;
+            }
 #define CVK_DISPATCH(NLV)                                                                              \
-        (variant == 0 ? launch_v0<NLV>(b, n, mat, pre, post, grid, s)                                 \
-         : variant == 10 ? launch<NLV, DIAG_MEMORY_ONLY>(b, n, mat, pre, post, grid, block, s)        \
-         : variant == 12 ? launch<NLV, DIAG_COMPUTE_ONLY>(b, n, mat, pre, post, grid, block, s)       \
-                         : launch<NLV, DIAG_NONE>(b, n, mat, pre, post, grid, block, s))
-        switch (uniform_layers) {
-        case 1: rc = CVK_DISPATCH(1); break;
-        case 2: rc = CVK_DISPATCH(2); break;
-        case 3: rc = CVK_DISPATCH(3); break;
-        case 4: rc = CVK_DISPATCH(4); break;
-        default: rc = launch_v0<0>(b, n, mat, pre, post, grid, s); break;     // 5..8 layers or mixed counts
-        }
+            (variant == 10 ? launch<NLV, DIAG_MEMORY_ONLY>(b, n, mat, pre, post, grid, block, s)          \
+             : variant == 12 ? launch<NLV, DIAG_COMPUTE_ONLY>(b, n, mat, pre, post, grid, block, s)       \
+                             : launch<NLV, DIAG_NONE>(b, n, mat, pre, post, grid, block, s))
+            switch (uniform_layers) {
+            case 1: rc = CVK_DISPATCH(1); break;
+            case 2: rc = CVK_DISPATCH(2); break;
+            case 3: rc = CVK_DISPATCH(3); break;
+            default: rc = CVK_DISPATCH(4); break;
+            }
 #undef CVK_DISPATCH
+        } else {
+            BatchV0 b;
+            memset(&b, 0, sizeof b);
+            memcpy(b.jobs, jobs + first, sizeof(cvk_chain_job) * (size_t)n);
+            switch (uniform_layers) {
+            case 1: rc = launch_v0<1>(b, n, mat, pre, post, grid, s); break;
+            case 2: rc = launch_v0<2>(b, n, mat, pre, post, grid, s); break;
+            case 3: rc = launch_v0<3>(b, n, mat, pre, post, grid, s); break;
+            case 4: rc = launch_v0<4>(b, n, mat, pre, post, grid, s); break;
+            default: rc = launch_v0<0>(b, n, mat, pre, post, grid, s); break;     // 5..8 layers or mixed counts
+            }
+        }
         if (rc != 0) return rc;
     }
     return 0;
