@@ -72,7 +72,7 @@ static bool same_box(const box2i *a, const box2i *b) {
 static bool job_is_fusable(const cvs_chain_job *j) {
     if (j->nlayers < 1 || j->nlayers > CVS_CHAIN_MAX_LAYERS) return false;
     const box2i *fw = &j->out->full_window;
-    if (box2i_is_empty(fw)) return false;
+    if (box2i_is_empty(fw) || cvs_box_pixels(fw) < 2) return false;       /* the kernel works on pixel pairs */
     if (((uintptr_t)j->out->data & 15u) != 0) return false;
     for (int k = 0; k < j->nlayers; k++) {
         const rgba_frame_f16 *l = j->layers[k];
@@ -152,4 +152,46 @@ CVS_EXPORT int cvs_chain_color_over_f16_dev(const cvs_chain_job *jobs, int njobs
     if (rc != 0) { cvs_set_error("chain kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     t_last_fused = 1;
     return 0;
+}
+
+/* Crossfade between two f16 frames with an f16 result: what an f16 pull of a crossfade node over two half-native
+ * sources computes -- widen both (main.c:105-144), video_mix_cross_f32 (video_mix.c:107-235), truncate
+ * (main.c:43-71).  One launch of the chain kernel in crossfade mode (8 + 8 read, 8 written per pixel) when every
+ * window is the whole output frame; otherwise the same three nodes on f32 scratch frames, with the reference's
+ * region walk. */
+CVS_EXPORT int cvs_mix_cross_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *a, const rgba_frame_f16 *b, float mix_b, cvs_stream_t stream) {
+    if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
+    hipStream_t s = cvs_pick_stream(stream);
+    mix_b = clampf(mix_b, 0.0f, 1.0f);
+    const cvs_chain_job job = { out, { a, b }, 2 };
+    if (job_is_fusable(&job)) {
+        cvk_chain_job rec;
+        memset(&rec, 0, sizeof rec);
+        rec.out = out->data; rec.layer[0] = a->data; rec.layer[1] = b->data; rec.nlayers = 2;
+        rec.npixels = cvs_box_pixels(&out->full_window);
+        int rc = cvk_chain_cross(&rec, 1, 1.0f - mix_b, mix_b, cvs_cus(), s);
+        if (rc != 0) { cvs_set_error("crossfade kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); box2i_set_empty(&out->current_window); return rc; }
+        out->current_window = out->full_window;
+        t_last_fused = 1;
+        return 0;
+    }
+    t_last_fused = 0;
+    const box2i *fw = &out->full_window;
+    const size_t n = cvs_box_pixels(fw);
+    if (!n) { box2i_set_empty(&out->current_window); return 0; }
+    rgba_frame_f32 fa = { cvs_pool_malloc(n * sizeof(rgba_f32), s), *fw, *fw }, fb = { cvs_pool_malloc(n * sizeof(rgba_f32), s), *fw, *fw };
+    rgba_frame_f32 fo = { cvs_pool_malloc(n * sizeof(rgba_f32), s), *fw, *fw };
+    int rc = (fa.data && fb.data && fo.data) ? 0 : -1;
+    /* each input as its f32 pull would deliver it: clipped to the output's buffer, then widened */
+    rgba_frame_f16 clip = { cvs_pool_malloc(n * sizeof(rgba_f16), s), *fw, *fw };
+    if (!clip.data) rc = -1;
+    if (rc == 0) rc = cvs_copy_frame_f16_dev(&clip, a, s);
+    if (rc == 0) rc = cvs_frame_f16_to_f32_dev(&fa, &clip, s);
+    if (rc == 0) rc = cvs_copy_frame_f16_dev(&clip, b, s);
+    if (rc == 0) rc = cvs_frame_f16_to_f32_dev(&fb, &clip, s);
+    if (rc == 0) rc = cvs_mix_cross_f32_dev(&fo, &fa, &fb, mix_b, s);
+    if (rc == 0) rc = cvs_frame_f32_to_f16_dev(out, &fo, s);
+    cvs_pool_free(clip.data, s); cvs_pool_free(fa.data, s); cvs_pool_free(fb.data, s); cvs_pool_free(fo.data, s);
+    if (rc != 0) box2i_set_empty(&out->current_window);
+    return rc;
 }

@@ -124,6 +124,24 @@ __device__ __forceinline__ px32x2 over_pair(px32x2 lo, px32x2 b) {
     return o;
 }
 
+// video_mix.c:193-205: crossfade of two pixels, weights wa = 1 - mix_b and wb = mix_b made by the host
+__device__ __forceinline__ px32x2 cross_pair(px32x2 p, px32x2 q, float wa, float wb) {
+    const f32x2 alpha_a = p.a * wa;
+    const f32x2 alpha_b = q.a * wb;
+    const f32x2 a = alpha_a + alpha_b;
+    px32x2 o;
+    o.r = p.r * alpha_a + q.r * alpha_b;
+    o.g = p.g * alpha_a + q.g * alpha_b;
+    o.b = p.b * alpha_a + q.b * alpha_b;
+    o.a = a;
+    if (!(a.x == 1.0f && a.y == 1.0f)) {
+        div3_pair(o.r, o.g, o.b, a);
+        if (a.x == 0.0f) { o.r.x = 0.0f; o.g.x = 0.0f; o.b.x = 0.0f; o.a.x = 0.0f; }
+        if (a.y == 0.0f) { o.r.y = 0.0f; o.g.y = 0.0f; o.b.y = 0.0f; o.a.y = 0.0f; }
+    }
+    return o;
+}
+
 // The same blend for ONE pixel per lane (the FIR epilogue): (r, g) ride as a packed pair, b and alpha as scalars;
 // the three quotients share one refined reciprocal under the same band rule as div3_pair.
 struct px1 { f32x2 rg; float b, a; };
@@ -175,6 +193,10 @@ __device__ __forceinline__ px32x2 layer_pair(u32x4 p, const Mat &mat, const uint
 
 template <int NL, bool PRE, bool POST>
 __device__ __forceinline__ u32x4 chain_pair_lean(const u32x4 (&w)[NL], const Mat &mat, const uint16_t *lut, const uint16_t *post) {
+    if constexpr (NL == 2) {
+        if (mat.cross)         // wave-uniform: a crossfade of two half frames (widen, video_mix.c:193-205, truncate)
+            return narrow_pair(cross_pair(widen2(make_uint4(w[0].x, w[0].y, w[0].z, w[0].w)), widen2(make_uint4(w[1].x, w[1].y, w[1].z, w[1].w)), mat.wa, mat.wb));
+    }
     px32x2 acc = layer_pair<PRE, POST>(w[0], mat, lut, post);
 #pragma unroll
     for (int k = 1; k < NL; k++) acc = over_pair(acc, layer_pair<PRE, POST>(w[k], mat, lut, post));

@@ -41,6 +41,7 @@ static_assert(sizeof(Batch) + 128 <= 4096, "kernel arguments must fit the 4 KiB 
 
 template <int MAXL, bool PRE, bool POST>
 __device__ __forceinline__ uint2 chain_pixel(const uint2 (&px)[MAXL], int nl, const Mat &mat, const uint16_t *lut, const uint16_t *post) {
+    if (MAXL >= 2 && mat.cross) return narrow(blend_cross(widen(px[0]), widen(px[MAXL >= 2 ? 1 : 0]), mat.wa, mat.wb));
     px32 acc = mat.plain ? widen(px[0]) : grade<PRE, POST>(px[0], mat, lut, post);
 #pragma unroll
     for (int k = 1; k < MAXL; k++)      // static indices only: a runtime-indexed array would live in scratch
@@ -258,9 +259,23 @@ int launch_v0(const BatchV0 &jobs, int njobs, const Mat &mat, const uint16_t *pr
 //   CVS_CHAIN_VARIANT  unset/1 = production kernel; 0 = the simple first version (A/B reference);
 //                      10 = memory traffic only, 12 = arithmetic only (diagnostic builds, wrong output)
 //   CVS_CHAIN_BLOCK    lanes per workgroup (default 512 = 2 waves per SIMD; one workgroup per CU)
+static int chain_dispatch(const cvk_chain_job *jobs, int njobs, int uniform_layers, const Mat &mat,
+                          const uint16_t *pre, const uint16_t *post, int cus, void *stream);
+
 extern "C" int cvk_chain_color_over(const cvk_chain_job *jobs, int njobs, int uniform_layers, const float *m,
                                     const uint16_t *pre, const uint16_t *post, int cus, void *stream) {
-    Mat mat = make_mat(m);
+    return chain_dispatch(jobs, njobs, uniform_layers, make_mat(m), pre, post, cus, stream);
+}
+
+// two-layer jobs, crossfaded: out = cross(layer[0], layer[1]) with weights wa, wb
+extern "C" int cvk_chain_cross(const cvk_chain_job *jobs, int njobs, float wa, float wb, int cus, void *stream) {
+    Mat mat = make_mat(NULL);
+    mat.cross = 1; mat.wa = wa; mat.wb = wb;
+    return chain_dispatch(jobs, njobs, 2, mat, NULL, NULL, cus, stream);
+}
+
+static int chain_dispatch(const cvk_chain_job *jobs, int njobs, int uniform_layers, const Mat &mat,
+                          const uint16_t *pre, const uint16_t *post, int cus, void *stream) {
     const unsigned grid = (unsigned)(cus > 0 ? cus : 256);
     hipStream_t s = (hipStream_t)stream;
     const char *env = getenv("CVS_CHAIN_VARIANT");

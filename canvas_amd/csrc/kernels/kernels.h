@@ -70,6 +70,9 @@ typedef struct {
 int cvk_chain_color_over(const cvk_chain_job *jobs, int njobs, int uniform_layers, const float *m,
                          const uint16_t *pre_lut, const uint16_t *post_lut, int cus, void *stream);
 
+/* the same machinery crossfading two-layer jobs: out = cross(layer[0], layer[1]), weights wa = 1 - mix_b, wb = mix_b */
+int cvk_chain_cross(const cvk_chain_job *jobs, int njobs, float wa, float wb, int cus, void *stream);
+
 /* separable FIR passes (video_scale.c structure) */
 typedef struct {
     cvk_view target, source;

@@ -9,7 +9,9 @@ namespace cvs {
 constexpr int kWG = 1024;                  // 16 waves: the LDS table allows one workgroup per CU
 constexpr int kLutHalfs = 65536;
 
-struct Mat { float m[9]; int plain; };     // plain: no colour stage at all (layers go straight to the stack)
+// plain: no colour stage at all (layers go straight to the stack); cross: the two layers are crossfaded with the
+// weights wa, wb (video_mix.c:193-205) instead of stacked
+struct Mat { float m[9]; int plain; int cross; float wa, wb; };
 
 // Pointers that arrive inside a job record are generic to the compiler, which then emits flat_load
 // (counts on BOTH vmcnt and lgkmcnt and so serialises against the LDS gathers).  Tell it they are global.
@@ -51,6 +53,7 @@ inline unsigned persistent_grid(int cus, size_t work_items) {
 inline Mat make_mat(const float *m) {
     Mat r;
     r.plain = m ? 0 : 1;
+    r.cross = 0; r.wa = r.wb = 0.0f;
     for (int i = 0; i < 9; i++) r.m[i] = m ? m[i] : (i % 4 == 0 ? 1.0f : 0.0f);
     return r;
 }

@@ -211,8 +211,38 @@ static void mix_render(PyObject *o, int frame_index, rgba_frame_dev *f) {       
     f->current_window = fa.current_window;
     cvs_pool_free(tb.data, f->stream);
 }
-DEFINE_NODE_VTABLE(mix, CVS_FORMAT_F32, 0, 1)
-static void *mix_unused[] UNUSED = { (void *)mix_slot_16 };
+/* a source that fills the f16 host slot only is half-native: its f32 pull is "pull f16, widen" (main.c:105-144) */
+static bool half_native(const video_source *src) { return src && src->funcs && src->funcs->get_frame && !src->funcs->get_frame_32; }
+
+/* f16 wanted and both inputs half-native: pull them as f16 and crossfade in one launch (widen, cross, truncate in
+ * registers) instead of rendering f32 and narrowing; same arithmetic, a fifth of the traffic */
+static bool mix_render_half(py_mix *self, int frame_index, rgba_frame_dev *f) {
+    if (f->format != CVS_FORMAT_F16 || !half_native(self->a) || !half_native(self->b)) return false;
+    const float mix_b = clampf(framefunc_get_f32(&self->mix_b, frame_index), 0.0f, 1.0f);
+    if (mix_b == 0.0f) { pull_dev(self->a, frame_index, f); return true; }       /* video_mix.c:46-71 */
+    if (mix_b == 1.0f) { pull_dev(self->b, frame_index, f); return true; }
+    rgba_frame_dev ta = scratch_like(f, CVS_FORMAT_F16, &f->full_window), tb = scratch_like(f, CVS_FORMAT_F16, &f->full_window);
+    if (ta.data && tb.data) {
+        pull_dev(self->a, frame_index, &ta);
+        pull_dev(self->b, frame_index, &tb);
+        rgba_frame_f16 fa = { ta.data, ta.full_window, ta.current_window }, fb = { tb.data, tb.full_window, tb.current_window };
+        rgba_frame_f16 fo = { f->data, f->full_window, f->full_window };
+        if (cvs_mix_cross_f16_dev(&fo, &fa, &fb, mix_b, f->stream) != 0) box2i_set_empty(&fo.current_window);
+        f->current_window = fo.current_window;
+    } else box2i_set_empty(&f->current_window);
+    cvs_pool_free(ta.data, f->stream); cvs_pool_free(tb.data, f->stream);
+    return true;
+}
+static void mix_slot_dev(PyObject *self, int i, rgba_frame_dev *f) {
+    if (!mix_render_half((py_mix *)self, i, f)) node_get_frame_dev(self, i, f, CVS_FORMAT_F32, mix_render);
+}
+static void mix_render_any(PyObject *self, int i, rgba_frame_dev *f) { mix_slot_dev(self, i, f); }
+static void mix_slot_32(PyObject *self, int i, rgba_frame_f32 *f) { node_get_frame_host32(self, i, f, CVS_FORMAT_F32, mix_render); }
+static video_frame_source_funcs mix_funcs = {
+    .flags = VIDEO_SOURCE_FLAG_DEVICE, .get_frame_32 = (video_get_frame_32_func)mix_slot_32,
+    .get_frame_dev = (video_get_frame_dev_func)mix_slot_dev };
+static PyObject *mix_capsule;
+static void *mix_unused[] UNUSED = { (void *)mix_render_any };
 static PyGetSetDef mix_getset[] = { { VIDEO_FRAME_SOURCE_FUNCS, pyext_capsule_getter, NULL, "Video frame source C API.", &mix_capsule }, { NULL } };
 static PyTypeObject py_type_Mix = {
     PyVarObject_HEAD_INIT(NULL, 0)

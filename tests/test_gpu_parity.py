@@ -757,6 +757,25 @@ def test_plain_over_stack_matches_oracle(cvs, orc, nlayers, translucent):
     assert_same_f16(out.download().array, want.array, "plain stack, %d layers" % nlayers)
 
 
+@pytest.mark.parametrize("size", [(1, 1), (2, 1), (3, 1), (1, 5)])
+def test_chain_on_tiny_frames(cvs, orc, size):
+    """One pixel cannot form a pair: the call goes node by node; two and three pixels run the pair kernel + tail."""
+    w, h = size
+    full = (0, 0, w - 1, h - 1)
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    layers = _synth_layers(w, h, 3)
+    for matrix, pre, table in [(m, _lib.LUT_REC709_TO_LINEAR_SCENE, orc.transfer_table(0)), (None, _lib.LUT_NONE, None)]:
+        want = orc.chain_color_over(layers, matrix, table, None)
+        dl = [DeviceFrame.from_host(l) for l in layers]
+        out = DeviceFrame(full, np.uint16)
+        chain_color_over([(out, dl)], matrix, pre, _lib.LUT_NONE)
+        _lib.check(cvs.cvs_stream_sync(None))
+        assert cvs.cvs_chain_last_was_fused() == (0 if w * h < 2 else 1)
+        got = out.download()
+        assert same_window(got.current_window, want.current_window)
+        assert_same_f16(got.array, want.array, "chain on %dx%d" % size)
+
+
 def test_plain_stack_rejects_tables_and_takes_ragged_windows(cvs, orc):
     full = (0, 0, 47, 19)
     rng = np.random.default_rng(13)
@@ -1055,3 +1074,52 @@ def test_lanczos_halving_uniform_taps(cvs, orc, ksize, geom):
     got = d_out.download()
     assert same_window(got.current_window, want.current_window)
     assert_same_f32(got.array, want.array, "lanczos halving, kernel size %d" % ksize)
+
+
+# ------------------------------------------------------------------ fused f16 crossfade
+
+def _oracle_cross_f16(orc, out_full, a, b, mix):
+    """widen (clipped to the output buffer, as a pull into it would be) -> video_mix_cross_f32 -> truncate"""
+    def pulled(frame):
+        clip = HostFrame(out_full, np.uint16)
+        orc.lib().orc_copy_frame_f16(clip.ref(), frame.ref())
+        return HostFrame(out_full, np.float32, orc.half_to_float(clip.array), clip.current_window)
+    pa, pb = pulled(a), pulled(b)
+    out = HostFrame(out_full, np.float32)
+    orc.lib().orc_mix_cross_f32(out.ref(), pa.ref(), pb.ref(), C.c_float(mix))
+    return HostFrame(out_full, np.uint16, orc.float_to_half(out.array), out.current_window)
+
+
+@pytest.mark.parametrize("mix", [0.3, 0.5, 0.0, 1.0, 0.999])
+@pytest.mark.parametrize("size", [(96, 54), (33, 7), (1, 1)])
+def test_mix_cross_f16_fused(cvs, orc, mix, size):
+    from canvas_amd.synth import truncate_to_half
+    w, h = size
+    full = (0, 0, w - 1, h - 1)
+    rng = np.random.default_rng(1200 + w)
+    a = HostFrame(full, np.uint16, truncate_to_half(rand_f32_frame(rng, full, full, alpha="mixed", lo=-0.25, hi=1.5).array))
+    b = HostFrame(full, np.uint16, truncate_to_half(rand_f32_frame(rng, full, full, alpha="mixed", lo=-0.25, hi=1.5).array))
+    if w > 8:
+        a.array[1, 2] = [0x7BFF, 0xFBFF, 0x0001, 0x3C00]
+        b.array[1, 2] = [0x7BFF, 0x7BFF, 0x8001, 0x3C00]
+    want = _oracle_cross_f16(orc, full, a, b, mix)
+    da, db, out = DeviceFrame.from_host(a), DeviceFrame.from_host(b), DeviceFrame(full, np.uint16)
+    _lib.check(cvs.cvs_mix_cross_f16_dev(out.ref(), da.ref(), db.ref(), C.c_float(mix), None))
+    assert cvs.cvs_chain_last_was_fused() == (1 if w * h >= 2 else 0)
+    got = out.download()
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f16(got.array, want.array, "fused crossfade, mix %g" % mix)
+
+
+@pytest.mark.parametrize("pw,qw", MIX_WINDOWS[:6])
+def test_mix_cross_f16_windowed_goes_node_by_node(cvs, orc, pw, qw):
+    rng = np.random.default_rng(1300)
+    full = (0, 0, 23, 11)
+    a, b = rand_f16_frame(rng, full, pw), rand_f16_frame(rng, full, qw)
+    want = _oracle_cross_f16(orc, full, a, b, 0.35)
+    da, db, out = DeviceFrame.from_host(a), DeviceFrame.from_host(b), DeviceFrame(full, np.uint16)
+    _lib.check(cvs.cvs_mix_cross_f16_dev(out.ref(), da.ref(), db.ref(), C.c_float(0.35), None))
+    got = out.download()
+    assert same_window(got.current_window, want.current_window)
+    if not want.current_window.is_empty():
+        assert_same_f16(got.window_view(), want.window_view(), "windowed crossfade %r %r" % (pw, qw))

@@ -376,3 +376,22 @@ def test_workspace_of_half_native_clips_takes_the_fused_stack(process, bt, orc, 
     got2 = ws.get_frame_f16(1, bt.box2i(*full))
     assert _lib.load().cvs_chain_last_was_fused() == 0 and got2.current_window == bt.box2i(*full)
     assert got2.pixel(5, 5) == got.pixel(5, 5) and got2.pixel(20, 20) != got.pixel(20, 20)
+
+
+def test_crossfade_of_half_native_clips_is_one_launch(process, bt, orc):
+    """VideoMixFilter over two half-native clips pulled as f16: fused crossfade; same values as the f32 pull truncated."""
+    from canvas_amd import _lib
+    clip_a = process.VideoGainOffsetFilter(process.SolidColorVideoSource((0.2, 0.4, 0.6, 1.0)), gain=1.25, offset=0.03125)
+    clip_b = process.VideoGainOffsetFilter(process.SolidColorVideoSource((0.9, 0.1, 0.3, 0.5)), gain=0.75, offset=0.0)
+    fade = process.VideoMixFilter(src_a=clip_a, src_b=clip_b, mix_b=process.LerpFunc((0,), (1,), 10))
+    window = bt.box2i(0, 0, 63, 35)
+    for frame in (3, 5, 9):
+        got16 = fade.get_frame_f16(frame, window)
+        assert _lib.load().cvs_chain_last_was_fused() == 1
+        got32 = fade.get_frame_f32(frame, window)
+        for x, y in [(0, 0), (17, 9), (63, 35)]:
+            want = orc.float_to_half(np.array(got32.pixel(x, y), np.float32))
+            assert np.array_equal(orc.float_to_half(np.array(got16.pixel(x, y), np.float32)), want), (frame, x, y)
+    # the ends of the fade are single pulls (video_mix.c:46-71)
+    almost(fade.get_frame_f16(0, window).pixel(5, 5), clip_a.get_frame_f16(0, window).pixel(5, 5), 7)
+    almost(fade.get_frame_f16(10, window).pixel(5, 5), clip_b.get_frame_f16(10, window).pixel(5, 5), 7)
