@@ -12,6 +12,7 @@
 
 CVS_EXPORT int cvs_color_matrix_f16_dev(rgba_frame_f16 *frame, const float m[9], int pre_lut, int post_lut, cvs_stream_t s) {
     if (cvs_enter() != 0) return -1;
+    CVS_REQUIRE_INSIDE(frame, frame, "cvs_color_matrix_f16_dev");
     if (box2i_is_empty(&frame->current_window)) return 0;
     if (!cvs_box_contains(&frame->full_window, &frame->current_window)) { cvs_set_error("colour matrix: current_window outside the buffer"); return -1; }
     const half *pre = cvs_lut_dev_or_null(pre_lut), *post = cvs_lut_dev_or_null(post_lut);
@@ -25,6 +26,7 @@ CVS_EXPORT int cvs_color_matrix_f16_dev(rgba_frame_f16 *frame, const float m[9],
  * gl.c:584), one pass instead of video_copy_frame_f16 + the in-place filter */
 CVS_EXPORT int cvs_color_matrix_f16_to_dev(rgba_frame_f16 *out, const rgba_frame_f16 *in, const float m[9], int pre_lut, int post_lut, cvs_stream_t s) {
     if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(in, out, "cvs_color_matrix_f16_to_dev");
     box2i win;
     box2i_intersect(&win, &out->full_window, &in->current_window);
     out->current_window = win;
@@ -161,6 +163,8 @@ CVS_EXPORT int cvs_chain_color_over_f16_dev(const cvs_chain_job *jobs, int njobs
  * region walk. */
 CVS_EXPORT int cvs_mix_cross_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *a, const rgba_frame_f16 *b, float mix_b, cvs_stream_t stream) {
     if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(a, out, "cvs_mix_cross_f16_dev");
+    CVS_REQUIRE_INSIDE(b, out, "cvs_mix_cross_f16_dev");
     hipStream_t s = cvs_pick_stream(stream);
     mix_b = clampf(mix_b, 0.0f, 1.0f);
     const cvs_chain_job job = { out, { a, b }, 2 };

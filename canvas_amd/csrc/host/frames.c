@@ -20,6 +20,7 @@
 
 CVS_EXPORT int cvs_copy_frame_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *in, cvs_stream_t s) {
     if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(in, out, "cvs_copy_frame_f16_dev");
     box2i inner;
     box2i_intersect(&inner, &out->full_window, &in->current_window);
     out->current_window = inner;
@@ -30,6 +31,7 @@ CVS_EXPORT int cvs_copy_frame_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 
 
 CVS_EXPORT int cvs_copy_frame_alpha_f32_dev(rgba_frame_f32 *out, const rgba_frame_f32 *in, float alpha, cvs_stream_t s) {
     if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(in, out, "cvs_copy_frame_alpha_f32_dev");
     alpha = clampf(alpha, 0.0f, 1.0f);
     if (out->data == in->data && alpha == 1.0f) return 0;             /* video_mix.c:77-78 (same frame, nothing to do) */
     if (alpha == 0.0f) { box2i_set_empty(&out->current_window); return 0; }
@@ -43,6 +45,7 @@ CVS_EXPORT int cvs_copy_frame_alpha_f32_dev(rgba_frame_f32 *out, const rgba_fram
 
 CVS_EXPORT int cvs_frame_f16_to_f32_dev(rgba_frame_f32 *out, const rgba_frame_f16 *in, cvs_stream_t s) {
     if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(in, out, "cvs_frame_f16_to_f32_dev");
     /* main.c:115-139: the temp frame shares the target's full window, rows of current_window are widened */
     out->current_window = in->current_window;
     if (box2i_is_empty(&in->current_window)) return 0;
@@ -53,6 +56,7 @@ CVS_EXPORT int cvs_frame_f16_to_f32_dev(rgba_frame_f32 *out, const rgba_frame_f1
 
 CVS_EXPORT int cvs_frame_f32_to_f16_dev(rgba_frame_f16 *out, const rgba_frame_f32 *in, cvs_stream_t s) {
     if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(in, out, "cvs_frame_f32_to_f16_dev");
     out->current_window = in->current_window;                          /* main.c:43-71 */
     if (box2i_is_empty(&in->current_window)) return 0;
     if (!cvs_box_contains(&out->full_window, &in->current_window)) { cvs_set_error("f32->f16: source window outside target buffer"); box2i_set_empty(&out->current_window); return -1; }
@@ -94,6 +98,8 @@ static void plan_mix(cvk_mix_params *mp, void *out_data, const box2i *out_full,
 
 CVS_EXPORT int cvs_mix_cross_f32_dev(rgba_frame_f32 *out, const rgba_frame_f32 *a, const rgba_frame_f32 *b, float mix_b, cvs_stream_t s) {
     if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(a, out, "cvs_mix_cross_f32_dev");
+    CVS_REQUIRE_INSIDE(b, out, "cvs_mix_cross_f32_dev");
     mix_b = clampf(mix_b, 0.0f, 1.0f);
     const float mix_a = 1.0f - mix_b;
     if (box2i_is_empty(&a->current_window)) return cvs_copy_frame_alpha_f32_dev(out, b, mix_b, s);
@@ -109,6 +115,8 @@ CVS_EXPORT int cvs_mix_cross_f32_dev(rgba_frame_f32 *out, const rgba_frame_f32 *
 
 CVS_EXPORT int cvs_mix_over_f32_dev(rgba_frame_f32 *out, const rgba_frame_f32 *b, float mix_b, cvs_stream_t s) {
     if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(b, out, "cvs_mix_over_f32_dev");
+    CVS_REQUIRE_INSIDE(out, out, "cvs_mix_over_f32_dev");
     mix_b = clampf(mix_b, 0.0f, 1.0f);
     if (box2i_is_empty(&out->current_window)) return cvs_copy_frame_alpha_f32_dev(out, b, mix_b, s);
     if (box2i_is_empty(&b->current_window) || mix_b == 0.0f) return 0;
@@ -123,6 +131,7 @@ CVS_EXPORT int cvs_mix_over_f32_dev(rgba_frame_f32 *out, const rgba_frame_f32 *b
 
 CVS_EXPORT int cvs_gain_offset_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *in, float gain, float offset, cvs_stream_t s) {
     if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(in, out, "cvs_gain_offset_f16_dev");
     box2i win;
     box2i_intersect(&win, &out->full_window, &in->current_window);    /* gl.c:584: one-input filters cover out.full ∩ in.current */
     out->current_window = win;

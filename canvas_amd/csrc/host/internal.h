@@ -67,6 +67,17 @@ static inline bool cvs_box_contains(const box2i *outer, const box2i *inner) {
            (inner->min.x >= outer->min.x && inner->min.y >= outer->min.y && inner->max.x <= outer->max.x && inner->max.y <= outer->max.y);
 }
 
+/* A frame whose current_window reaches outside its own buffer would send a kernel out of bounds: refuse it here,
+ * loudly, with the output marked empty.  (The reference would read past the buffer.) */
+#define CVS_REQUIRE_INSIDE(in_frame, out_frame, what)                                                      \
+    do {                                                                                                   \
+        if (!cvs_box_contains(&(in_frame)->full_window, &(in_frame)->current_window)) {                   \
+            cvs_set_error("%s: the input's current_window lies outside its buffer", what);                \
+            box2i_set_empty(&(out_frame)->current_window);                                                 \
+            return -1;                                                                                     \
+        }                                                                                                  \
+    } while (0)
+
 /* ---- staging of host frames for the reference-named entry points (H2D -> kernels -> D2H) */
 typedef struct {
     void *dev;            /* device copy of the whole full_window buffer */

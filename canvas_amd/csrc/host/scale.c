@@ -182,6 +182,7 @@ static int triangle_pass(rgba_frame_f32 *target, float tmin, const rgba_frame_f3
 
 CVS_EXPORT int cvs_scale_bilinear_f32_dev(rgba_frame_f32 *target, v2f tp, const rgba_frame_f32 *source, v2f sp, v2f fac, cvs_stream_t stream) {
     if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(source, target, "cvs_scale_bilinear_f32_dev");
     hipStream_t s = cvs_pick_stream(stream);
     if (fac.x == 1.0f && tp.x == sp.x) {
         if (fac.y == 1.0f && tp.y == sp.y) return cvs_copy_frame_alpha_f32_dev(target, source, 1.0f, s);
@@ -569,6 +570,7 @@ static int lanczos_fused(void *tdata, const box2i *tfull, int out_half, const vo
 
 CVS_EXPORT int cvs_fir_blur_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, const float *taps, int ntaps, cvs_stream_t stream) {
     if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(source, target, "cvs_fir_blur_f32_dev");
     if (ntaps < 1 || !taps) { cvs_set_error("blur: need at least one tap"); box2i_set_empty(&target->current_window); return -1; }
     hipStream_t s = cvs_pick_stream(stream);
     box2i win;
@@ -585,6 +587,7 @@ CVS_EXPORT int cvs_fir_blur_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32
  * (widen, framework.h f16->f32 path; both passes in f32; truncate on the way out), in one launch. */
 CVS_EXPORT int cvs_fir_blur_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, const float *taps, int ntaps, cvs_stream_t stream) {
     if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(source, target, "cvs_fir_blur_f16_dev");
     if (ntaps < 1 || !taps) { cvs_set_error("blur: need at least one tap"); box2i_set_empty(&target->current_window); return -1; }
     hipStream_t s = cvs_pick_stream(stream);
     box2i win;
@@ -612,6 +615,7 @@ CVS_EXPORT int cvs_fir_blur_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16
 CVS_EXPORT int cvs_blur_over_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *source, const float *taps, int ntaps,
                                      const rgba_frame_f16 *const *overlays, int noverlays, cvs_stream_t stream) {
     if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(source, out, "cvs_blur_over_f16_dev");
     if (ntaps < 1 || !taps || noverlays < 0 || (noverlays > 0 && !overlays)) { cvs_set_error("blur+over: bad arguments"); box2i_set_empty(&out->current_window); return -1; }
     hipStream_t s = cvs_pick_stream(stream);
     const box2i *full = &out->full_window;
@@ -658,6 +662,7 @@ CVS_EXPORT int cvs_blur_over_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *
 
 CVS_EXPORT int cvs_resample_lanczos_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, float fx, float fy, int ksize, cvs_stream_t stream) {
     if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(source, target, "cvs_resample_lanczos_f32_dev");
     if (!(fx > 0.0f) || !(fy > 0.0f) || ksize < 1 || box2i_is_empty(&source->current_window) || box2i_is_empty(&target->full_window)) {
         box2i_set_empty(&target->current_window);
         return 0;
@@ -675,6 +680,7 @@ CVS_EXPORT int cvs_resample_lanczos_f32_dev(rgba_frame_f32 *target, const rgba_f
 CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, const float *taps, int ntaps,
                                         float fx, float fy, int ksize, cvs_stream_t stream) {
     if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(source, target, "cvs_blur_lanczos_f16_dev");
     if (ntaps < 1 || !taps || !(fx > 0.0f) || !(fy > 0.0f) || ksize < 1) { cvs_set_error("blur+lanczos: bad arguments"); box2i_set_empty(&target->current_window); return -1; }
     if (box2i_is_empty(&source->current_window) || box2i_is_empty(&target->full_window)) { box2i_set_empty(&target->current_window); return 0; }
     hipStream_t s = cvs_pick_stream(stream);

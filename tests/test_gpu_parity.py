@@ -1123,3 +1123,37 @@ def test_mix_cross_f16_windowed_goes_node_by_node(cvs, orc, pw, qw):
     assert same_window(got.current_window, want.current_window)
     if not want.current_window.is_empty():
         assert_same_f16(got.window_view(), want.window_view(), "windowed crossfade %r %r" % (pw, qw))
+
+
+def test_frames_whose_window_leaves_their_buffer_are_refused(cvs):
+    """A current_window reaching outside full_window would send a kernel out of bounds: every device entry point
+    refuses such an input (status, message, empty output window) instead of launching."""
+    full = (0, 0, 31, 17)
+    good16, good32 = DeviceFrame(full, np.uint16), DeviceFrame(full, np.float32)
+    bad16, bad32 = DeviceFrame(full, np.uint16, current_window=(0, 0, 40, 17)), DeviceFrame(full, np.float32, current_window=(-1, 0, 31, 17))
+    out16, out32 = DeviceFrame(full, np.uint16), DeviceFrame(full, np.float32)
+    taps = synth.gaussian_taps(9, 1.5)
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    calls = [
+        lambda: cvs.cvs_copy_frame_f16_dev(out16.ref(), bad16.ref(), None),
+        lambda: cvs.cvs_copy_frame_alpha_f32_dev(out32.ref(), bad32.ref(), C.c_float(0.5), None),
+        lambda: cvs.cvs_frame_f16_to_f32_dev(out32.ref(), bad16.ref(), None),
+        lambda: cvs.cvs_frame_f32_to_f16_dev(out16.ref(), bad32.ref(), None),
+        lambda: cvs.cvs_mix_cross_f32_dev(out32.ref(), good32.ref(), bad32.ref(), C.c_float(0.5), None),
+        lambda: cvs.cvs_mix_over_f32_dev(out32.ref(), bad32.ref(), C.c_float(1.0), None),
+        lambda: cvs.cvs_gain_offset_f16_dev(out16.ref(), bad16.ref(), C.c_float(1.0), C.c_float(0.0), None),
+        lambda: cvs.cvs_color_matrix_f16_to_dev(out16.ref(), bad16.ref(), f32p(m), -1, -1, None),
+        lambda: cvs.cvs_mix_cross_f16_dev(out16.ref(), bad16.ref(), good16.ref(), C.c_float(0.5), None),
+        lambda: cvs.cvs_scale_bilinear_f32_dev(out32.ref(), v2f(0, 0), bad32.ref(), v2f(0, 0), v2f(0.5, 0.5), None),
+        lambda: cvs.cvs_fir_blur_f32_dev(out32.ref(), bad32.ref(), f32p(taps), 9, None),
+        lambda: cvs.cvs_fir_blur_f16_dev(out16.ref(), bad16.ref(), f32p(taps), 9, None),
+        lambda: cvs.cvs_resample_lanczos_f32_dev(out32.ref(), bad32.ref(), C.c_float(0.5), C.c_float(0.5), 3, None),
+        lambda: cvs.cvs_blur_lanczos_f16_dev(out16.ref(), bad16.ref(), f32p(taps), 9, C.c_float(0.5), C.c_float(0.5), 3, None),
+    ]
+    for i, call in enumerate(calls):
+        out16.c.current_window = box2i.of(*full)
+        out32.c.current_window = box2i.of(*full)
+        assert call() != 0, i
+        assert "outside its buffer" in _lib.last_error(), (i, _lib.last_error())
+        assert out16.current_window.is_empty() or out32.current_window.is_empty(), i
+    _lib.check(cvs.cvs_stream_sync(None))
