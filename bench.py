@@ -147,7 +147,9 @@ def main():
     w, h, nl = args.width, args.height, args.layers
     full = (0, 0, w - 1, h - 1)
     ring = []
-    my_frames = frames_of_rank(rank, world, args.ring)          # global frame ids g with g % world == rank
+    # weak scaling: every rank owns --ring frame sets whatever the world size (frames_of_rank counts per rank);
+    # global frame g lives on rank g % world
+    my_frames = frames_of_rank(rank, world, args.ring)
     # one arena for the whole ring: a single large allocation maps with far fewer page-table entries than
     # dozens of 66 MB ones, and the TLB reach of the chip is what a multi-GB streaming working set leans on
     frame_bytes = w * h * 8
