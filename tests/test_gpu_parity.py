@@ -1157,3 +1157,55 @@ def test_frames_whose_window_leaves_their_buffer_are_refused(cvs):
         assert "outside its buffer" in _lib.last_error(), (i, _lib.last_error())
         assert out16.current_window.is_empty() or out32.current_window.is_empty(), i
     _lib.check(cvs.cvs_stream_sync(None))
+
+
+# ------------------------------------------------------------------ the other BASELINE configs at full size, every pixel
+
+def test_config3_full_4k_every_pixel(cvs, orc):
+    """3840x2160 f16 -> 9-tap Gaussian -> Lanczos3 -> 1920x1080 f16, whole frame against the oracle's nodes."""
+    w, h = 3840, 2160
+    taps = synth.gaussian_taps(9, 1.5)
+    layer = synth.layer_frame(w, h, 1, 0)
+    want = _oracle_config3(orc, layer, (w // 2, h // 2), taps, 0.5, 0.5)
+    d_src = DeviceFrame.from_host(layer)
+    d_out = DeviceFrame((0, 0, w // 2 - 1, h // 2 - 1), np.uint16)
+    _lib.check(cvs.cvs_blur_lanczos_f16_dev(d_out.ref(), d_src.ref(), f32p(taps), 9, C.c_float(0.5), C.c_float(0.5), 3, None))
+    got = d_out.download()
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f16(got.array, want.array, "4K config 3, every pixel")
+
+
+def test_config5_full_4k_every_pixel(cvs, orc):
+    """One 3840x2160 frame of the 10-node graph (colour -> blur -> 4-step composite), whole frame against the oracle."""
+    from canvas_amd.stream import GraphStream
+    from tests.util import oracle_graph
+    w, h = 3840, 2160
+    g = GraphStream(w, h, ring=1)
+    out = g.render(0)
+    _lib.check(cvs.cvs_stream_sync(None))
+    want = oracle_graph(orc, GraphStream.host_inputs(w, h, 0), g.matrix, orc.transfer_table(0), None, g.taps)
+    got = out.download()
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f16(got.array, want.array, "4K config 5, every pixel")
+
+
+def test_config4_8k_rows_against_oracle(cvs, orc):
+    """7680x4320 3-layer over stack: the first and the last 64 rows of the frame against the oracle (the kernel is a
+    flat stream of pixel pairs: both ends of the buffer, 983 040 pixels, every layer translucent above the base)."""
+    w, h, rows = 7680, 4320, 64
+    full = (0, 0, w - 1, h - 1)
+    arrays = [synth.layer_pixels(w, h, k, 0) for k in range(3)]
+    dl = []
+    for a in arrays:
+        d = DeviceFrame(full, np.uint16)
+        d.upload(a)
+        dl.append(d)
+    out = DeviceFrame(full, np.uint16)
+    chain_color_over([(out, dl)], None)
+    _lib.check(cvs.cvs_stream_sync(None))
+    assert cvs.cvs_chain_last_was_fused() == 1
+    got = out.download().array
+    for sl in (slice(0, rows), slice(h - rows, h)):
+        part = [HostFrame((0, 0, w - 1, rows - 1), np.uint16, a[sl]) for a in arrays]
+        want = orc.chain_color_over(part, None)
+        assert_same_f16(got[sl], want.array, "8K config 4 rows %r" % (sl,))
