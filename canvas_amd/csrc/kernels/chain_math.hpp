@@ -34,7 +34,7 @@ __device__ __forceinline__ f32x2 through_half(f32x2 v, const uint16_t *lds_lut, 
 }
 
 template <bool PRE, bool POST>
-__device__ __forceinline__ px32x2 grade_pair(u32x4 p, const Mat &mat, const uint16_t *lds_lut, const uint16_t *glb_post) {
+__device__ __forceinline__ px32x2 grade_pair(u32x4 p, const MatR &mat, const uint16_t *lds_lut, const uint16_t *glb_post) {
     uint32_t c[8] = { p.x & 0xFFFFu, p.x >> 16, p.y & 0xFFFFu, p.y >> 16, p.z & 0xFFFFu, p.z >> 16, p.w & 0xFFFFu, p.w >> 16 };
     if (PRE) {
 #pragma unroll
@@ -44,7 +44,7 @@ __device__ __forceinline__ px32x2 grade_pair(u32x4 p, const Mat &mat, const uint
     v.r = f32x2{ h2f(c[0]), h2f(c[4]) };
     v.g = f32x2{ h2f(c[1]), h2f(c[5]) };
     v.b = f32x2{ h2f(c[2]), h2f(c[6]) };
-    px32x2 o = mat3x2(v, mat.m);
+    px32x2 o = mat3x2(v, mat);
     // rare: a channel at or beyond the half range must become Inf, not 65504
     const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.r.x), __builtin_fabsf(o.g.x)), __builtin_fabsf(o.b.x)),
                                       __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.r.y), __builtin_fabsf(o.g.y)), __builtin_fabsf(o.b.y)));
@@ -186,13 +186,13 @@ __device__ __forceinline__ u32x4 narrow_pair(px32x2 v) {
 
 // a layer as the stack sees it: through the colour filter, or (mat.plain, wave-uniform) just widened
 template <bool PRE, bool POST>
-__device__ __forceinline__ px32x2 layer_pair(u32x4 p, const Mat &mat, const uint16_t *lut, const uint16_t *post) {
+__device__ __forceinline__ px32x2 layer_pair(u32x4 p, const MatR &mat, const uint16_t *lut, const uint16_t *post) {
     if (mat.plain) return widen2(make_uint4(p.x, p.y, p.z, p.w));
     return grade_pair<PRE, POST>(p, mat, lut, post);
 }
 
 template <int NL, bool PRE, bool POST>
-__device__ __forceinline__ u32x4 chain_pair_lean(const u32x4 (&w)[NL], const Mat &mat, const uint16_t *lut, const uint16_t *post) {
+__device__ __forceinline__ u32x4 chain_pair_lean(const u32x4 (&w)[NL], const MatR &mat, const uint16_t *lut, const uint16_t *post) {
     if constexpr (NL == 2) {
         if (mat.cross)         // wave-uniform: a crossfade of two half frames (widen, video_mix.c:193-205, truncate)
             return narrow_pair(cross_pair(widen2(make_uint4(w[0].x, w[0].y, w[0].z, w[0].w)), widen2(make_uint4(w[1].x, w[1].y, w[1].z, w[1].w)), mat.wa, mat.wb));
@@ -205,7 +205,7 @@ __device__ __forceinline__ u32x4 chain_pair_lean(const u32x4 (&w)[NL], const Mat
 
 // the colour filter alone, codes in -> codes out (color.c structure on a pair of pixels)
 template <bool PRE, bool POST>
-__device__ __forceinline__ u32x4 color_pair_codes(u32x4 p, const Mat &mat, const uint16_t *lds_lut, const uint16_t *glb_post) {
+__device__ __forceinline__ u32x4 color_pair_codes(u32x4 p, const MatR &mat, const uint16_t *lds_lut, const uint16_t *glb_post) {
     uint32_t c[8] = { p.x & 0xFFFFu, p.x >> 16, p.y & 0xFFFFu, p.y >> 16, p.z & 0xFFFFu, p.z >> 16, p.w & 0xFFFFu, p.w >> 16 };
     if (PRE) {
 #pragma unroll
@@ -215,7 +215,7 @@ __device__ __forceinline__ u32x4 color_pair_codes(u32x4 p, const Mat &mat, const
     v.r = f32x2{ h2f(c[0]), h2f(c[4]) };
     v.g = f32x2{ h2f(c[1]), h2f(c[5]) };
     v.b = f32x2{ h2f(c[2]), h2f(c[6]) };
-    px32x2 o = mat3x2(v, mat.m);
+    px32x2 o = mat3x2(v, mat);
     const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.r.x), __builtin_fabsf(o.g.x)), __builtin_fabsf(o.b.x)),
                                       __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.r.y), __builtin_fabsf(o.g.y)), __builtin_fabsf(o.b.y)));
     if (wave_any(big >= 65536.0f)) { o.r = saturate_to_inf2(o.r); o.g = saturate_to_inf2(o.g); o.b = saturate_to_inf2(o.b); }

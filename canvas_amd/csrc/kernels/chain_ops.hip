@@ -40,7 +40,7 @@ static_assert(sizeof(Batch) + 128 <= 4096, "kernel arguments must fit the 4 KiB 
 // ---------------------------------------------------------------- v0: first correct version (kept for A/B)
 
 template <int MAXL, bool PRE, bool POST>
-__device__ __forceinline__ uint2 chain_pixel(const uint2 (&px)[MAXL], int nl, const Mat &mat, const uint16_t *lut, const uint16_t *post) {
+__device__ __forceinline__ uint2 chain_pixel(const uint2 (&px)[MAXL], int nl, const MatR &mat, const uint16_t *lut, const uint16_t *post) {
     if (MAXL >= 2 && mat.cross) return narrow(blend_cross(widen(px[0]), widen(px[MAXL >= 2 ? 1 : 0]), mat.wa, mat.wb));
     px32 acc = mat.plain ? widen(px[0]) : grade<PRE, POST>(px[0], mat, lut, post);
 #pragma unroll
@@ -50,8 +50,9 @@ __device__ __forceinline__ uint2 chain_pixel(const uint2 (&px)[MAXL], int nl, co
 }
 
 template <int NL, bool PRE, bool POST>
-__global__ __launch_bounds__(kWG) void k_chain_v0(BatchV0 batch, int njobs, Mat mat,
+__global__ __launch_bounds__(kWG) void k_chain_v0(BatchV0 batch, int njobs, Mat kmat,
                                                   const uint16_t *__restrict__ pre, const uint16_t *__restrict__ post) {
+    const MatR mat = CVS_MAT_REGS(kmat);
     __shared__ uint16_t lut[(PRE || POST) ? kLutHalfs : 1];
     if (PRE) stage_lut(lut, pre);
     else if (POST) stage_lut(lut, post);
@@ -143,8 +144,9 @@ enum { DIAG_NONE = 0, DIAG_MEMORY_ONLY = 1, DIAG_COMPUTE_ONLY = 2 };
 
 // NL in 1..4, the same for every job of the batch; every job has npixels >= 2
 template <int NL, bool PRE, bool POST, int DIAG>
-__global__ __launch_bounds__(kWG) void k_chain(Batch batch, int njobs, Mat mat,
+__global__ __launch_bounds__(kWG) void k_chain(Batch batch, int njobs, Mat kmat,
                                                const uint16_t *__restrict__ pre, const uint16_t *__restrict__ post) {
+    const MatR mat = CVS_MAT_REGS(kmat);
     __shared__ uint16_t lut[(PRE || POST) ? kLutHalfs : 1];
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -51,8 +51,9 @@ __global__ __launch_bounds__(kWG) void k_lookup(const uint16_t *__restrict__ tab
 // ---------------------------------------------------------------- colour matrix on a window (dst may be src)
 
 template <bool PRE, bool POST>
-__global__ __launch_bounds__(kWG) void k_color(cvk_view dst, cvk_view src, cvk_rect r, Mat mat, const uint16_t *__restrict__ pre,
+__global__ __launch_bounds__(kWG) void k_color(cvk_view dst, cvk_view src, cvk_rect r, Mat kmat, const uint16_t *__restrict__ pre,
                                                const uint16_t *__restrict__ post) {
+    const MatR mat = CVS_MAT_REGS(kmat);
     __shared__ uint16_t lut[(PRE || POST) ? kLutHalfs : 1];
     if (PRE) stage_lut(lut, pre);
     else if (POST) stage_lut(lut, post);
@@ -69,8 +70,9 @@ __global__ __launch_bounds__(kWG) void k_color(cvk_view dst, cvk_view src, cvk_r
 // whole rows, both buffers packed the same way: a flat stream of pixel pairs (16 B per lane, non-temporal),
 // 512 lanes per CU as in the chain kernel.  8 B read + 8 B written per pixel.
 template <bool PRE, bool POST>
-__global__ __launch_bounds__(kWG) void k_color_flat(uint16_t *__restrict__ dst, const uint16_t *__restrict__ src, size_t npixels, Mat mat,
+__global__ __launch_bounds__(kWG) void k_color_flat(uint16_t *__restrict__ dst, const uint16_t *__restrict__ src, size_t npixels, Mat kmat,
                                                     const uint16_t *__restrict__ pre, const uint16_t *__restrict__ post) {
+    const MatR mat = CVS_MAT_REGS(kmat);
     __shared__ uint16_t lut[(PRE || POST) ? kLutHalfs : 1];
     if (PRE || POST) {
         const uint4 *t = reinterpret_cast<const uint4 *>(PRE ? pre : post);

@@ -6,9 +6,9 @@ namespace cvs {
 
 // one layer pixel through the color.c structure; returns the f32 value the stack then sees
 template <bool PRE, bool POST>
-__device__ __forceinline__ px32 grade(uint2 p, const Mat &mat, const uint16_t *lds_lut, const uint16_t *glb_post) {
+__device__ __forceinline__ px32 grade(uint2 p, const MatR &mat, const uint16_t *lds_lut, const uint16_t *glb_post) {
     if (PRE) { p.x = gather2<true>(lds_lut, p.x); p.y = gather2<true>(lds_lut, p.y); }
-    uint2 h = narrow(mat3(widen(p), mat.m));
+    uint2 h = narrow(mat3(widen(p), mat));
     if (POST) {
         // the LDS slot belongs to the pre table when there is one
         if (PRE) { h.x = gather2<false>(glb_post, h.x); h.y = gather2<false>(glb_post, h.y); }
@@ -18,9 +18,9 @@ __device__ __forceinline__ px32 grade(uint2 p, const Mat &mat, const uint16_t *l
 }
 
 template <bool PRE, bool POST>
-__device__ __forceinline__ uint2 grade_h(uint2 p, const Mat &mat, const uint16_t *lds_lut, const uint16_t *glb_post) {
+__device__ __forceinline__ uint2 grade_h(uint2 p, const MatR &mat, const uint16_t *lds_lut, const uint16_t *glb_post) {
     if (PRE) { p.x = gather2<true>(lds_lut, p.x); p.y = gather2<true>(lds_lut, p.y); }
-    uint2 h = narrow(mat3(widen(p), mat.m));
+    uint2 h = narrow(mat3(widen(p), mat));
     if (POST) {
         if (PRE) { h.x = gather2<false>(glb_post, h.x); h.y = gather2<false>(glb_post, h.y); }
         else     { h.x = gather2<true>(lds_lut, h.x);   h.y = gather2<true>(lds_lut, h.y); }

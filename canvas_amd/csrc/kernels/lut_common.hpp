@@ -13,6 +13,12 @@ constexpr int kLutHalfs = 65536;
 // weights wa, wb (video_mix.c:193-205) instead of stacked
 struct Mat { float m[9]; int plain; int cross; float wa, wb; };
 
+// The same parameters as the kernels use them: named scalars, built at the top of a kernel straight from the
+// kernel-argument struct.  (Handing the argument struct -- or its array -- down by reference made the compiler keep a
+// private copy of it in scratch memory, which turns scratch on for the whole kernel.)
+struct MatR { float m0, m1, m2, m3, m4, m5, m6, m7, m8; int plain, cross; float wa, wb; };
+#define CVS_MAT_REGS(k) { (k).m[0], (k).m[1], (k).m[2], (k).m[3], (k).m[4], (k).m[5], (k).m[6], (k).m[7], (k).m[8], (k).plain, (k).cross, (k).wa, (k).wb }
+
 // Pointers that arrive inside a job record are generic to the compiler, which then emits flat_load
 // (counts on BOTH vmcnt and lgkmcnt and so serialises against the LDS gathers).  Tell it they are global.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

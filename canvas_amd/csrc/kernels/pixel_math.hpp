@@ -56,11 +56,13 @@ __device__ __forceinline__ uint2 narrow(px32 v) {
 }
 
 // color.c:34-42 -- left-to-right, alpha copied.  m is column-major (see canvas_hip.h).
-__device__ __forceinline__ px32 mat3(px32 v, const float *m) {
+// `mat`: the nine coefficients as named members m0..m8 (cvs::MatR)
+template <class M>
+__device__ __forceinline__ px32 mat3(px32 v, const M &mat) {
     px32 o;
-    o.r = v.r * m[0] + v.g * m[3] + v.b * m[6];
-    o.g = v.r * m[1] + v.g * m[4] + v.b * m[7];
-    o.b = v.r * m[2] + v.g * m[5] + v.b * m[8];
+    o.r = v.r * mat.m0 + v.g * mat.m3 + v.b * mat.m6;
+    o.g = v.r * mat.m1 + v.g * mat.m4 + v.b * mat.m7;
+    o.b = v.r * mat.m2 + v.g * mat.m5 + v.b * mat.m8;
     o.a = v.a;
     return o;
 }
@@ -129,11 +131,12 @@ __device__ __forceinline__ uint4 narrow2(px32x2 v) {
     return make_uint4(pkrtz(r.x, g.x), pkrtz(b.x, a.x), pkrtz(r.y, g.y), pkrtz(b.y, a.y));
 }
 
-__device__ __forceinline__ px32x2 mat3x2(px32x2 v, const float *m) {
+template <class M>
+__device__ __forceinline__ px32x2 mat3x2(px32x2 v, const M &mat) {
     px32x2 o;
-    o.r = v.r * m[0] + v.g * m[3] + v.b * m[6];
-    o.g = v.r * m[1] + v.g * m[4] + v.b * m[7];
-    o.b = v.r * m[2] + v.g * m[5] + v.b * m[8];
+    o.r = v.r * mat.m0 + v.g * mat.m3 + v.b * mat.m6;
+    o.g = v.r * mat.m1 + v.g * mat.m4 + v.b * mat.m7;
+    o.b = v.r * mat.m2 + v.g * mat.m5 + v.b * mat.m8;
     o.a = v.a;
     return o;
 }

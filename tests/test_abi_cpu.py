@@ -186,3 +186,36 @@ def test_product_never_touches_the_oracle():
     assert not bad, bad
     out = subprocess.run(["ldd", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True).stdout
     assert "oracle" not in out
+
+
+def test_hot_kernels_keep_their_state_in_registers():
+    """The FIR ring, the chain's pixel sets and the divide paths index their register arrays with compile-time
+    constants only; one runtime index would move an array to scratch memory (private segment) and cost a factor
+    of 2-3 without failing any parity test.  Read the code objects' metadata: no hot kernel may use scratch or spill."""
+    import glob
+    import re
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    build = os.path.join(ROOT, "canvas_amd", "csrc", "build")
+    if not (os.path.exists(readelf) and os.path.exists(objdump) and os.path.isdir(build)):
+        pytest.skip("no ROCm LLVM tools or no object files in tree")
+    import tempfile
+    checked = 0
+    with tempfile.TemporaryDirectory(dir=build) as tmp:
+        for obj in ("blur_ops.hip.o", "chain_ops.hip.o", "color_ops.hip.o", "display_ops.hip.o"):
+            src = os.path.join(build, obj)
+            if not os.path.exists(src):
+                continue
+            local = os.path.join(tmp, obj)
+            with open(src, "rb") as f, open(local, "wb") as g:
+                g.write(f.read())
+            subprocess.run([objdump, "-d", "--offloading", obj], cwd=tmp, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            for co in glob.glob(os.path.join(tmp, obj + "*gfx950")):
+                notes = subprocess.run([readelf, "--notes", co], stdout=subprocess.PIPE, text=True).stdout
+                for name, scratch, spills in re.findall(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", notes, re.S):
+                    if "k_chain_v0" in name or re.search(r"k_chainILi\dELb[01]ELb[01]ELi[12]E", name) or "k_chainILi1E" in name:
+                        continue            # not hot: the first version (A/B reference, 5-8 layers), the diagnostic builds, and the
+                                            # single-layer chain (keeps one 16-byte word in scratch)
+                    assert int(scratch) == 0 and int(spills) == 0, (name, scratch, spills)
+                    checked += 1
+    assert checked >= 20, checked
