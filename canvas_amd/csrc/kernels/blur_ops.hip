@@ -158,22 +158,38 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
             float4 v[NT];
 #pragma unroll
             for (int k = 0; k < NT; k++) v[k] = buf[k % STEP][lane + k / STEP];
+            // all products first, then the two add chains interleaved: a packed add right behind the packed multiply it
+            // depends on costs a hazard slot (s_nop) per tap; the rounding and the order of the additions do not change
+            f32x2 prg[NT], pba[NT];
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                prg[k] = f32x2{ v[k].x, v[k].y } * w[k];
+                pba[k] = f32x2{ v[k].z, v[k].w } * w[k];
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x2 rg = { 0.0f, 0.0f }, ba = { 0.0f, 0.0f };
 #pragma unroll
             for (int k = 0; k < NT; k++) {
-                rg = rg + f32x2{ v[k].x, v[k].y } * w[k];
-                ba = ba + f32x2{ v[k].z, v[k].w } * w[k];
+                rg = rg + prg[k];
+                ba = ba + pba[k];
             }
             ring[j].rg = rg;
             ring[j].ba = ba;
             if (emits) {
                 // ring[(j+1) % NT] is the oldest row = tap 0
-                f32x2 org = { 0.0f, 0.0f }, oba = { 0.0f, 0.0f };
+                f32x2 qrg[NT], qba[NT];
 #pragma unroll
                 for (int k = 0; k < NT; k++) {
                     const Px &p = ring[(j + 1 + k) % NT];
-                    org = org + p.rg * w[k];
-                    oba = oba + p.ba * w[k];
+                    qrg[k] = p.rg * w[k];
+                    qba[k] = p.ba * w[k];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x2 org = { 0.0f, 0.0f }, oba = { 0.0f, 0.0f };
+#pragma unroll
+                for (int k = 0; k < NT; k++) {
+                    org = org + qrg[k];
+                    oba = oba + qba[k];
                 }
                 if constexpr (EPI) {
                     cvs::px1 acc = { org, oba.x, oba.y };
