@@ -91,14 +91,12 @@ __device__ __forceinline__ void div3_pair(f32x2 &n0, f32x2 &n1, f32x2 &n2, f32x2
         f32x2 r = { __builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y) };
         const f32x2 nd = -d;
         r = fma2(fma2(nd, r, f32x2{ 1.0f, 1.0f }), r, r);
-        f32x2 *n[3] = { &n0, &n1, &n2 };
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const f32x2 x = *n[c];
-            f32x2 q = x * r;
-            q = fma2(fma2(nd, q, x), r, q);
-            *n[c] = fma2(fma2(nd, q, x), r, q);
-        }
+        // the three channels step by step side by side: a packed FMA right behind the one it depends on costs a hazard slot
+        f32x2 q0 = n0 * r, q1 = n1 * r, q2 = n2 * r;
+        f32x2 e0 = fma2(nd, q0, n0), e1 = fma2(nd, q1, n1), e2 = fma2(nd, q2, n2);
+        q0 = fma2(e0, r, q0); q1 = fma2(e1, r, q1); q2 = fma2(e2, r, q2);
+        e0 = fma2(nd, q0, n0); e1 = fma2(nd, q1, n1); e2 = fma2(nd, q2, n2);
+        n0 = fma2(e0, r, q0); n1 = fma2(e1, r, q1); n2 = fma2(e2, r, q2);
     } else {
         n0 = f32x2{ n0.x / d.x, n0.y / d.y };
         n1 = f32x2{ n1.x / d.x, n1.y / d.y };
