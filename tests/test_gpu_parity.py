@@ -1209,3 +1209,57 @@ def test_config4_8k_rows_against_oracle(cvs, orc):
         part = [HostFrame((0, 0, w - 1, rows - 1), np.uint16, a[sl]) for a in arrays]
         want = orc.chain_color_over(part, None)
         assert_same_f16(got[sl], want.array, "8K config 4 rows %r" % (sl,))
+
+
+def test_concurrent_callers_each_get_their_own_results(cvs, orc):
+    """SURVEY 8b threading: pulls arrive from any thread, concurrently.  Six threads (each on the library's per-thread
+    stream) hammer different entry points with their own frames -- shared state under them: the scratch pool, the tap
+    table cache, the transfer and byte tables -- and every result must still equal the oracle's."""
+    import threading
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    taps = synth.gaussian_taps(9, 1.5)
+    errors = []
+
+    def worker(seed):
+        try:
+            rng = np.random.default_rng(9000 + seed)
+            w, h = 64 + 8 * seed, 36 + 2 * seed
+            full = (0, 0, w - 1, h - 1)
+            for it in range(6):
+                layers = [synth.layer_frame(w, h, k, seed * 10 + it) for k in range(3)]
+                want_chain = orc.chain_color_over(layers, m, orc.transfer_table(0), None)
+                dl = [DeviceFrame.from_host(l) for l in layers]
+                out = DeviceFrame(full, np.uint16)
+                chain_color_over([(out, dl)], m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE)
+                got = out.download()
+                assert np.array_equal(got.array, want_chain.array), "chain"
+                # blur + halving resample (two launches, pooled f32 intermediate, cached tables)
+                want3 = _oracle_config3(orc, layers[1], (w // 2, h // 2), taps, 0.5, 0.5)
+                small = DeviceFrame((0, 0, w // 2 - 1, h // 2 - 1), np.uint16)
+                _lib.check(cvs.cvs_blur_lanczos_f16_dev(small.ref(), dl[1].ref(), f32p(taps), 9, C.c_float(0.5), C.c_float(0.5), 3, None))
+                assert_same_f16(small.download().array, want3.array, "config 3")
+                # triangle scaler on f32 frames
+                src = rand_f32_frame(rng, full)
+                t_full = (0, 0, 2 * w - 1, 2 * h - 1)
+                want_s = HostFrame(t_full, np.float32)
+                orc.lib().orc_scale_bilinear_f32(want_s.ref(), v2f(0, 0), src.ref(), v2f(0, 0), v2f(2.0, 2.0))
+                d_src, d_up = DeviceFrame.from_host(src), DeviceFrame(t_full, np.float32)
+                _lib.check(cvs.cvs_scale_bilinear_f32_dev(d_up.ref(), v2f(0, 0), d_src.ref(), v2f(0, 0), v2f(2.0, 2.0), None))
+                got_s = d_up.download()
+                assert same_window(got_s.current_window, want_s.current_window)
+                assert_same_f32(got_s.window_view(), want_s.window_view(), "scale")
+                # display bytes
+                packed = np.zeros((h, w), np.uint32)
+                want_b = np.zeros((h, w), np.uint32)
+                _lib.check(cvs.video_frame_to_bytes(packed.ctypes.data, layers[2].ref(), _lib.LUT_LINEAR_TO_SRGB, _lib.DISPLAY_RGBA8))
+                orc.lib().orc_frame_to_bytes(want_b.ctypes.data_as(C.POINTER(C.c_uint32)), layers[2].ref(), u16p(orc.transfer_table(3)), 0)
+                assert np.array_equal(packed, want_b), "bytes"
+        except Exception as e:          # noqa: BLE001 -- reported on the main thread
+            errors.append("thread %d: %r" % (seed, e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
