@@ -63,7 +63,8 @@ CVS_EXPORT int cvs_init(int device) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        snprintf(g_name, sizeof g_name, "%s (%s)", prop.name, prop.gcnArchName);
+        /* some boxes report an empty marketing name */
+        snprintf(g_name, sizeof g_name, "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD GPU", prop.gcnArchName, prop.multiProcessorCount);
     }
     g_device = device;
     pthread_mutex_unlock(&g_lock);
