@@ -61,7 +61,7 @@ def main():
         # algorithmic bytes in the f32 form these kernels work in: blur 16 r + 16 w per px; scale 16 r + 16/4 w
         out["config3"] = {"blur_ms": t_blur, "scale_ms": t_scale, "Mpx_per_s_input": px / ((t_blur + t_scale) * 1e-3) / 1e6,
                           "blur_GBps": px * 32 / (t_blur * 1e-3) / 1e9, "scale_GBps": px * 20 / (t_scale * 1e-3) / 1e9,
-                          "note": "f32 frames (the reference scales in f32); times include the host-side tap planning + table upload + sync of each pass"}
+                          "note": "blur_ms / scale_ms: f32 frames in and out, one launch each (register-window FIR kernel, taps as kernel arguments); pipeline_f16_ms: cvs_blur_lanczos_f16_dev, f16 in, f32 frame between the two launches, f16 out"}
         # the config as BASELINE states it: f16 in, f16 out, f32 in between (two fused launches)
         out16 = DeviceFrame((0, 0, w // 2 - 1, h // 2 - 1), np.uint16)
         t_pipe = timed(lib, stream, lambda: _lib.check(lib.cvs_blur_lanczos_f16_dev(out16.ref(), src16.ref(), f32p(taps), 9, C.c_float(0.5), C.c_float(0.5), 3, stream)), args.reps)
