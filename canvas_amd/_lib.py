@@ -129,6 +129,7 @@ SIGNATURES = {
     "cvs_gain_offset_f16_dev": (C.c_int, [_F16, _F16, C.c_float, C.c_float, _vp]),
     "cvs_fill_solid_f16_dev": (C.c_int, [_F16, P(box2i), P(rgba_f32), _vp]),
     "cvs_fill_solid_f32_dev": (C.c_int, [_F32, P(box2i), P(rgba_f32), _vp]),
+    "cvs_scale_bilinear_f16_dev": (C.c_int, [_F16, v2f, _F16, v2f, v2f, _vp]),
     "cvs_scale_bilinear_f32_dev": (C.c_int, [_F32, v2f, _F32, v2f, v2f, _vp]),
     "cvs_fir_blur_f32_dev": (C.c_int, [_F32, _F32, _f32p, C.c_int, _vp]),
     "coded_image_alloc": (P(coded_image), [P(C.c_int), P(C.c_int), C.c_int]),

@@ -147,16 +147,21 @@ static int triangle_table_cached(float tmin, float smin, float factor, int s0, i
                                  cvk_fir_axis *axis, int *used_lo, int *used_hi);
 
 /* one pass of video_scale.c:34-127 (axis 0) or :129-229 (axis 1) on device frames */
-static int triangle_pass(rgba_frame_f32 *target, float tmin, const rgba_frame_f32 *source, float smin, float factor, int axis, hipStream_t s) {
-    const box2i srect = source->current_window, trect = target->full_window;
+/* a frame of either pixel format, as the passes see it */
+typedef struct { void *data; box2i full, cur; int half; } any_frame;
+
+static size_t any_bytes(const any_frame *f) { return cvs_box_pixels(&f->full) * (f->half ? sizeof(rgba_f16) : sizeof(rgba_f32)); }
+
+static int triangle_pass(any_frame *target, float tmin, const any_frame *source, float smin, float factor, int axis, hipStream_t s) {
+    const box2i srect = source->cur, trect = target->full;
     const int lo = axis ? (srect.min.y > trect.min.y ? srect.min.y : trect.min.y) : (srect.min.x > trect.min.x ? srect.min.x : trect.min.x);
     const int hi = axis ? (srect.max.y < trect.max.y ? srect.max.y : trect.max.y) : (srect.max.x < trect.max.x ? srect.max.x : trect.max.x);
     const int s0 = axis ? srect.min.x : srect.min.y, s1 = axis ? srect.max.x : srect.max.y;
     const int t0 = axis ? trect.min.x : trect.min.y, t1 = axis ? trect.max.x : trect.max.y;
-    cvk_view tv = cvs_view(target->data, &target->full_window), sv = cvs_view(source->data, &source->full_window);
+    cvk_view tv = cvs_view(target->data, &target->full), sv = cvs_view(source->data, &source->full);
 
-    CVS_KERNEL(cvk_zero_f32(tv, s));
-    if (factor == 1.0f && tmin == smin) return cvs_copy_frame_alpha_f32_dev(target, source, 1.0f, s);
+    /* video_scale.c:25-32,44: the target starts as zeros (all-zero bytes are 0.0 in either format) */
+    if (any_bytes(target)) CVS_HIP(hipMemsetAsync(target->data, 0, any_bytes(target), s));
 
     /* the per-line taps depend only on the geometry, which repeats from frame to frame: planned once, kept on the
      * device; steady state is the zero fill and one gather launch, nothing synchronous */
@@ -173,41 +178,67 @@ static int triangle_pass(rgba_frame_f32 *target, float tmin, const rgba_frame_f3
         fp.t0 = used_lo; fp.t1 = used_hi; fp.lo = lo; fp.hi = hi;
         fp.ntaps = table.ntaps + first; fp.tap_src = table.src + first * (size_t)table.stride; fp.taps = table.taps + first * (size_t)table.stride;
         fp.stride = table.stride;
+        fp.in_half = source->half; fp.out_half = target->half;
         CVS_KERNEL(cvk_fir_gather(&fp, s));
     }
-    if (axis) box2i_set(&target->current_window, used_lo, lo, used_hi, hi);
-    else      box2i_set(&target->current_window, lo, used_lo, hi, used_hi);
+    if (axis) box2i_set(&target->cur, used_lo, lo, used_hi, hi);
+    else      box2i_set(&target->cur, lo, used_lo, hi, used_hi);
     return 0;
+}
+
+/* video_scale_bilinear_f32 (video_scale.c:231-286) between frames of either format: f16 sources are widened as they
+ * are read, f16 targets truncated as they are written (what the pulls around an f32 scaler node do, main.c:43-71,
+ * 105-144); the frame between the two passes is always f32.  The caller has dealt with the all-identity case. */
+static int scale_core(any_frame *target, v2f tp, const any_frame *source, v2f sp, v2f fac, hipStream_t s) {
+    if (fac.x == 1.0f && tp.x == sp.x) return triangle_pass(target, tp.y, source, sp.y, fac.y, 0, s);
+    if (fac.y == 1.0f && tp.y == sp.y) return triangle_pass(target, tp.x, source, sp.x, fac.x, 1, s);
+
+    any_frame mid;
+    memset(&mid, 0, sizeof mid);
+    const box2i *tf = &target->full, *sc = &source->cur;
+    const bool x_first = fac.x < fac.y;
+    if (x_first)
+        box2i_set(&mid.full, (int)(sp.x - (tp.x - tf->min.x) * fac.x), sc->min.y,
+                  (int)(sp.x + (tf->max.x - tp.x) * fac.x), sc->max.y);
+    else
+        box2i_set(&mid.full, sc->min.x, (int)(sp.y - (tp.y - tf->min.y) * fac.y),
+                  sc->max.x, (int)(sp.y + (tf->max.y - tp.y) * fac.y));
+    box2i_intersect(&mid.full, &mid.full, tf);
+    mid.cur = mid.full;
+    size_t n = cvs_box_pixels(&mid.full);
+    mid.data = cvs_pool_malloc(sizeof(rgba_f32) * (n ? n : 1), s);
+    if (!mid.data) return -1;
+    int rc;
+    if (x_first) { rc = triangle_pass(&mid, tp.x, source, sp.x, fac.x, 1, s); if (rc == 0) rc = triangle_pass(target, tp.y, &mid, sp.y, fac.y, 0, s); }
+    else         { rc = triangle_pass(&mid, tp.y, source, sp.y, fac.y, 0, s); if (rc == 0) rc = triangle_pass(target, tp.x, &mid, sp.x, fac.x, 1, s); }
+    cvs_pool_free(mid.data, s);
+    return rc;
 }
 
 CVS_EXPORT int cvs_scale_bilinear_f32_dev(rgba_frame_f32 *target, v2f tp, const rgba_frame_f32 *source, v2f sp, v2f fac, cvs_stream_t stream) {
     if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
     CVS_REQUIRE_INSIDE(source, target, "cvs_scale_bilinear_f32_dev");
     hipStream_t s = cvs_pick_stream(stream);
-    if (fac.x == 1.0f && tp.x == sp.x) {
-        if (fac.y == 1.0f && tp.y == sp.y) return cvs_copy_frame_alpha_f32_dev(target, source, 1.0f, s);
-        return triangle_pass(target, tp.y, source, sp.y, fac.y, 0, s);
-    }
-    if (fac.y == 1.0f && tp.y == sp.y) return triangle_pass(target, tp.x, source, sp.x, fac.x, 1, s);
+    if (fac.x == 1.0f && tp.x == sp.x && fac.y == 1.0f && tp.y == sp.y) return cvs_copy_frame_alpha_f32_dev(target, source, 1.0f, s);
+    any_frame t = { target->data, target->full_window, target->full_window, 0 };
+    const any_frame src = { source->data, source->full_window, source->current_window, 0 };
+    int rc = scale_core(&t, tp, &src, sp, fac, s);
+    target->current_window = t.cur;
+    if (rc != 0) box2i_set_empty(&target->current_window);
+    return rc;
+}
 
-    rgba_frame_f32 mid;
-    const box2i *tf = &target->full_window, *sc = &source->current_window;
-    const bool x_first = fac.x < fac.y;
-    if (x_first)
-        box2i_set(&mid.full_window, (int)(sp.x - (tp.x - tf->min.x) * fac.x), sc->min.y,
-                  (int)(sp.x + (tf->max.x - tp.x) * fac.x), sc->max.y);
-    else
-        box2i_set(&mid.full_window, sc->min.x, (int)(sp.y - (tp.y - tf->min.y) * fac.y),
-                  sc->max.x, (int)(sp.y + (tf->max.y - tp.y) * fac.y));
-    box2i_intersect(&mid.full_window, &mid.full_window, tf);
-    mid.current_window = mid.full_window;
-    size_t n = cvs_box_pixels(&mid.full_window);
-    mid.data = cvs_pool_malloc(sizeof(rgba_f32) * (n ? n : 1), s);
-    if (!mid.data) { box2i_set_empty(&target->current_window); return -1; }
-    int rc;
-    if (x_first) { rc = triangle_pass(&mid, tp.x, source, sp.x, fac.x, 1, s); if (rc == 0) rc = triangle_pass(target, tp.y, &mid, sp.y, fac.y, 0, s); }
-    else         { rc = triangle_pass(&mid, tp.y, source, sp.y, fac.y, 0, s); if (rc == 0) rc = triangle_pass(target, tp.x, &mid, sp.x, fac.x, 1, s); }
-    cvs_pool_free(mid.data, s);
+/* The same scaler between two f16 frames: the f16 pull of a scaler node whose input is a half-native source, without
+ * the widened copy of the input and the f32 copy of the output ever existing. */
+CVS_EXPORT int cvs_scale_bilinear_f16_dev(rgba_frame_f16 *target, v2f tp, const rgba_frame_f16 *source, v2f sp, v2f fac, cvs_stream_t stream) {
+    if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(source, target, "cvs_scale_bilinear_f16_dev");
+    hipStream_t s = cvs_pick_stream(stream);
+    if (fac.x == 1.0f && tp.x == sp.x && fac.y == 1.0f && tp.y == sp.y) return cvs_copy_frame_f16_dev(target, source, s);
+    any_frame t = { target->data, target->full_window, target->full_window, 1 };
+    const any_frame src = { (void *)source->data, source->full_window, source->current_window, 1 };
+    int rc = scale_core(&t, tp, &src, sp, fac, s);
+    target->current_window = t.cur;
     if (rc != 0) box2i_set_empty(&target->current_window);
     return rc;
 }

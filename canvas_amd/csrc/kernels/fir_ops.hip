@@ -22,6 +22,14 @@ __device__ __forceinline__ float4 *at(const cvk_view &v, int x, int y) {
     return reinterpret_cast<float4 *>(v.data) + (size_t)(y - v.fy0) * (size_t)v.pitch + (size_t)(x - v.fx0);
 }
 
+// a source pixel as f32: f16 frames are widened on the way in (main.c:105-144), exactly
+__device__ __forceinline__ float4 px_in(const cvk_view &v, bool half, int x, int y) {
+    const size_t i = (size_t)(y - v.fy0) * (size_t)v.pitch + (size_t)(x - v.fx0);
+    if (!half) return reinterpret_cast<const float4 *>(v.data)[i];
+    const uint2 p = reinterpret_cast<const uint2 *>(v.data)[i];
+    return make_float4(cvs::h2f(p.x & 0xFFFFu), cvs::h2f(p.x >> 16), cvs::h2f(p.y & 0xFFFFu), cvs::h2f(p.y >> 16));
+}
+
 // axis 0: lines are rows -> grid.y walks target rows, lanes walk x (coalesced both sides)
 // axis 1: lines are columns -> lanes walk target columns (each with its own tap list), grid.y walks rows
 __global__ __launch_bounds__(kBlock) void k_fir(cvk_fir_params fp) {
@@ -43,13 +51,19 @@ __global__ __launch_bounds__(kBlock) void k_fir(cvk_fir_params fp) {
     for (int k = 0; k < n; k++) {
         const int s = src[k];
         const float w = c[k];
-        const float4 v = fp.axis == 0 ? *at(fp.source, other, s) : *at(fp.source, s, other);
+        const float4 v = fp.axis == 0 ? px_in(fp.source, fp.in_half != 0, other, s) : px_in(fp.source, fp.in_half != 0, s, other);
         r = r + v.x * w;
         g = g + v.y * w;
         b = b + v.z * w;
         a = a + v.w * w;
     }
-    *(fp.axis == 0 ? at(fp.target, other, line) : at(fp.target, line, other)) = make_float4(r, g, b, a);
+    const int ox = fp.axis == 0 ? other : line, oy = fp.axis == 0 ? line : other;
+    if (fp.out_half) {       // the consumer pulls f16: truncate here (main.c:43-71) instead of in a pass of its own
+        const size_t o = (size_t)(oy - fp.target.fy0) * (size_t)fp.target.pitch + (size_t)(ox - fp.target.fx0);
+        reinterpret_cast<uint2 *>(fp.target.data)[o] = make_uint2(cvs::f2h_rz2(r, g), cvs::f2h_rz2(b, a));
+    } else {
+        *at(fp.target, ox, oy) = make_float4(r, g, b, a);
+    }
 }
 
 }  // namespace

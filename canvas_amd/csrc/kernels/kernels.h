@@ -84,6 +84,7 @@ typedef struct {
     const int *tap_src;       /* device: per target line, `stride` source line indices, ascending */
     const float *taps;        /* device: per target line, `stride` coefficients */
     int stride;
+    int in_half, out_half;    /* 0: rgba_f32 pixels, 1: rgba_f16 pixels (widened on load / truncated on store) */
 } cvk_fir_params;
 int cvk_fir_gather(const cvk_fir_params *fp, void *stream);
 int cvk_zero_f32(cvk_view v, void *stream);

@@ -271,7 +271,9 @@ static void scaler_dealloc(py_scaler *self) {
     pthread_rwlock_destroy(&self->n.lock);
     Py_TYPE(self)->tp_free((PyObject *)self);
 }
-static void scaler_render(PyObject *o, int frame_index, rgba_frame_dev *f) {     /* native: f32 */
+/* fmt: the format of BOTH the pulled input and `f`.  f32 is the node's native format; f16 is taken when the consumer
+ * wants f16 and the input is half-native (widen on load, truncate on store inside the scaler's own passes) */
+static void scaler_render_fmt(PyObject *o, int frame_index, rgba_frame_dev *f, int fmt) {
     py_scaler *self = (py_scaler *)o;
     pthread_rwlock_rdlock(&self->n.lock);                 /* released on every path (the reference leaks it at VideoScaler.c:64-69) */
     if (!self->n.source) { pthread_rwlock_unlock(&self->n.lock); box2i_set_empty(&f->current_window); return; }
@@ -291,21 +293,39 @@ static void scaler_render(PyObject *o, int frame_index, rgba_frame_dev *f) {    
         box2i_intersect(&need, &need, &rect);
         if (box2i_is_empty(&need)) { box2i_set_empty(&f->current_window); }
         else {
-            rgba_frame_dev in = scratch_like(f, CVS_FORMAT_F32, &need);
+            rgba_frame_dev in = scratch_like(f, fmt, &need);
             if (!in.data) box2i_set_empty(&f->current_window);
             else {
                 pull_dev(self->n.source, frame_index, &in);
-                rgba_frame_f32 fs = { in.data, in.full_window, in.current_window }, ft = { f->data, f->full_window, f->full_window };
-                if (cvs_scale_bilinear_f32_dev(&ft, tp, &fs, sp, fac, f->stream) != 0) box2i_set_empty(&ft.current_window);
-                f->current_window = ft.current_window;
+                if (fmt == CVS_FORMAT_F32) {
+                    rgba_frame_f32 fs = { in.data, in.full_window, in.current_window }, ft = { f->data, f->full_window, f->full_window };
+                    if (cvs_scale_bilinear_f32_dev(&ft, tp, &fs, sp, fac, f->stream) != 0) box2i_set_empty(&ft.current_window);
+                    f->current_window = ft.current_window;
+                } else {
+                    rgba_frame_f16 fs = { in.data, in.full_window, in.current_window }, ft = { f->data, f->full_window, f->full_window };
+                    if (cvs_scale_bilinear_f16_dev(&ft, tp, &fs, sp, fac, f->stream) != 0) box2i_set_empty(&ft.current_window);
+                    f->current_window = ft.current_window;
+                }
                 cvs_pool_free(in.data, f->stream);
             }
         }
     }
     pthread_rwlock_unlock(&self->n.lock);
 }
-DEFINE_NODE_VTABLE(scaler, CVS_FORMAT_F32, 0, 1)
-static void *scaler_unused[] UNUSED = { (void *)scaler_slot_16 };
+static void scaler_render(PyObject *o, int frame_index, rgba_frame_dev *f) { scaler_render_fmt(o, frame_index, f, CVS_FORMAT_F32); }     /* native: f32 */
+static void scaler_slot_dev(PyObject *self, int i, rgba_frame_dev *f) {
+    py_scaler *sc = (py_scaler *)self;
+    pthread_rwlock_rdlock(&sc->n.lock);
+    const bool half = f->format == CVS_FORMAT_F16 && half_native(sc->n.source);
+    pthread_rwlock_unlock(&sc->n.lock);
+    if (half) scaler_render_fmt(self, i, f, CVS_FORMAT_F16);
+    else node_get_frame_dev(self, i, f, CVS_FORMAT_F32, scaler_render);
+}
+static void scaler_slot_32(PyObject *self, int i, rgba_frame_f32 *f) { node_get_frame_host32(self, i, f, CVS_FORMAT_F32, scaler_render); }
+static video_frame_source_funcs scaler_funcs = {
+    .flags = VIDEO_SOURCE_FLAG_DEVICE, .get_frame_32 = (video_get_frame_32_func)scaler_slot_32,
+    .get_frame_dev = (video_get_frame_dev_func)scaler_slot_dev };
+static PyObject *scaler_capsule;
 static PyObject *scaler_source(py_scaler *self, PyObject *dummy) { return node1_get_source(&self->n, NULL); }
 static PyMethodDef scaler_methods[] = {
     { "source", (PyCFunction)scaler_source, METH_NOARGS, "Gets the video source." },

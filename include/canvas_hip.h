@@ -275,6 +275,8 @@ CVS_EXPORT int cvs_color_matrix_f16_to_dev(rgba_frame_f16 *out, const rgba_frame
 CVS_EXPORT int cvs_gain_offset_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *in, float gain, float offset, cvs_stream_t s);
 CVS_EXPORT int cvs_fill_solid_f16_dev(rgba_frame_f16 *frame, const box2i *window, const rgba_f32 *color, cvs_stream_t s);
 CVS_EXPORT int cvs_fill_solid_f32_dev(rgba_frame_f32 *frame, const box2i *window, const rgba_f32 *color, cvs_stream_t s);
+/* the f16 twin: widen on load, truncate on store (the f16 pull of a scaler node over a half-native source) */
+CVS_EXPORT int cvs_scale_bilinear_f16_dev(rgba_frame_f16 *target, v2f tp, const rgba_frame_f16 *source, v2f sp, v2f fac, cvs_stream_t stream);
 CVS_EXPORT int cvs_scale_bilinear_f32_dev(rgba_frame_f32 *target, v2f target_point, const rgba_frame_f32 *source, v2f source_point, v2f factors, cvs_stream_t s);
 /* separable FIR blur at factor 1 (absent from the reference; defined in DESIGN.md) and the Lanczos
  * gather resampler built on filter_createLanczos */

@@ -1263,3 +1263,20 @@ def test_concurrent_callers_each_get_their_own_results(cvs, orc):
     for t in threads:
         t.join(120)
     assert not errors, errors
+
+
+@pytest.mark.parametrize("tfull,sfull,scur,tp,sp,fac", SCALE_CASES)
+def test_scale_bilinear_f16_twin(cvs, orc, tfull, sfull, scur, tp, sp, fac):
+    """The scaler between two f16 frames = widen -> video_scale_bilinear_f32 -> truncate, without those two copies."""
+    rng = np.random.default_rng(56)
+    src = rand_f16_frame(rng, sfull, scur)
+    src32 = HostFrame(sfull, np.float32, orc.half_to_float(src.array), scur)
+    want32 = HostFrame(tfull, np.float32)
+    orc.lib().orc_scale_bilinear_f32(want32.ref(), v2f(*tp), src32.ref(), v2f(*sp), v2f(*fac))
+    want = HostFrame(tfull, np.uint16, orc.float_to_half(want32.array), want32.current_window)
+    d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(tfull, np.uint16)
+    _lib.check(cvs.cvs_scale_bilinear_f16_dev(d_out.ref(), v2f(*tp), d_src.ref(), v2f(*sp), v2f(*fac), None))
+    got = d_out.download()
+    assert same_window(got.current_window, want.current_window)
+    if not want.current_window.is_empty():
+        assert_same_f16(got.window_view(), want.window_view(), "f16 scale %r" % (fac,))

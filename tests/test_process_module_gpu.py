@@ -395,3 +395,19 @@ def test_crossfade_of_half_native_clips_is_one_launch(process, bt, orc):
     # the ends of the fade are single pulls (video_mix.c:46-71)
     almost(fade.get_frame_f16(0, window).pixel(5, 5), clip_a.get_frame_f16(0, window).pixel(5, 5), 7)
     almost(fade.get_frame_f16(10, window).pixel(5, 5), clip_b.get_frame_f16(10, window).pixel(5, 5), 7)
+
+
+def test_scaler_over_a_half_native_clip_pulled_as_f16(process, bt, orc):
+    """VideoScaler over a half-native input, f16 pull: the scaler's own passes widen and truncate; values equal the
+    f32 pull truncated."""
+    clip = process.VideoGainOffsetFilter(process.SolidColorVideoSource(process.LerpFunc((0.1, 0.2, 0.3, 1.0), (0.9, 0.8, 0.7, 0.5), 10),
+                                                                        bt.box2i(2, 1, 40, 30)), gain=1.25, offset=0.03125)
+    scaler = process.VideoScaler(clip, target_point=(0, 0), source_point=(0, 0), scale_factors=(2.0, 1.5), source_rect=bt.box2i(0, 0, 63, 35))
+    window = bt.box2i(0, 0, 99, 59)
+    for frame in (0, 4):
+        got16, got32 = scaler.get_frame_f16(frame, window), scaler.get_frame_f32(frame, window)
+        assert got16.current_window == got32.current_window and not got16.current_window.empty()
+        cw = got16.current_window
+        for x, y in [(cw.min.x, cw.min.y), (cw.max.x, cw.max.y), ((cw.min.x + cw.max.x) // 2, (cw.min.y + cw.max.y) // 2), (cw.min.x + 1, cw.max.y - 1)]:
+            want = orc.float_to_half(np.array(got32.pixel(x, y), np.float32))
+            assert np.array_equal(orc.float_to_half(np.array(got16.pixel(x, y), np.float32)), want), (frame, x, y)
