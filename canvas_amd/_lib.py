@@ -91,6 +91,7 @@ SIGNATURES = {
     "cvs_device_count": (C.c_int, []),
     "cvs_current_device": (C.c_int, []),
     "cvs_last_error": (C.c_char_p, []),
+    "cvs_set_log_handler": (None, [C.c_void_p, C.c_void_p]),
     "cvs_device_name": (C.c_char_p, []),
     "cvs_compute_units": (C.c_int, []),
     "cvs_malloc": (_vp, [C.c_size_t]),

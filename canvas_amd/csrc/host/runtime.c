@@ -22,12 +22,24 @@ static __thread char t_error[512];
 static __thread hipStream_t t_stream;
 static __thread int t_stream_device = -1;
 
+/* where diagnostics go besides cvs_last_error(): stderr unless the host installs a handler (the reference routes its
+ * g_log domains to Python's logging the same way, src/process/main.c:272-329) */
+static cvs_log_func g_log_handler;
+static void *g_log_user;
+
+CVS_EXPORT void cvs_set_log_handler(cvs_log_func handler, void *user_data) {
+    __atomic_store_n(&g_log_user, user_data, __ATOMIC_RELEASE);
+    __atomic_store_n(&g_log_handler, handler, __ATOMIC_RELEASE);
+}
+
 void cvs_set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(t_error, sizeof t_error, fmt, ap);
     va_end(ap);
-    fprintf(stderr, "canvas_hip: %s\n", t_error);
+    cvs_log_func handler = __atomic_load_n(&g_log_handler, __ATOMIC_ACQUIRE);
+    if (handler) handler("fluggo.media.cprocess", CVS_LOG_WARNING, t_error, __atomic_load_n(&g_log_user, __ATOMIC_ACQUIRE));
+    else fprintf(stderr, "canvas_hip: %s\n", t_error);
 }
 
 void cvs_clear_error(void) { t_error[0] = 0; }

@@ -306,9 +306,36 @@ static PyObject *mod_time_get_frame(PyObject *self, PyObject *args, PyObject *kw
     return PyLong_FromLongLong(t1 - t0);
 }
 
+/* enable_glib_logging(enable): the reference bridges its glib log domains to Python's `logging` (main.c:171-191,
+ * 272-329).  The library's diagnostics take the same road here: logging.getLogger(domain).warning(message), from
+ * whichever thread the failure happened on (the handler takes the GIL itself). */
+static PyObject *g_get_logger;
+
+static void python_log_handler(const char *domain, int level, const char *message, void *user_data) {
+    if (!Py_IsInitialized()) { fprintf(stderr, "%s: %s\n", domain, message); return; }
+    PyGILState_STATE g = PyGILState_Ensure();
+    PyObject *type, *value, *tb;
+    PyErr_Fetch(&type, &value, &tb);                      /* a failing call may already carry a Python error */
+    PyObject *logger = g_get_logger ? PyObject_CallFunction(g_get_logger, "s", domain) : NULL;
+    PyObject *r = logger ? PyObject_CallMethod(logger, level == CVS_LOG_ERROR ? "error" : level == CVS_LOG_INFO ? "info" : "warning", "s", message) : NULL;
+    if (!r) { PyErr_Clear(); fprintf(stderr, "%s: %s\n", domain, message); }
+    Py_XDECREF(r);
+    Py_XDECREF(logger);
+    PyErr_Restore(type, value, tb);
+    PyGILState_Release(g);
+}
+
 static PyObject *mod_enable_logging(PyObject *self, PyObject *args) {
-    /* the reference bridges glib log domains to `logging` (main.c:171-191, 272-329); this library
-     * reports through cvs_last_error() and stderr, so there is nothing to switch */
+    int enable = 1;
+    if (!PyArg_ParseTuple(args, "|p", &enable)) return NULL;
+    if (enable && !g_get_logger) {
+        PyObject *logging = PyImport_ImportModule("logging");
+        if (!logging) return NULL;
+        g_get_logger = PyObject_GetAttrString(logging, "getLogger");
+        Py_DECREF(logging);
+        if (!g_get_logger) return NULL;
+    }
+    cvs_set_log_handler(enable ? python_log_handler : NULL, NULL);
     Py_RETURN_NONE;
 }
 
@@ -324,7 +351,7 @@ static PyMethodDef module_methods[] = {
     { "get_time_frame", mod_get_time_frame, METH_VARARGS, "get_time_frame(rate, time_ns) -> frame" },
     { "time_get_frame", (PyCFunction)mod_time_get_frame, METH_VARARGS | METH_KEYWORDS,
       "time_get_frame(source, min_frame, max_frame[, data_window=(0,0,4095,4095)]) -> elapsed ns" },
-    { "enable_glib_logging", mod_enable_logging, METH_VARARGS, "No-op: errors are reported through last_error() and stderr." },
+    { "enable_glib_logging", mod_enable_logging, METH_VARARGS, "enable_glib_logging(enable=True): route the library's diagnostics to logging.getLogger('fluggo.media.cprocess') instead of stderr." },
     { "create_offscreen_gl_context", mod_gl_stub, METH_VARARGS, "No-op: there is no GL path." },
     { "set_current_gl_context", mod_gl_stub, METH_VARARGS, "No-op: there is no GL path." },
     { "check_context_supported", mod_check_context, METH_VARARGS, "True when a HIP device is available." },

@@ -219,7 +219,14 @@ enum { CVS_LUT_NONE = -1, CVS_LUT_REC709_TO_LINEAR_SCENE = 0, CVS_LUT_REC709_TO_
 CVS_EXPORT int cvs_init(int device);                   /* 0 on success; idempotent per device */
 CVS_EXPORT int cvs_device_count(void);
 CVS_EXPORT int cvs_current_device(void);
-CVS_EXPORT const char *cvs_last_error(void);           /* thread-local, "" when none */
+CVS_EXPORT const char *cvs_last_error(void);
+/* Diagnostics: every failure message (the text of cvs_last_error) is also handed to the installed handler, or written to
+ * stderr when there is none.  The handler may be called from any thread that calls into the library.  The reference
+ * logs through g_log in per-file domains (e.g. src/cprocess/video_reconstruct.c:23-24); here the domain is always
+ * "fluggo.media.cprocess". */
+enum { CVS_LOG_ERROR = 0, CVS_LOG_WARNING = 1, CVS_LOG_INFO = 2 };
+typedef void (*cvs_log_func)(const char *domain, int level, const char *message, void *user_data);
+CVS_EXPORT void cvs_set_log_handler(cvs_log_func handler, void *user_data);           /* thread-local, "" when none */
 CVS_EXPORT const char *cvs_device_name(void);
 CVS_EXPORT int cvs_compute_units(void);
 

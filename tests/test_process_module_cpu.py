@@ -200,6 +200,27 @@ def test_animation_func_drives_filter_parameters(process):
     assert hasattr(mix, "_frame_function_funcs")
 
 
+def test_diagnostics_reach_python_logging(process):
+    """enable_glib_logging (main.c:171-191, 272-329): library diagnostics arrive at logging.getLogger(domain)."""
+    import io
+    import logging
+    from fluggo.media.basetypes import box2i
+    stream = io.StringIO()
+    handler = logging.StreamHandler(stream)
+    logger = logging.getLogger("fluggo.media.cprocess")
+    logger.addHandler(handler)
+    try:
+        process.enable_glib_logging(True)
+        if process.check_context_supported():
+            pytest.skip("a GPU is present: nothing fails here")
+        frame = process.SolidColorVideoSource((1, 0, 0, 1)).get_frame_f16(0, box2i(0, 0, 3, 3))
+        assert frame.current_window.empty()
+        assert "no CPU path" in stream.getvalue()
+    finally:
+        process.enable_glib_logging(False)
+        logger.removeHandler(handler)
+
+
 def test_pull_queue_worker_count(process):
     process.VideoPullQueue(workers=4)
     for bad in (0, 17):
