@@ -21,13 +21,14 @@ constexpr int kBlock = 256;
 __device__ __forceinline__ float4 *at(const cvk_view &v, int x, int y) {
     return reinterpret_cast<float4 *>(v.data) + (size_t)(y - v.fy0) * (size_t)v.pitch + (size_t)(x - v.fx0);
 }
-__device__ __forceinline__ bool holds(const cvk_view &v, int x, int y) {
-    return x >= v.fx0 && x <= v.fx1 && y >= v.fy0 && y <= v.fy1;
-}
-// A lone-region read can fall outside the source's CURRENT window (the reference then copies
-// whatever the buffer holds).  It must still stay inside the allocation.
+// A lone-region read can fall outside the source's CURRENT window -- even outside its row (the `left` selector
+// quirk, video_mix.c:137,265): the reference indexes `row[x]` with whatever x the region has, i.e. it reads
+// data + (y - y0) * pitch + (x - x0) wherever that lands.  Inside the allocation that is a neighbouring row's pixel,
+// reproduced here; outside it the reference reads foreign memory, here the pixel is zero and nothing faults.
 __device__ __forceinline__ float4 fetch(const cvk_view &v, int x, int y) {
-    return holds(v, x, y) ? *at(v, x, y) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long off = (long long)(y - v.fy0) * (long long)v.pitch + (long long)(x - v.fx0);
+    const long long n = (long long)v.pitch * (long long)(v.fy1 - v.fy0 + 1);
+    return (off >= 0 && off < n) ? reinterpret_cast<const float4 *>(v.data)[off] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 enum Action { LEAVE, ZERO, COPY_P, COPY_Q, BLEND };

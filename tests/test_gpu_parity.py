@@ -1280,3 +1280,101 @@ def test_scale_bilinear_f16_twin(cvs, orc, tfull, sfull, scur, tp, sp, fac):
     assert same_window(got.current_window, want.current_window)
     if not want.current_window.is_empty():
         assert_same_f16(got.window_view(), want.window_view(), "f16 scale %r" % (fac,))
+
+
+# ------------------------------------------------------------------ randomized window sweeps (region walks of video_mix.c / copy / scale)
+
+def _random_window(rng, full, allow_empty=True, inside=None):
+    """A random window inside `full` (and inside `inside`, when given: the reference's mixers write a lone frame's whole
+    row span, video_mix.c:146-149, so an input window reaching beyond the OUTPUT buffer makes the reference itself
+    write out of bounds -- its callers always pull inputs into temps that share the output's full window)."""
+    if inside is not None:
+        full = (max(full[0], inside[0]), max(full[1], inside[1]), min(full[2], inside[2]), min(full[3], inside[3]))
+        if full[2] < full[0] or full[3] < full[1]:
+            return (0, 0, -1, -1)
+    x0, y0, x1, y1 = full
+    if allow_empty and rng.random() < 0.08:
+        return (0, 0, -1, -1)
+    ax, bx = sorted(int(v) for v in rng.integers(x0, x1 + 1, 2))
+    ay, by = sorted(int(v) for v in rng.integers(y0, y1 + 1, 2))
+    return (ax, ay, bx, by)
+
+
+def test_mix_over_and_cross_random_windows(cvs, orc):
+    """300 random (out, upper) window pairs per mixer on the device twins, frames with different buffers and origins,
+    whole-buffer compare: the 9-region walk, the `left` selector quirk (video_mix.c:137,265) and every copy / zero /
+    blend region land where the reference puts them."""
+    rng = np.random.default_rng(20261003)
+    for case in range(300):
+        out_full = (int(rng.integers(-6, 3)), int(rng.integers(-4, 3)), int(rng.integers(14, 30)), int(rng.integers(8, 16)))
+        b_full = (int(rng.integers(-6, 3)), int(rng.integers(-4, 3)), int(rng.integers(14, 30)), int(rng.integers(8, 16)))
+        mix = float(rng.choice([0.0, 0.25, 0.5, 1.0, 1.5, -0.5]))
+        # over, in place on `out`
+        out = rand_f32_frame(rng, out_full, _random_window(rng, out_full), "mixed")
+        upper = rand_f32_frame(rng, b_full, _random_window(rng, b_full, inside=out_full), "mixed")
+        want = out.copy()
+        d_out, d_up = DeviceFrame.from_host(out), DeviceFrame.from_host(upper)
+        _lib.check(cvs.cvs_mix_over_f32_dev(d_out.ref(), d_up.ref(), C.c_float(mix), None))
+        orc.lib().orc_mix_over_f32(want.ref(), upper.ref(), C.c_float(mix))
+        got = d_out.download()
+        assert same_window(got.current_window, want.current_window), ("over", case)
+        assert_same_f32(got.array, want.array, "over, random case %d" % case)
+        # cross into a third buffer
+        a = rand_f32_frame(rng, b_full, _random_window(rng, b_full, inside=out_full), "mixed")
+        target = rand_f32_frame(rng, out_full)
+        want = target.copy()
+        d_t, d_a = DeviceFrame.from_host(target), DeviceFrame.from_host(a)
+        _lib.check(cvs.cvs_mix_cross_f32_dev(d_t.ref(), d_a.ref(), d_up.ref(), C.c_float(mix), None))
+        orc.lib().orc_mix_cross_f32(want.ref(), a.ref(), upper.ref(), C.c_float(mix))
+        got = d_t.download()
+        assert same_window(got.current_window, want.current_window), ("cross", case)
+        assert_same_f32(got.array, want.array, "cross, random case %d" % case)
+
+
+def test_copy_and_convert_random_windows(cvs, orc):
+    rng = np.random.default_rng(20261004)
+    for case in range(200):
+        out_full = (int(rng.integers(-6, 3)), int(rng.integers(-4, 3)), int(rng.integers(10, 30)), int(rng.integers(6, 16)))
+        in_full = (int(rng.integers(-6, 3)), int(rng.integers(-4, 3)), int(rng.integers(10, 30)), int(rng.integers(6, 16)))
+        src = rand_f16_frame(rng, in_full, _random_window(rng, in_full))
+        out = rand_f16_frame(rng, out_full)
+        want = out.copy()
+        d_src, d_out = DeviceFrame.from_host(src), DeviceFrame.from_host(out)
+        _lib.check(cvs.cvs_copy_frame_f16_dev(d_out.ref(), d_src.ref(), None))
+        orc.lib().orc_copy_frame_f16(want.ref(), src.ref())
+        got = d_out.download()
+        assert same_window(got.current_window, want.current_window), case
+        assert_same_f16(got.array, want.array, "copy, random case %d" % case)
+        alpha = float(rng.choice([1.0, 0.5, 0.0, 2.0]))
+        src32 = rand_f32_frame(rng, in_full, _random_window(rng, in_full), "mixed")
+        out32 = rand_f32_frame(rng, out_full)
+        want32 = out32.copy()
+        d_s32, d_o32 = DeviceFrame.from_host(src32), DeviceFrame.from_host(out32)
+        _lib.check(cvs.cvs_copy_frame_alpha_f32_dev(d_o32.ref(), d_s32.ref(), C.c_float(alpha), None))
+        orc.lib().orc_copy_frame_alpha_f32(want32.ref(), src32.ref(), C.c_float(alpha))
+        got32 = d_o32.download()
+        assert same_window(got32.current_window, want32.current_window), case
+        if not want32.current_window.is_empty():
+            assert_same_f32(got32.window_view(), want32.window_view(), "copy alpha, random case %d" % case)
+
+
+def test_scale_bilinear_random_geometry(cvs, orc):
+    """120 random scaler set-ups (factors on both sides of 1, fractional points, source windows inside their buffers)
+    against the oracle: window reported, and every pixel inside it."""
+    rng = np.random.default_rng(20261005)
+    for case in range(120):
+        sfull = (int(rng.integers(-4, 3)), int(rng.integers(-3, 3)), int(rng.integers(10, 28)), int(rng.integers(6, 18)))
+        tfull = (int(rng.integers(-4, 3)), int(rng.integers(-3, 3)), int(rng.integers(10, 40)), int(rng.integers(6, 30)))
+        scur = _random_window(rng, sfull, allow_empty=False)
+        fac = (float(rng.choice([0.25, 0.5, 0.75, 1.0, 1.5, 2.0, 3.0])), float(rng.choice([0.25, 0.5, 0.8, 1.0, 1.25, 2.0, 4.0])))
+        tp = (float(rng.choice([0.0, 0.5, 2.25])), float(rng.choice([0.0, 1.0, 3.5])))
+        sp = (float(rng.choice([0.0, 0.75, 2.0])), float(rng.choice([0.0, 0.5, 1.0])))
+        src = rand_f32_frame(rng, sfull, scur)
+        want = HostFrame(tfull, np.float32)
+        orc.lib().orc_scale_bilinear_f32(want.ref(), v2f(*tp), src.ref(), v2f(*sp), v2f(*fac))
+        d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(tfull, np.float32)
+        _lib.check(cvs.cvs_scale_bilinear_f32_dev(d_out.ref(), v2f(*tp), d_src.ref(), v2f(*sp), v2f(*fac), None))
+        got = d_out.download()
+        assert same_window(got.current_window, want.current_window), (case, fac, tp, sp, got.current_window.tuple(), want.current_window.tuple())
+        if not want.current_window.is_empty():
+            assert_same_f32(got.window_view(), want.window_view(), "scale, random case %d %r" % (case, fac))
