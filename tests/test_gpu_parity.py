@@ -1378,3 +1378,62 @@ def test_scale_bilinear_random_geometry(cvs, orc):
         assert same_window(got.current_window, want.current_window), (case, fac, tp, sp, got.current_window.tuple(), want.current_window.tuple())
         if not want.current_window.is_empty():
             assert_same_f32(got.window_view(), want.window_view(), "scale, random case %d %r" % (case, fac))
+
+
+def test_fir_blur_random_geometry(cvs, orc):
+    """150 random blurs: tap counts 1..16 (odd ones up to 15 take the register-window kernel, the rest the tiled
+    gather kernel), source windows inside their buffers, targets with other origins, f32 and f16 entry points."""
+    rng = np.random.default_rng(20261006)
+    for case in range(150):
+        sfull = (int(rng.integers(-5, 3)), int(rng.integers(-4, 3)), int(rng.integers(20, 300)), int(rng.integers(8, 50)))
+        tfull = (int(rng.integers(-5, 3)), int(rng.integers(-4, 3)), int(rng.integers(20, 300)), int(rng.integers(8, 50)))
+        scur = _random_window(rng, sfull)
+        ntaps = int(rng.integers(1, 17))
+        taps = rng.uniform(-0.2, 1.0, ntaps).astype(np.float32)
+        taps /= np.float32(taps.sum())
+        src = rand_f32_frame(rng, sfull, scur, lo=-0.5, hi=1.5)
+        want = HostFrame(tfull, np.float32)
+        orc.lib().orc_fir_blur_f32(want.ref(), src.ref(), f32p(taps), ntaps)
+        d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(tfull, np.float32)
+        _lib.check(cvs.cvs_fir_blur_f32_dev(d_out.ref(), d_src.ref(), f32p(taps), ntaps, None))
+        got = d_out.download()
+        assert same_window(got.current_window, want.current_window), (case, ntaps)
+        if not want.current_window.is_empty():
+            assert_same_f32(got.window_view(), want.window_view(), "blur f32, random case %d, %d taps" % (case, ntaps))
+        # the f16 entry point on the truncated source
+        from canvas_amd.synth import truncate_to_half
+        src16 = HostFrame(sfull, np.uint16, truncate_to_half(src.array), scur)
+        wide = HostFrame(sfull, np.float32, orc.half_to_float(src16.array), scur)
+        want32 = HostFrame(tfull, np.float32)
+        orc.lib().orc_fir_blur_f32(want32.ref(), wide.ref(), f32p(taps), ntaps)
+        want16 = HostFrame(tfull, np.uint16, orc.float_to_half(want32.array), want32.current_window)
+        d_src16, d_out16 = DeviceFrame.from_host(src16), DeviceFrame(tfull, np.uint16)
+        _lib.check(cvs.cvs_fir_blur_f16_dev(d_out16.ref(), d_src16.ref(), f32p(taps), ntaps, None))
+        got16 = d_out16.download()
+        assert same_window(got16.current_window, want16.current_window), (case, ntaps)
+        if not want16.current_window.is_empty():
+            assert_same_f16(got16.window_view(), want16.window_view(), "blur f16, random case %d, %d taps" % (case, ntaps))
+
+
+def test_lanczos_random_geometry(cvs, orc):
+    """80 random resamples: factor 1/2 on both axes (uniform taps: register-window kernel) and other factors (per-line
+    taps: tiled gather kernel, or two passes when a footprint does not fit), kernel sizes 1..4, windows with origins."""
+    rng = np.random.default_rng(20261007)
+    for case in range(80):
+        sfull = (int(rng.integers(-5, 3)), int(rng.integers(-4, 3)), int(rng.integers(20, 200)), int(rng.integers(8, 60)))
+        tfull = (int(rng.integers(-3, 3)), int(rng.integers(-3, 3)), int(rng.integers(8, 120)), int(rng.integers(6, 40)))
+        scur = _random_window(rng, sfull, allow_empty=False)
+        if rng.random() < 0.5:
+            fx = fy = 0.5
+        else:
+            fx, fy = float(rng.choice([0.25, 0.4, 0.5, 1.0, 1.5, 2.0])), float(rng.choice([0.3, 0.5, 0.75, 1.0, 2.0]))
+        ksize = int(rng.integers(1, 5))
+        src = rand_f32_frame(rng, sfull, scur, lo=-0.5, hi=1.5)
+        want = HostFrame(tfull, np.float32)
+        orc.lib().orc_resample_lanczos_f32(want.ref(), src.ref(), C.c_float(fx), C.c_float(fy), ksize)
+        d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(tfull, np.float32)
+        _lib.check(cvs.cvs_resample_lanczos_f32_dev(d_out.ref(), d_src.ref(), C.c_float(fx), C.c_float(fy), ksize, None))
+        got = d_out.download()
+        assert same_window(got.current_window, want.current_window), (case, fx, fy, ksize)
+        if not want.current_window.is_empty():
+            assert_same_f32(got.window_view(), want.window_view(), "lanczos, random case %d (%g, %g, k=%d)" % (case, fx, fy, ksize))
