@@ -1437,3 +1437,30 @@ def test_lanczos_random_geometry(cvs, orc):
         assert same_window(got.current_window, want.current_window), (case, fx, fy, ksize)
         if not want.current_window.is_empty():
             assert_same_f32(got.window_view(), want.window_view(), "lanczos, random case %d (%g, %g, k=%d)" % (case, fx, fy, ksize))
+
+
+def test_chain_and_crossfade_on_arbitrary_half_codes(cvs, orc):
+    """Layers made of uniformly random 16-bit patterns -- every exponent class, subnormals, Inf, NaN, both signs, in
+    colour and in alpha: the band test of the shared-reciprocal divide, the Inf saturation of the truncation and the
+    zero-alpha rule all get inputs no image would give them.  (NaN payloads and zero signs are folded, as everywhere.)"""
+    rng = np.random.default_rng(20261008)
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    w, h = 128, 33
+    full = (0, 0, w - 1, h - 1)
+    for case in range(12):
+        nl = int(rng.integers(2, 5))
+        layers = [HostFrame(full, np.uint16, rng.integers(0, 65536, (h, w, 4), dtype=np.uint16)) for _ in range(nl)]
+        if case % 3 == 0:
+            layers[0].array[..., 3] = 0x3C00                     # an opaque base now and then
+        dl = [DeviceFrame.from_host(l) for l in layers]
+        out = DeviceFrame(full, np.uint16)
+        for matrix, pre, table in [(m, _lib.LUT_REC709_TO_LINEAR_SCENE, orc.transfer_table(0)), (None, _lib.LUT_NONE, None)]:
+            want = orc.chain_color_over(layers, matrix, table, None)
+            chain_color_over([(out, dl)], matrix, pre, _lib.LUT_NONE)
+            _lib.check(cvs.cvs_stream_sync(None))
+            assert cvs.cvs_chain_last_was_fused() == 1
+            assert_same_f16(out.download().array, want.array, "arbitrary codes, case %d, %d layers, matrix %s" % (case, nl, matrix is not None))
+        mix = float(rng.choice([0.0, 0.3, 0.5, 1.0]))
+        want = _oracle_cross_f16(orc, full, layers[0], layers[1], mix)
+        _lib.check(cvs.cvs_mix_cross_f16_dev(out.ref(), dl[0].ref(), dl[1].ref(), C.c_float(mix), None))
+        assert_same_f16(out.download().array, want.array, "arbitrary codes, crossfade, case %d" % case)
