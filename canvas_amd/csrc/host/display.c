@@ -69,7 +69,7 @@ CVS_EXPORT int video_frame_to_bytes(void *dst_host, const rgba_frame_f16 *frame,
     const size_t pitch = (size_t)(frame->full_window.max.x - frame->full_window.min.x + 1);
     const rgba_f16 *first = frame->data + (size_t)(w->min.y - frame->full_window.min.y) * pitch;
     const size_t in_bytes = cvs_box_pixels(&band.full_window) * sizeof(rgba_f16), out_bytes = cvs_box_pixels(w) * 4;
-    cvs_staged din = { NULL, 0 }, dout = { NULL, 0 };
+    cvs_staged din = { 0 }, dout = { 0 };
     int rc = cvs_stage_in(&din, first, in_bytes, 1, s);
     if (rc == 0) rc = cvs_stage_in(&dout, NULL, out_bytes, 0, s);
     if (rc == 0) { band.data = din.dev; rc = cvs_frame_to_bytes_dev(dout.dev, &band, pre_lut, mode, s); }

@@ -80,8 +80,9 @@ static inline bool cvs_box_contains(const box2i *outer, const box2i *inner) {
 
 /* ---- staging of host frames for the reference-named entry points (H2D -> kernels -> D2H) */
 typedef struct {
-    void *dev;            /* device copy of the whole full_window buffer */
+    void *dev;            /* device copy of the whole full_window buffer (from the stream-ordered pool) */
     size_t bytes;
+    hipStream_t stream;   /* the stream it was staged on: the block goes back to the pool on it */
 } cvs_staged;
 
 int cvs_stage_in(cvs_staged *st, const void *host, size_t bytes, int upload, hipStream_t s);

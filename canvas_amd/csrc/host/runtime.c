@@ -114,8 +114,15 @@ CVS_EXPORT void *cvs_malloc(size_t bytes) {
     return p;
 }
 
+/* Work enqueued on any of the library's (non-blocking) streams may still be reading or writing the block: wait for
+ * the device first.  hipFree alone was observed to return memory that a queued kernel then faulted on. */
+static void free_when_idle(void *dev) {
+    (void)hipDeviceSynchronize();
+    (void)hipFree(dev);
+}
+
 CVS_EXPORT void cvs_free(void *dev) {
-    if (dev && cvs_enter() == 0) hipFree(dev);
+    if (dev && cvs_enter() == 0) free_when_idle(dev);
 }
 
 CVS_EXPORT int cvs_memcpy_h2d(void *dev, const void *host, size_t bytes, cvs_stream_t s) {
@@ -214,14 +221,14 @@ CVS_EXPORT void cvs_pool_free(void *dev, cvs_stream_t s) {
             break;
         }
     pthread_mutex_unlock(&g_lock);
-    hipFree(dev);
+    free_when_idle(dev);
 }
 
 CVS_EXPORT void cvs_pool_trim(void) {
     if (cvs_enter() != 0) return;
     pthread_mutex_lock(&g_lock);
     for (int i = 0; i < POOL_SLOTS; i++)
-        if (g_pool[i].ptr && !g_pool[i].live) { hipFree(g_pool[i].ptr); g_pool_parked -= g_pool[i].bytes; g_pool[i].ptr = NULL; }
+        if (g_pool[i].ptr && !g_pool[i].live) { free_when_idle(g_pool[i].ptr); g_pool_parked -= g_pool[i].bytes; g_pool[i].ptr = NULL; }
     pthread_mutex_unlock(&g_lock);
 }
 
@@ -260,8 +267,10 @@ CVS_EXPORT float cvs_event_elapsed_ms(cvs_event_t start, cvs_event_t stop) {
 int cvs_stage_in(cvs_staged *st, const void *host, size_t bytes, int upload, hipStream_t s) {
     st->dev = NULL;
     st->bytes = bytes;
+    st->stream = s;
     if (!bytes) return 0;
-    CVS_HIP(hipMalloc(&st->dev, bytes));
+    st->dev = cvs_pool_malloc(bytes, s);
+    if (!st->dev) return -1;
     if (upload) CVS_HIP(hipMemcpyAsync(st->dev, host, bytes, hipMemcpyHostToDevice, s));
     return 0;
 }
@@ -273,7 +282,7 @@ int cvs_stage_out(cvs_staged *st, void *host, hipStream_t s) {
 }
 
 void cvs_stage_free(cvs_staged *st) {
-    if (st->dev) hipFree(st->dev);
+    if (st->dev) cvs_pool_free(st->dev, st->stream);      /* stream-ordered: whatever is still queued on it finishes first */
     st->dev = NULL;
 }
 

@@ -1464,3 +1464,44 @@ def test_chain_and_crossfade_on_arbitrary_half_codes(cvs, orc):
         want = _oracle_cross_f16(orc, full, layers[0], layers[1], mix)
         _lib.check(cvs.cvs_mix_cross_f16_dev(out.ref(), dl[0].ref(), dl[1].ref(), C.c_float(mix), None))
         assert_same_f16(out.download().array, want.array, "arbitrary codes, crossfade, case %d" % case)
+
+
+def test_pointwise_ops_on_arbitrary_bit_patterns(cvs, orc):
+    """mix_over / mix_cross / copy_alpha on uniformly random f32 bit patterns, gain/offset, colour matrix and the
+    conversions on uniformly random half codes: NaNs, infinities, denormals and signed zeros everywhere."""
+    rng = np.random.default_rng(20261009)
+    full = (0, 0, 95, 40)
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    for case in range(8):
+        bits = lambda: rng.integers(0, 2 ** 32, (41, 96, 4), dtype=np.uint32).view(np.float32)      # noqa: E731
+        a, b = HostFrame(full, np.float32, bits()), HostFrame(full, np.float32, bits())
+        for mix in (1.0, 0.4):
+            want = a.copy()
+            orc.lib().orc_mix_over_f32(want.ref(), b.ref(), C.c_float(mix))
+            d_a, d_b = DeviceFrame.from_host(a), DeviceFrame.from_host(b)
+            _lib.check(cvs.cvs_mix_over_f32_dev(d_a.ref(), d_b.ref(), C.c_float(mix), None))
+            assert_same_f32(d_a.download().array, want.array, "over on raw bits, case %d" % case)
+            want = HostFrame(full, np.float32)
+            orc.lib().orc_mix_cross_f32(want.ref(), a.ref(), b.ref(), C.c_float(mix))
+            d_o, d_a2 = DeviceFrame(full, np.float32), DeviceFrame.from_host(a)
+            _lib.check(cvs.cvs_mix_cross_f32_dev(d_o.ref(), d_a2.ref(), d_b.ref(), C.c_float(mix), None))
+            assert_same_f32(d_o.download().array, want.array, "cross on raw bits, case %d" % case)
+        codes = HostFrame(full, np.uint16, rng.integers(0, 65536, (41, 96, 4), dtype=np.uint16))
+        d_c = DeviceFrame.from_host(codes)
+        # gain / offset
+        want16, out16 = HostFrame(full, np.uint16), DeviceFrame(full, np.uint16)
+        orc.lib().orc_gain_offset_f16(want16.ref(), codes.ref(), C.c_float(1.75), C.c_float(-0.125))
+        _lib.check(cvs.cvs_gain_offset_f16_dev(out16.ref(), d_c.ref(), C.c_float(1.75), C.c_float(-0.125), None))
+        assert_same_f16(out16.download().array, want16.array, "gain/offset on raw codes")
+        # colour matrix with both tables
+        want16 = codes.copy()
+        orc.lib().orc_color_matrix_f16(want16.ref(), f32p(m), u16p(orc.transfer_table(0)), u16p(orc.transfer_table(2)))
+        _lib.check(cvs.cvs_color_matrix_f16_to_dev(out16.ref(), d_c.ref(), f32p(m), 0, 2, None))
+        assert_same_f16(out16.download().array, want16.array, "colour matrix on raw codes")
+        # widen, narrow of raw bits
+        wide = DeviceFrame(full, np.float32)
+        _lib.check(cvs.cvs_frame_f16_to_f32_dev(wide.ref(), d_c.ref(), None))
+        assert_same_f32(wide.download().array, orc.half_to_float(codes.array), "widen raw codes")
+        d_a3 = DeviceFrame.from_host(a)
+        _lib.check(cvs.cvs_frame_f32_to_f16_dev(out16.ref(), d_a3.ref(), None))
+        assert_same_f16(out16.download().array, orc.float_to_half(a.array), "narrow raw bits")
