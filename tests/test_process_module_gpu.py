@@ -411,3 +411,54 @@ def test_scaler_over_a_half_native_clip_pulled_as_f16(process, bt, orc):
         for x, y in [(cw.min.x, cw.min.y), (cw.max.x, cw.max.y), ((cw.min.x + cw.max.x) // 2, (cw.min.y + cw.max.y) // 2), (cw.min.x + 1, cw.max.y - 1)]:
             want = orc.float_to_half(np.array(got32.pixel(x, y), np.float32))
             assert np.array_equal(orc.float_to_half(np.array(got16.pixel(x, y), np.float32)), want), (frame, x, y)
+
+
+def test_random_graphs_f16_pull_equals_truncated_f32_pull(process, bt, orc):
+    """Differential fuzz of the fused f16 paths (crossfade, workspace stack, gain) against the node-by-node f32 path:
+    for 60 random graphs of full-window nodes, an f16 pull must equal the f32 pull truncated -- that is what
+    video_get_frame_f16 does to an f32 node's output (main.c:43-71), whichever route the pixels took."""
+    rng = random.Random(20261010)
+    window = bt.box2i(0, 0, 47, 26)
+
+    def colour():
+        return (rng.random(), rng.random(), rng.random(), rng.choice([1.0, 1.0, rng.random(), 0.0]))
+
+    def leaf():
+        solid = process.SolidColorVideoSource(process.LerpFunc(colour(), colour(), 10))
+        return process.VideoGainOffsetFilter(solid, gain=rng.choice([1.0, 0.5, 1.5]), offset=rng.choice([0.0, 0.0625])) if rng.random() < 0.7 else solid
+
+    def node(depth):
+        if depth == 0 or rng.random() < 0.25:
+            return leaf()
+        kind = rng.choice(["gain", "mix", "workspace", "pass", "sequence"])
+        if kind == "gain":
+            return process.VideoGainOffsetFilter(node(depth - 1), gain=rng.uniform(0.2, 2.0), offset=rng.uniform(-0.1, 0.1))
+        if kind == "mix":
+            return process.VideoMixFilter(node(depth - 1), node(depth - 1), rng.choice([0.0, 1.0, rng.random(), process.LerpFunc((0,), (1,), 10)]))
+        if kind == "workspace":
+            ws = process.VideoWorkspace()
+            for z in range(rng.randint(1, 4)):
+                ws.add(source=node(depth - 1), x=0, length=20, z=rng.randint(-3, 3), offset=rng.randint(0, 3))
+            return ws
+        if kind == "pass":
+            return process.VideoPassThroughFilter(node(depth - 1), offset=rng.randint(-2, 2))
+        seq = process.VideoSequence()
+        for _ in range(rng.randint(1, 3)):
+            seq.append((node(depth - 1), rng.randint(0, 3), rng.randint(3, 8)))
+        return seq
+
+    for case in range(60):
+        graph = node(3)
+        for frame in (0, 4):
+            f16, f32 = graph.get_frame_f16(frame, window), graph.get_frame_f32(frame, window)
+            assert f16.current_window == f32.current_window, (case, frame)
+            if f16.current_window.empty():
+                continue
+            cw = f16.current_window
+            for _ in range(25):
+                x, y = rng.randint(cw.min.x, cw.max.x), rng.randint(cw.min.y, cw.max.y)
+                want = orc.float_to_half(np.array(f32.pixel(x, y), np.float32))
+                got = orc.float_to_half(np.array(f16.pixel(x, y), np.float32))
+                # fold zero signs and NaNs the way tests/util.py does
+                same = np.array_equal(got, want) or all((g == w) or ((g & 0x7FFF) == 0 and (w & 0x7FFF) == 0) or ((g & 0x7FFF) > 0x7C00 and (w & 0x7FFF) > 0x7C00) for g, w in zip(got, want))
+                assert same, (case, frame, x, y, got, want)
