@@ -278,3 +278,19 @@ def test_extension_links_only_the_library_not_the_oracle():
     for f in glob.glob(os.path.join(ROOT, "canvas_amd", "pyext", "*.[ch]")):
         assert "orc_" not in open(f).read()
 
+
+
+def test_reference_own_frame_function_tests_run_unmodified(process):
+    """Where the reference tree is mounted (this container, not the GPU box): its own unittest file for frame
+    functions, loaded as it is and run against THIS module -- LerpFunc and AnimationFunc need no pixels."""
+    import importlib.util
+    import unittest
+    path = "/root/reference/tests/process/frame_func.py"
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present")
+    spec = importlib.util.spec_from_file_location("reference_frame_func_tests", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.process is process                       # it imported fluggo.media.process from this repo
+    result = unittest.TextTestRunner(stream=open(os.devnull, "w")).run(unittest.defaultTestLoader.loadTestsFromModule(mod))
+    assert result.testsRun >= 3 and result.wasSuccessful(), (result.failures, result.errors)
