@@ -96,6 +96,10 @@ SIGNATURES = {
     "cvs_compute_units": (C.c_int, []),
     "cvs_malloc": (_vp, [C.c_size_t]),
     "cvs_free": (None, [_vp]),
+    "cvs_graph_begin": (C.c_int, [_vp]),
+    "cvs_graph_end": (_vp, [_vp]),
+    "cvs_graph_launch": (C.c_int, [_vp, _vp]),
+    "cvs_graph_destroy": (None, [_vp]),
     "cvs_pool_malloc": (_vp, [C.c_size_t, _vp]),
     "cvs_pool_free": (None, [_vp, _vp]),
     "cvs_pool_trim": (None, []),

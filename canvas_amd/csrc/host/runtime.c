@@ -204,9 +204,19 @@ CVS_EXPORT void *cvs_pool_malloc(size_t bytes, cvs_stream_t s) {
     return p;
 }
 
+/* ---- graph capture state of the calling thread (see cvs_graph_begin below) */
+#define GRAPH_BLOCKS 64
+static __thread struct { int active, overflow; hipStream_t stream; void *blocks[GRAPH_BLOCKS]; int n; } t_capture;
+
 CVS_EXPORT void cvs_pool_free(void *dev, cvs_stream_t s) {
     if (!dev || cvs_enter() != 0) return;
     hipStream_t st = cvs_pick_stream(s);
+    if (t_capture.active && st == t_capture.stream) {
+        /* the captured kernels will use this block at every replay: it stays out of the pool, owned by the graph */
+        if (t_capture.n < GRAPH_BLOCKS) t_capture.blocks[t_capture.n++] = dev;
+        else t_capture.overflow = 1;
+        return;
+    }
     pthread_mutex_lock(&g_lock);
     for (int i = 0; i < POOL_SLOTS; i++)
         if (g_pool[i].ptr == dev) {
@@ -230,6 +240,66 @@ CVS_EXPORT void cvs_pool_trim(void) {
     for (int i = 0; i < POOL_SLOTS; i++)
         if (g_pool[i].ptr && !g_pool[i].live) { free_when_idle(g_pool[i].ptr); g_pool_parked -= g_pool[i].bytes; g_pool[i].ptr = NULL; }
     pthread_mutex_unlock(&g_lock);
+}
+
+/* ---- HIP graphs: a launch-bound sequence (a node graph on small frames is a dozen 10-20 us kernels) recorded once
+ * and replayed with one submission.  Everything between begin and end must be device-frame entry points on the
+ * capturing stream, called from the capturing thread, and must have run once before (so that tables, occupancy
+ * figures and pool blocks exist: nothing may allocate or synchronise while a stream is capturing).  Scratch blocks
+ * the sequence takes from the pool belong to the graph until it is destroyed.  Frame pointers and parameters are
+ * baked in; the CONTENTS of the frames are whatever they hold at replay time. */
+typedef struct { hipGraph_t graph; hipGraphExec_t exec; void *blocks[GRAPH_BLOCKS]; int n; hipStream_t stream; } cvs_graph;
+
+CVS_EXPORT int cvs_graph_begin(cvs_stream_t s) {
+    if (cvs_enter() != 0) return -1;
+    if (t_capture.active) { cvs_set_error("graph capture: already capturing on this thread"); return -1; }
+    hipStream_t st = cvs_pick_stream(s);
+    CVS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed));
+    memset(&t_capture, 0, sizeof t_capture);
+    t_capture.active = 1;
+    t_capture.stream = st;
+    return 0;
+}
+
+CVS_EXPORT cvs_graph_t cvs_graph_end(cvs_stream_t s) {
+    if (cvs_enter() != 0 || !t_capture.active) { cvs_set_error("graph capture: not capturing"); return NULL; }
+    hipStream_t st = t_capture.stream;
+    t_capture.active = 0;
+    hipGraph_t graph = NULL;
+    hipError_t e = hipStreamEndCapture(st, &graph);
+    cvs_graph *g = (e == hipSuccess && graph && !t_capture.overflow) ? calloc(1, sizeof *g) : NULL;
+    if (g) {
+        g->graph = graph;
+        e = hipGraphInstantiate(&g->exec, graph, NULL, NULL, 0);
+        if (e != hipSuccess) { free(g); g = NULL; }
+    }
+    if (!g) {
+        cvs_set_error("graph capture failed: %s", t_capture.overflow ? "too many scratch blocks" : hipGetErrorString(e));
+        if (graph) hipGraphDestroy(graph);
+        for (int i = 0; i < t_capture.n; i++) cvs_pool_free(t_capture.blocks[i], st);     /* not capturing any more: back to the pool */
+        return NULL;
+    }
+    memcpy(g->blocks, t_capture.blocks, sizeof(void *) * (size_t)t_capture.n);
+    g->n = t_capture.n;
+    g->stream = st;
+    return g;
+}
+
+CVS_EXPORT int cvs_graph_launch(cvs_graph_t graph, cvs_stream_t s) {
+    cvs_graph *g = graph;
+    if (cvs_enter() != 0 || !g) return -1;
+    CVS_HIP(hipGraphLaunch(g->exec, cvs_pick_stream(s)));
+    return 0;
+}
+
+CVS_EXPORT void cvs_graph_destroy(cvs_graph_t graph) {
+    cvs_graph *g = graph;
+    if (!g || cvs_enter() != 0) return;
+    (void)hipDeviceSynchronize();                 /* a replay may still be running */
+    hipGraphExecDestroy(g->exec);
+    hipGraphDestroy(g->graph);
+    for (int i = 0; i < g->n; i++) cvs_pool_free(g->blocks[i], g->stream);
+    free(g);
 }
 
 CVS_EXPORT cvs_event_t cvs_event_create(void) {

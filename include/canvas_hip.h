@@ -234,6 +234,16 @@ CVS_EXPORT void *cvs_malloc(size_t bytes);
 CVS_EXPORT void cvs_free(void *dev);
 /* recycled scratch for per-frame intermediates (no device sync on free, unlike hipFree); a block
  * handed to a different stream than it was last used on waits for that stream first */
+/* HIP graphs: record a sequence of device-frame calls on a stream once, replay it with one submission (worth it when
+ * the sequence is launch-bound: many short kernels on small frames).  Rules: capturing thread = calling thread; only
+ * `cvs_*_dev` entry points on the capturing stream in between; the same sequence must have run once before (tables,
+ * pool blocks); frame pointers and parameters are baked in, frame CONTENTS are read at replay time; scratch blocks the
+ * sequence took from the pool stay with the graph until cvs_graph_destroy. */
+typedef void *cvs_graph_t;
+CVS_EXPORT int cvs_graph_begin(cvs_stream_t stream);
+CVS_EXPORT cvs_graph_t cvs_graph_end(cvs_stream_t stream);          /* NULL on failure */
+CVS_EXPORT int cvs_graph_launch(cvs_graph_t graph, cvs_stream_t stream);
+CVS_EXPORT void cvs_graph_destroy(cvs_graph_t graph);
 CVS_EXPORT void *cvs_pool_malloc(size_t bytes, cvs_stream_t s);
 CVS_EXPORT void cvs_pool_free(void *dev, cvs_stream_t s);
 CVS_EXPORT void cvs_pool_trim(void);

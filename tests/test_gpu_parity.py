@@ -1505,3 +1505,79 @@ def test_pointwise_ops_on_arbitrary_bit_patterns(cvs, orc):
         d_a3 = DeviceFrame.from_host(a)
         _lib.check(cvs.cvs_frame_f32_to_f16_dev(out16.ref(), d_a3.ref(), None))
         assert_same_f16(out16.download().array, orc.float_to_half(a.array), "narrow raw bits")
+
+
+# ------------------------------------------------------------------ HIP graph capture of launch-bound sequences
+
+def test_graph_capture_replays_a_node_by_node_stack(cvs, orc):
+    """A ragged three-layer stack takes the node-by-node path: a dozen short kernels and three pooled scratch frames.
+    Recorded once as a HIP graph, replayed on changing layer CONTENTS: every replay equals the oracle."""
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    rng = np.random.default_rng(77001)
+    full = (0, 0, 95, 53)
+    wins = [full, (5, 3, 60, 40), (40, 2, 95, 30)]            # see test_chain_ragged_windows for the choice
+    layers = [rand_f16_frame(rng, full, w, alpha="one" if i == 0 else "rand") for i, w in enumerate(wins)]
+    dl = [DeviceFrame.from_host(l) for l in layers]
+    out = DeviceFrame(full, np.uint16)
+    stream = cvs.cvs_stream_create()
+    chain_color_over([(out, dl)], m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE, stream)       # warm: tables, pool blocks
+    _lib.check(cvs.cvs_stream_sync(stream))
+    assert cvs.cvs_chain_last_was_fused() == 0
+    _lib.check(cvs.cvs_graph_begin(stream))
+    chain_color_over([(out, dl)], m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE, stream)
+    graph = cvs.cvs_graph_end(stream)
+    assert graph, _lib.last_error()
+    try:
+        for replay in range(3):
+            fresh = [rand_f16_frame(rng, full, w, alpha="one" if i == 0 else "rand") for i, w in enumerate(wins)]
+            for d, f in zip(dl, fresh):
+                d.upload(f.array, stream)
+            cvs.cvs_memset(out.ptr, 0x11, out.nbytes, stream)
+            _lib.check(cvs.cvs_graph_launch(graph, stream))
+            _lib.check(cvs.cvs_stream_sync(stream))
+            want = orc.chain_color_over(fresh, m, orc.transfer_table(0), None)
+            got = out.download()
+            x0, y0, x1, y1 = want.current_window.tuple()
+            assert_same_f16(got.array[y0:y1 + 1, x0:x1 + 1], want.array[y0:y1 + 1, x0:x1 + 1], "graph replay %d" % replay)
+        # other work on the same stream between replays does not disturb the graph's own scratch
+        other = DeviceFrame(full, np.uint16)
+        chain_color_over([(other, dl)], m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE, stream)
+        _lib.check(cvs.cvs_graph_launch(graph, stream))
+        _lib.check(cvs.cvs_stream_sync(stream))
+        assert np.array_equal(other.download().array[y0:y1 + 1, x0:x1 + 1], out.download().array[y0:y1 + 1, x0:x1 + 1])
+    finally:
+        cvs.cvs_graph_destroy(graph)
+        cvs.cvs_stream_destroy(stream)
+    # capture state is per thread and exclusive
+    assert cvs.cvs_graph_end(None) is None
+    _lib.check(cvs.cvs_graph_begin(None))
+    assert cvs.cvs_graph_begin(None) != 0
+    empty = cvs.cvs_graph_end(None)
+    cvs.cvs_graph_destroy(empty)
+
+
+def test_graph_capture_of_the_config5_frame(cvs, orc):
+    from canvas_amd.stream import GraphStream
+    from tests.util import oracle_graph
+    w, h = 160, 90
+    g = GraphStream(w, h, ring=1)
+    stream = cvs.cvs_stream_create()
+    g.render(0, stream)
+    _lib.check(cvs.cvs_stream_sync(stream))
+    _lib.check(cvs.cvs_graph_begin(stream))
+    out = g.render(0, stream)
+    graph = cvs.cvs_graph_end(stream)
+    assert graph, _lib.last_error()
+    try:
+        for frame in (3, 4):
+            inputs = GraphStream.host_inputs(w, h, frame)
+            g.slots[0]["src"].upload(inputs[0].array, stream)
+            for o, f in zip(g.slots[0]["over"], inputs[1:]):
+                o.upload(f.array, stream)
+            _lib.check(cvs.cvs_graph_launch(graph, stream))
+            _lib.check(cvs.cvs_stream_sync(stream))
+            want = oracle_graph(orc, inputs, g.matrix, orc.transfer_table(0), None, g.taps)
+            assert_same_f16(out.download().array, want.array, "config 5 frame %d through a graph" % frame)
+    finally:
+        cvs.cvs_graph_destroy(graph)
+        cvs.cvs_stream_destroy(stream)
