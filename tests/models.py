@@ -82,3 +82,140 @@ def over_model(lower, lower_win, upper, upper_win, full, mix):
     out[only_u, 3] = (upper[only_u, 3] * mix).astype(f32)
     out[neither] = 0
     return out, outer
+
+
+# ---------------------------------------------------------------- more independent statements (full windows unless said otherwise)
+
+F32 = np.float32
+
+
+def _div_or_zero(num, den):
+    with np.errstate(divide="ignore", invalid="ignore"):
+        q = (num / den).astype(F32)
+    return np.where(den != 0, q, F32(0))
+
+
+def cross_model(a, b, mix_b):
+    """video_mix.c:193-205 on whole (H, W, 4) f32 arrays: weights 1 - m and m, un-premultiplied normalisation."""
+    mix_b = F32(min(max(mix_b, 0.0), 1.0))
+    mix_a = F32(F32(1.0) - mix_b)
+    aa, ab = (a[..., 3] * mix_a).astype(F32), (b[..., 3] * mix_b).astype(F32)
+    alpha = (aa + ab).astype(F32)
+    out = np.zeros_like(a)
+    for c in range(3):
+        num = ((a[..., c] * aa).astype(F32) + (b[..., c] * ab).astype(F32)).astype(F32)
+        out[..., c] = _div_or_zero(num, alpha)
+    out[..., 3] = alpha
+    out[alpha == 0] = 0
+    return out
+
+
+def gain_offset_model(codes, gain, offset):
+    """video_filter.c:34-39 as the library defines its rounding: widen, c * gain + offset in two f32 steps, truncate."""
+    v = h2f_ieee(codes)
+    out = v.copy()
+    with np.errstate(invalid="ignore", over="ignore"):
+        for c in range(3):
+            out[..., c] = ((v[..., c] * F32(gain)).astype(F32) + F32(offset)).astype(F32)
+    return f2h_rz_model(out)
+
+
+def bytes_model(codes, ramp, pre, premultiplied_argb):
+    """widget_gl.c:291-307 / writeVideo.c:328-340 (bytes r,g,b,a) and RgbaFrameF16.c:114-149 (premultiplied ARGB32)."""
+    c = codes if pre is None else pre[codes]
+    r, g, b, a = (ramp[c[..., k]].astype(np.uint32) for k in range(4))
+    if not premultiplied_argb:
+        return r | (g << 8) | (b << 16) | (a << 24)
+    return (a << 24) | ((((r * a) >> 8) & 0xFF) << 16) | ((((g * a) >> 8) & 0xFF) << 8) | (((b * a) >> 8) & 0xFF)
+
+
+def _fir_pass(src, valid, taps_for_line, axis):
+    """One gather pass along `axis` (0: rows, 1: columns) over a whole array.  taps_for_line(t) -> [(source index, weight)]
+    ascending; `valid` marks the source lines that exist (others are skipped taps).  Sums start at 0.0f."""
+    n = src.shape[axis]
+    out = np.zeros_like(src)
+    for t in range(n):
+        acc = np.zeros_like(np.take(src, 0, axis=axis))
+        for s, w in taps_for_line(t):
+            if 0 <= s < n and valid[s]:
+                acc = (acc + (np.take(src, s, axis=axis) * F32(w)).astype(F32)).astype(F32)
+        if axis == 0:
+            out[t] = acc
+        else:
+            out[:, t] = acc
+    return out
+
+
+def blur_model(src, taps):
+    """Separable FIR on a whole frame whose window is the whole frame: centre ntaps // 2, x pass then y pass."""
+    c = len(taps) // 2
+    lines = lambda t: [(t - c + k, taps[k]) for k in range(len(taps))]          # noqa: E731
+    h = _fir_pass(src, np.ones(src.shape[1], bool), lines, 1)
+    return _fir_pass(h, np.ones(src.shape[0], bool), lines, 0)
+
+
+def lanczos_model(src, tsize, factor_x, factor_y, kernel_size, tap_generator):
+    """Gather resample of a whole frame to tsize = (w, h), origin 0 on both sides: per target line the taps of
+    tap_generator(factor, kernel_size, frac(t / factor)) -> (taps, centre), x pass then y pass."""
+    def resample(a, n_out, factor, axis):
+        n_in = a.shape[axis]
+        shape = list(a.shape)
+        shape[axis] = n_out
+        out = np.zeros(shape, F32)
+        for t in range(n_out):
+            centre_f = F32(F32(t) / F32(factor))
+            centre = int(np.floor(centre_f))
+            taps, tc = tap_generator(float(factor), kernel_size, float(F32(centre_f - F32(centre))))
+            acc = np.zeros_like(np.take(a, 0, axis=axis))
+            for k, w in enumerate(taps):
+                s = centre - tc + k
+                if 0 <= s < n_in:
+                    acc = (acc + (np.take(a, s, axis=axis) * F32(w)).astype(F32)).astype(F32)
+            if axis == 0:
+                out[t] = acc
+            else:
+                out[:, t] = acc
+        return out
+    return resample(resample(src, tsize[0], factor_x, 1), tsize[1], factor_y, 0)
+
+
+def dv_reconstruct_model(y, cb, cr, lut, triangle):
+    """video_reconstruct.c:50-137 on whole planes (480x720, 480x180, 480x180) -> half codes (480, 720, 4); the frame's
+    row 0 is picture line 0 here (the caller places it at y = -1).  triangle = (taps, centre) of filter_createTriangle(4, 0)."""
+    taps, centre = triangle
+    cbf = ((cb.astype(F32) - F32(128)) / F32(224)).astype(F32)
+    crf = ((cr.astype(F32) - F32(128)) / F32(224)).astype(F32)
+    pb, pr = np.zeros((480, 720), F32), np.zeros((480, 720), F32)
+    for xs in range(180):                                  # scatter in ascending sample order, like the reference
+        for k, w in enumerate(taps):
+            i = xs * 4 - centre + k
+            if 0 <= i < 720:
+                pb[:, i] = (pb[:, i] + (cbf[:, xs] * F32(w)).astype(F32)).astype(F32)
+                pr[:, i] = (pr[:, i] + (crf[:, xs] * F32(w)).astype(F32)).astype(F32)
+    yf = ((y.astype(F32) - F32(16)) / F32(219)).astype(F32)
+    m = [[1.0, 0.0, 1.5748], [1.0, -0.187324, -0.468124], [1.0, 1.8556, 0.0]]
+    out = np.zeros((480, 720, 4), F32)
+    for c in range(3):
+        out[..., c] = (((yf * F32(m[c][0])).astype(F32) + (pb * F32(m[c][1])).astype(F32)).astype(F32) + (pr * F32(m[c][2])).astype(F32)).astype(F32)
+    out[..., 3] = 1
+    return lut[f2h_rz_model(out)]
+
+
+def dv_subsample_model(codes, lut, triangle):
+    """video_subsample.c:99-187 on a whole (480, 720, 4) frame of half codes -> (Y, Cb, Cr) planes.
+    triangle = (taps, centre) of filter_createTriangle(1/4, 0).  (uint8)float = truncate to int32, keep the low byte."""
+    taps, centre = triangle
+    v = h2f_ieee(lut[codes])
+    def dot(row):
+        return (((v[..., 0] * F32(row[0])).astype(F32) + (v[..., 1] * F32(row[1])).astype(F32)).astype(F32) + (v[..., 2] * F32(row[2])).astype(F32)).astype(F32)
+    low = lambda f: (f.astype(np.int64) & 0xFF).astype(np.uint8)         # noqa: E731
+    yy = low(((dot((0.2126, 0.7152, 0.0722)) * F32(219)).astype(F32) + F32(16)).astype(F32))
+    pb, pr = dot((-0.114572, -0.385428, 0.5)), dot((0.5, -0.454153, -0.045847))
+    cb, cr = np.zeros((480, 180), F32), np.zeros((480, 180), F32)
+    for tx in range(180):
+        for k, w in enumerate(taps):
+            sx = tx * 4 - centre + k
+            if 0 <= sx < 720:
+                cb[:, tx] = (cb[:, tx] + (pb[:, sx] * F32(w)).astype(F32)).astype(F32)
+                cr[:, tx] = (cr[:, tx] + (pr[:, sx] * F32(w)).astype(F32)).astype(F32)
+    return yy, low(((cb * F32(224)).astype(F32) + F32(128)).astype(F32)), low(((cr * F32(224)).astype(F32) + F32(128)).astype(F32))

@@ -334,3 +334,76 @@ def test_chain_equals_node_by_node(orc):
         orc.lib().orc_mix_over_f32(acc.ref(), g.ref(), C.c_float(1.0))
     assert np.array_equal(got.array, orc.float_to_half(acc.array))
     assert got.current_window.tuple() == full
+
+
+# ---------------------------------------------------------------- second statements of the remaining operations
+# The reference holds no test for these; the C oracle and the numpy models in tests/models.py were
+# written separately from the same source lines, in different forms (row loops against whole-array expressions).
+
+def _canon(a):
+    from tests.util import canon_f16, canon_f32
+    return canon_f32(a) if a.dtype == np.float32 else canon_f16(a)
+
+
+def test_crossfade_matches_model(orc):
+    from tests.models import cross_model
+    rng = np.random.default_rng(301)
+    full = (0, 0, 40, 21)
+    for mix in (0.0, 0.3, 0.5, 1.0, 1.7):
+        a = rng.uniform(-0.5, 1.5, (22, 41, 4)).astype(np.float32)
+        b = rng.uniform(-0.5, 1.5, (22, 41, 4)).astype(np.float32)
+        a[..., 3] = rng.choice([0.0, 1.0, 0.4], (22, 41)).astype(np.float32)
+        b[..., 3] = rng.choice([0.0, 1.0, 0.7], (22, 41)).astype(np.float32)
+        out = HostFrame(full, np.float32)
+        orc.lib().orc_mix_cross_f32(out.ref(), HostFrame(full, np.float32, a).ref(), HostFrame(full, np.float32, b).ref(), C.c_float(mix))
+        assert np.array_equal(_canon(out.array), _canon(cross_model(a, b, mix))), mix
+
+
+def test_gain_offset_and_bytes_match_models(orc):
+    from tests.models import bytes_model, gain_offset_model
+    rng = np.random.default_rng(302)
+    full = (0, 0, 63, 35)
+    codes = rng.integers(0, 65536, (36, 64, 4), dtype=np.uint16)
+    src, out = HostFrame(full, np.uint16, codes), HostFrame(full, np.uint16)
+    orc.lib().orc_gain_offset_f16(out.ref(), src.ref(), C.c_float(1.75), C.c_float(-0.125))
+    assert np.array_equal(_canon(out.array), _canon(gain_offset_model(codes, 1.75, -0.125)))
+    ramp = orc.gamma45_ramp()
+    for table, mode in [(None, 0), (orc.transfer_table(3), 0), (None, 1), (orc.transfer_table(3), 1)]:
+        packed = np.zeros((36, 64), np.uint32)
+        orc.lib().orc_frame_to_bytes(packed.ctypes.data_as(C.POINTER(C.c_uint32)), src.ref(),
+                                     None if table is None else table.ctypes.data_as(C.POINTER(C.c_uint16)), mode)
+        assert np.array_equal(packed, bytes_model(codes, ramp, table, mode == 1))
+
+
+def test_blur_and_lanczos_match_models(orc):
+    from tests.models import blur_model, lanczos_model
+    rng = np.random.default_rng(303)
+    src = rng.uniform(-0.5, 1.5, (23, 37, 4)).astype(np.float32)
+    frame = HostFrame((0, 0, 36, 22), np.float32, src)
+    for ntaps in (9, 4, 1):
+        taps = rng.uniform(-0.2, 1.0, ntaps).astype(np.float32)
+        out = HostFrame((0, 0, 36, 22), np.float32)
+        orc.lib().orc_fir_blur_f32(out.ref(), frame.ref(), taps.ctypes.data_as(C.POINTER(C.c_float)), ntaps)
+        assert np.array_equal(_canon(out.array), _canon(blur_model(src, taps))), ntaps
+    for fx, fy, tsize in [(0.5, 0.5, (19, 12)), (2.0, 1.5, (60, 30)), (0.4, 1.0, (15, 23))]:
+        out = HostFrame((0, 0, tsize[0] - 1, tsize[1] - 1), np.float32)
+        orc.lib().orc_resample_lanczos_f32(out.ref(), frame.ref(), C.c_float(fx), C.c_float(fy), 3)
+        want = lanczos_model(src, tsize, fx, fy, 3, orc.fir_lanczos)
+        assert np.array_equal(_canon(out.array), _canon(want)), (fx, fy)
+
+
+def test_dv_edge_matches_models(orc):
+    from tests.models import dv_reconstruct_model, dv_subsample_model
+    rng = np.random.default_rng(304)
+    planes = [np.ascontiguousarray(rng.integers(0, 256, (480, s), dtype=np.uint8)) for s in (720, 180, 180)]
+    frame = HostFrame((0, -1, 719, 478), np.uint16)
+    orc.lib().orc_reconstruct_dv(frame.ref(), (C.c_void_p * 3)(*[p.ctypes.data for p in planes]), (C.c_int * 3)(720, 180, 180))
+    want = dv_reconstruct_model(planes[0], planes[1], planes[2], orc.transfer_table(0), orc.fir_triangle(4.0, 0.0))
+    assert np.array_equal(_canon(frame.array), _canon(want))
+    codes = rng.integers(0, 0x7C00, (480, 720, 4), dtype=np.uint16)          # finite, non-negative halfs
+    src = HostFrame((0, -1, 719, 478), np.uint16, codes.copy())
+    back = [np.zeros((480, s), np.uint8) for s in (720, 180, 180)]
+    orc.lib().orc_subsample_dv((C.c_void_p * 3)(*[p.ctypes.data for p in back]), (C.c_int * 3)(720, 180, 180), src.ref())
+    yy, cb, cr = dv_subsample_model(codes, orc.transfer_table(2), orc.fir_triangle(0.25, 0.0))
+    assert np.array_equal(back[0], yy) and np.array_equal(back[1], cb) and np.array_equal(back[2], cr)
+    assert np.array_equal(src.array, orc.transfer_table(2)[codes])          # the input was encoded in place
