@@ -219,3 +219,78 @@ def dv_subsample_model(codes, lut, triangle):
                 cb[:, tx] = (cb[:, tx] + (pb[:, sx] * F32(w)).astype(F32)).astype(F32)
                 cr[:, tx] = (cr[:, tx] + (pr[:, sx] * F32(w)).astype(F32)).astype(F32)
     return yy, low(((cb * F32(224)).astype(F32) + F32(128)).astype(F32)), low(((cr * F32(224)).astype(F32) + F32(128)).astype(F32))
+
+
+def scale_model(src, sfull, scur, tfull, tp, sp, fac, triangle):
+    """video_scale.c:231-286 in whole-array form.  src: (H, W, 4) f32 over sfull; scur: the source's current window;
+    returns (array over tfull, window).  triangle(sub, offset) -> (taps, centre) (filter_createTriangle).
+    Statement: per axis, target lines start at zero; upscaling scatters every source line onto the target lines its
+    triangle touches, downscaling gathers; the axis with the smaller factor goes first through an f32 frame whose
+    window is computed with `* factor` (video_scale.c:256-262); the window reported is the span of lines touched."""
+    def empty(w):
+        return w[2] < w[0] or w[3] < w[1]
+
+    def one_pass(a, afull, acur, bfull, tmin, smin, factor, axis):          # axis 0: along y, 1: along x
+        bh, bw = bfull[3] - bfull[1] + 1, bfull[2] - bfull[0] + 1
+        out = np.zeros((max(bh, 0), max(bw, 0), 4), F32)
+        o_lo = max(acur[axis], bfull[axis])                                  # the other axis (x for a y pass, y for an x pass) is clipped
+        o_hi = min(acur[2 + axis], bfull[2 + axis])
+        s0, s1 = acur[0 if axis else 1], acur[2 if axis else 3]
+        t0, t1 = bfull[0 if axis else 1], bfull[2 if axis else 3]
+        used = []
+        if not (factor == 1.0 and tmin == smin):
+            pairs = []                                                        # (target line, source line, weight) in the reference's order
+            if factor > 1.0:
+                for s in range(s0, s1 + 1):
+                    centre_f = F32(F32(F32(s) - F32(smin)) * F32(factor) + F32(tmin))
+                    centre = int(np.floor(centre_f))
+                    taps, tc = triangle(float(factor), float(F32(centre_f - F32(centre))))
+                    pairs += [(centre - tc + k, s, w) for k, w in enumerate(taps)]
+            else:
+                for t in range(t0, t1 + 1):
+                    centre_f = F32(F32(F32(t) - F32(tmin)) / F32(factor) + F32(smin))
+                    centre = int(np.floor(centre_f))
+                    taps, tc = triangle(float(factor), float(F32(centre_f - F32(centre))))
+                    pairs += [(t, centre - tc + k, w) for k, w in enumerate(taps)]
+            for t, s, w in pairs:
+                if t < t0 or t > t1 or s < s0 or s > s1:
+                    continue
+                if axis == 0 or o_lo <= o_hi:
+                    used.append(t)
+                if o_lo > o_hi:
+                    continue
+                if axis:
+                    tgt = out[o_lo - bfull[1]: o_hi - bfull[1] + 1, t - bfull[0]]
+                    line = a[o_lo - afull[1]: o_hi - afull[1] + 1, s - afull[0]]
+                else:
+                    tgt = out[t - bfull[1], o_lo - bfull[0]: o_hi - bfull[0] + 1]
+                    line = a[s - afull[1], o_lo - afull[0]: o_hi - afull[0] + 1]
+                tgt[...] = (tgt + (line * F32(w)).astype(F32)).astype(F32)
+            lo, hi = (min(used), max(used)) if used else (2 ** 31 - 1, -2 ** 31)
+            win = (lo, o_lo, hi, o_hi) if axis else (o_lo, lo, o_hi, hi)
+            return out, win
+        # identity on this axis: a clipped copy (video_copy_frame_alpha_f32 with alpha 1)
+        win = (max(acur[0], bfull[0]), max(acur[1], bfull[1]), min(acur[2], bfull[2]), min(acur[3], bfull[3]))
+        if not empty(win):
+            out[win[1] - bfull[1]: win[3] - bfull[1] + 1, win[0] - bfull[0]: win[2] - bfull[0] + 1] = \
+                a[win[1] - afull[1]: win[3] - afull[1] + 1, win[0] - afull[0]: win[2] - afull[0] + 1]
+        return out, win
+
+    fx, fy = F32(fac[0]), F32(fac[1])
+    if fx == 1.0 and tp[0] == sp[0]:
+        if fy == 1.0 and tp[1] == sp[1]:
+            return one_pass(src, sfull, scur, tfull, 0.0, 0.0, 1.0, 0)
+        return one_pass(src, sfull, scur, tfull, tp[1], sp[1], fy, 0)
+    if fy == 1.0 and tp[1] == sp[1]:
+        return one_pass(src, sfull, scur, tfull, tp[0], sp[0], fx, 1)
+    x_first = fx < fy
+    if x_first:
+        mid = (int(F32(F32(sp[0]) - F32(F32(tp[0]) - F32(tfull[0])) * fx)), scur[1], int(F32(F32(sp[0]) + F32(F32(tfull[2]) - F32(tp[0])) * fx)), scur[3])
+    else:
+        mid = (scur[0], int(F32(F32(sp[1]) - F32(F32(tp[1]) - F32(tfull[1])) * fy)), scur[2], int(F32(F32(sp[1]) + F32(F32(tfull[3]) - F32(tp[1])) * fy)))
+    mid = (max(mid[0], tfull[0]), max(mid[1], tfull[1]), min(mid[2], tfull[2]), min(mid[3], tfull[3]))
+    if x_first:
+        m, mwin = one_pass(src, sfull, scur, mid, tp[0], sp[0], fx, 1)
+        return one_pass(m, mid, mwin, tfull, tp[1], sp[1], fy, 0)
+    m, mwin = one_pass(src, sfull, scur, mid, tp[1], sp[1], fy, 0)
+    return one_pass(m, mid, mwin, tfull, tp[0], sp[0], fx, 1)

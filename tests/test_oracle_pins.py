@@ -407,3 +407,41 @@ def test_dv_edge_matches_models(orc):
     yy, cb, cr = dv_subsample_model(codes, orc.transfer_table(2), orc.fir_triangle(0.25, 0.0))
     assert np.array_equal(back[0], yy) and np.array_equal(back[1], cb) and np.array_equal(back[2], cr)
     assert np.array_equal(src.array, orc.transfer_table(2)[codes])          # the input was encoded in place
+
+
+def test_triangle_scaler_matches_model(orc):
+    """video_scale_bilinear_f32 against the whole-array statement: 60 random set-ups plus the fixed cases of the GPU
+    parity test (pass order, partial-coverage intermediate window, scatter / gather, window reported)."""
+    from canvas_amd.abi import v2f
+    from tests.models import scale_model
+    rng = np.random.default_rng(305)
+    cases = [((0, 0, 31, 17), (0, 0, 15, 8), (0, 0, 15, 8), (0, 0), (0, 0), (2.0, 2.0)),
+             ((0, 0, 15, 8), (0, 0, 31, 17), (0, 0, 31, 17), (0, 0), (0, 0), (0.5, 0.5)),
+             ((0, 0, 40, 30), (0, 0, 15, 8), (0, 0, 15, 8), (3.5, 2.25), (1.0, 0.5), (2.5, 3.0)),
+             ((0, 0, 20, 40), (0, 0, 15, 8), (0, 0, 15, 8), (0, 0), (0, 0), (1.3, 4.0)),
+             ((0, 0, 15, 8), (0, 0, 15, 8), (0, 0, 15, 8), (2.0, 0.0), (0, 0), (1.0, 1.0)),
+             ((-8, -4, 23, 13), (0, 0, 15, 8), (0, 0, 15, 8), (0, 0), (8.0, 4.0), (2.0, 2.0))]
+    for _ in range(60):
+        sfull = (int(rng.integers(-4, 3)), int(rng.integers(-3, 3)), int(rng.integers(8, 22)), int(rng.integers(5, 14)))
+        tfull = (int(rng.integers(-4, 3)), int(rng.integers(-3, 3)), int(rng.integers(8, 30)), int(rng.integers(5, 22)))
+        ax, bx = sorted(int(v) for v in rng.integers(sfull[0], sfull[2] + 1, 2))
+        ay, by = sorted(int(v) for v in rng.integers(sfull[1], sfull[3] + 1, 2))
+        fac = (float(rng.choice([0.25, 0.5, 0.75, 1.0, 1.5, 2.0, 3.0])), float(rng.choice([0.25, 0.5, 0.8, 1.0, 1.25, 2.0, 4.0])))
+        tp = (float(rng.choice([0.0, 0.5, 2.25])), float(rng.choice([0.0, 1.0, 3.5])))
+        sp = (float(rng.choice([0.0, 0.75, 2.0])), float(rng.choice([0.0, 0.5, 1.0])))
+        cases.append((tfull, sfull, (ax, ay, bx, by), tp, sp, fac))
+    for tfull, sfull, scur, tp, sp, fac in cases:
+        h, w = sfull[3] - sfull[1] + 1, sfull[2] - sfull[0] + 1
+        src = rng.uniform(-0.5, 1.5, (h, w, 4)).astype(np.float32)
+        frame = HostFrame(sfull, np.float32, src, scur)
+        out = HostFrame(tfull, np.float32)
+        orc.lib().orc_scale_bilinear_f32(out.ref(), v2f(*tp), frame.ref(), v2f(*sp), v2f(*fac))
+        want, win = scale_model(src, sfull, scur, tfull, tp, sp, fac, orc.fir_triangle)
+        got_win = out.current_window.tuple()
+        both_empty = (got_win[2] < got_win[0] or got_win[3] < got_win[1]) and (win[2] < win[0] or win[3] < win[1])
+        assert both_empty or got_win == tuple(win), (tfull, sfull, scur, tp, sp, fac, got_win, win)
+        if not both_empty:
+            x0, y0, x1, y1 = got_win
+            a = out.array[y0 - tfull[1]: y1 - tfull[1] + 1, x0 - tfull[0]: x1 - tfull[0] + 1]
+            b = want[y0 - tfull[1]: y1 - tfull[1] + 1, x0 - tfull[0]: x1 - tfull[0] + 1]
+            assert np.array_equal(_canon(a), _canon(b)), (tfull, sfull, scur, tp, sp, fac)
