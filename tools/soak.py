@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Soak: the three hot kernels re-run thousands of times on the same inputs; every 40th result is downloaded and must
+equal the first one bit for bit (a rare ordering bug in a software pipeline shows up as a handful of wrong pixels once
+in many launches, not in a parity test that runs each case once)."""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from canvas_amd import REC709_RGB_TO_YPBPR, _lib, synth  # noqa: E402
+from canvas_amd.device import DeviceFrame, chain_color_over  # noqa: E402
+from canvas_amd.stream import GraphStream  # noqa: E402
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 20.0
+lib = _lib.load()
+_lib.check(lib.cvs_init(0))
+lib.init_half()
+stream = lib.cvs_stream_create()
+w, h = 3840, 2160
+full = (0, 0, w - 1, h - 1)
+m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+sets = []
+for g in range(4):
+    layers = [DeviceFrame.from_host(synth.layer_frame(w, h, k, g)) for k in range(2)]
+    sets.append((DeviceFrame(full, np.uint16), layers))
+graph = GraphStream(w, h, ring=2)
+taps = synth.gaussian_taps(9, 1.5)
+small = DeviceFrame((0, 0, w // 2 - 1, h // 2 - 1), np.uint16)
+f32p = taps.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def once():
+    chain_color_over([sets[i % 4] for i in range(8)], m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE, stream)
+    graph.render(0, stream)
+    graph.render(1, stream)
+    _lib.check(lib.cvs_blur_lanczos_f16_dev(small.ref(), sets[0][1][1].ref(), f32p, 9, C.c_float(0.5), C.c_float(0.5), 3, stream))
+
+
+def snapshot():
+    _lib.check(lib.cvs_stream_sync(stream))
+    return [s[0].download().array.copy() for s in sets] + [graph.slots[0]["out"].download().array.copy(), graph.slots[1]["out"].download().array.copy(),
+                                                        small.download().array.copy()]
+
+
+once()
+first = snapshot()
+t0, n, checks = time.perf_counter(), 0, 0
+while time.perf_counter() - t0 < seconds:
+    for _ in range(40):
+        once()
+    n += 40
+    now = snapshot()
+    for a, b in zip(first, now):
+        if not np.array_equal(a, b):
+            bad = int((a != b).sum())
+            print("MISMATCH after %d iterations: %d values differ" % (n, bad))
+            sys.exit(1)
+    checks += 1
+print("soak ok: %d iterations (%d launches of the chain over 8 frames, %d config-5 frames, %d config-3 frames), %d full compares, %.1f s"
+      % (n, n, 2 * n, n, checks, time.perf_counter() - t0))
