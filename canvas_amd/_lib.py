@@ -100,6 +100,7 @@ SIGNATURES = {
     "cvs_graph_end": (_vp, [_vp]),
     "cvs_graph_launch": (C.c_int, [_vp, _vp]),
     "cvs_graph_destroy": (None, [_vp]),
+    "cvs_mem_info": (C.c_int, [P(C.c_size_t), P(C.c_size_t)]),
     "cvs_pool_malloc": (_vp, [C.c_size_t, _vp]),
     "cvs_pool_free": (None, [_vp, _vp]),
     "cvs_pool_trim": (None, []),

@@ -234,6 +234,15 @@ CVS_EXPORT void cvs_pool_free(void *dev, cvs_stream_t s) {
     free_when_idle(dev);
 }
 
+CVS_EXPORT int cvs_mem_info(size_t *free_bytes, size_t *total_bytes) {
+    if (cvs_enter() != 0) return -1;
+    size_t f = 0, t = 0;
+    CVS_HIP(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+}
+
 CVS_EXPORT void cvs_pool_trim(void) {
     if (cvs_enter() != 0) return;
     pthread_mutex_lock(&g_lock);

@@ -244,6 +244,7 @@ CVS_EXPORT int cvs_graph_begin(cvs_stream_t stream);
 CVS_EXPORT cvs_graph_t cvs_graph_end(cvs_stream_t stream);          /* NULL on failure */
 CVS_EXPORT int cvs_graph_launch(cvs_graph_t graph, cvs_stream_t stream);
 CVS_EXPORT void cvs_graph_destroy(cvs_graph_t graph);
+CVS_EXPORT int cvs_mem_info(size_t *free_bytes, size_t *total_bytes);     /* HBM free / total on the bound device */
 CVS_EXPORT void *cvs_pool_malloc(size_t bytes, cvs_stream_t s);
 CVS_EXPORT void cvs_pool_free(void *dev, cvs_stream_t s);
 CVS_EXPORT void cvs_pool_trim(void);

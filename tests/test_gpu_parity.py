@@ -1581,3 +1581,38 @@ def test_graph_capture_of_the_config5_frame(cvs, orc):
     finally:
         cvs.cvs_graph_destroy(graph)
         cvs.cvs_stream_destroy(stream)
+
+
+def test_scratch_memory_comes_back(cvs, orc):
+    """Hundreds of calls with ever-changing frame sizes (so the pool keeps meeting new block sizes and the tap-table
+    cache keeps evicting), then a trim: HBM in use returns to where it started -- nothing is leaked per call."""
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        _lib.check(cvs.cvs_stream_sync(None))
+        _lib.check(cvs.cvs_mem_info(C.byref(f), C.byref(t)))
+        return f.value
+
+    rng = np.random.default_rng(4242)
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    taps = synth.gaussian_taps(9, 1.5)
+
+    def burst(count):
+        for _ in range(count):
+            w, h = int(rng.integers(40, 400)), int(rng.integers(30, 200))
+            full = (0, 0, w - 1, h - 1)
+            layers = [DeviceFrame.from_host(rand_f16_frame(rng, full, (2, 1, w - 3, h - 2) if k else full)) for k in range(3)]
+            out = DeviceFrame(full, np.uint16)
+            chain_color_over([(out, layers)], m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE)          # ragged: node by node, pooled f32 frames
+            small = DeviceFrame((0, 0, w // 2 - 1, h // 2 - 1), np.uint16)
+            _lib.check(cvs.cvs_blur_lanczos_f16_dev(small.ref(), layers[0].ref(), f32p(taps), 9, C.c_float(0.5), C.c_float(0.5), 3, None))
+            big = DeviceFrame((0, 0, 2 * w - 1, 2 * h - 1), np.uint16)
+            _lib.check(cvs.cvs_scale_bilinear_f16_dev(big.ref(), v2f(0, 0), layers[0].ref(), v2f(0, 0), v2f(2.0, 2.0), None))
+            del layers, out, small, big
+
+    burst(20)                                    # first use of everything (tables, LUTs, code objects)
+    cvs.cvs_pool_trim()
+    before = free_bytes()
+    burst(150)
+    cvs.cvs_pool_trim()
+    after = free_bytes()
+    assert before - after < 64 << 20, (before, after)        # the tap-table cache holds at most 16 small tables
