@@ -247,10 +247,11 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16 storage, f32 arithmetic",
+            "dtype": "f32",      # the arithmetic type; pixels are stored as f16 (see config.storage)
             "data": "synthetic (Philox, seed 0xC0FFEE+1000*layer+frame), resident in HBM" + (
                 "; NON-BASELINE variant: random alpha on layer 0 too" if args.translucent_base else ""),
             "config": {"workload": "%dx%d f16 RGBA, Rec.709->linear LUT + RGB->Y'PbPr 3x3 on %d layers + %d-layer alpha-over, f16 out" % (w, h, nl, nl),
+                       "storage": "rgba_f16 (8 B per pixel) in and out, f32 arithmetic in registers",
                        "frames_per_step_per_gpu": args.batch, "ring_frames_per_gpu": len(ring),
                        "sharding": "frame g -> gpu g %% %d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
