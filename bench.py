@@ -117,6 +117,11 @@ def cpu_baseline(args, seconds):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result: libraries that write banners there (RCCL prints its version,
+    # host name and library path on communicator creation) are sent to stderr until the result is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -267,7 +272,10 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
             except Exception as e:
                 res["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %s" % e}
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(res), flush=True)
+        os.dup2(2, 1)
 
     if dist is not None:
         dist.barrier()
