@@ -226,6 +226,25 @@ def main():
         except Exception as e:                                  # the oracle is only a checker here
             verified = "unchecked: %s" % e
 
+    # same-run yardstick for this box: plain device-to-device copies of the same frames (SURVEY 8d asks for one beside
+    # the roofline figure; boxes of the pool differ by several per cent)
+    copy_gbs = None
+    if rank == 0:
+        try:
+            e0, e1 = lib.cvs_event_create(), lib.cvs_event_create()
+            nbytes = w * h * 8
+            pairs = [(ring[i % len(ring)][0], ring[(i + 1) % len(ring)][1][0]) for i in range(32)]
+            for rep in range(2):
+                lib.cvs_event_record(e0, stream)
+                for dst, src in pairs:
+                    lib.cvs_memcpy_d2d(dst.ptr, src.ptr, nbytes, stream)
+                lib.cvs_event_record(e1, stream)
+                _lib.check(lib.cvs_stream_sync(stream), "sync")
+            copy_gbs = round(2 * nbytes * len(pairs) / (lib.cvs_event_elapsed_ms(e0, e1) * 1e-3) / 1e9, 1)
+            lib.cvs_event_destroy(e0), lib.cvs_event_destroy(e1)
+        except Exception:                                       # a yardstick, not a result
+            copy_gbs = None
+
     if rank == 0:
         px_per_step = args.batch * w * h
         total_px = px_per_step * args.steps * world
@@ -262,6 +281,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "k_chain<%d,pre-LUT>" % nl, "avg_launch_ms": round(avg_ms, 4),
+                         "same_run_dtod_copy_GBps": copy_gbs,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "achieved = %d B/px x %d px per launch / HIP-event launch time" % (BYTES_PER_PIXEL_PER_LAYER * (nl + 1), px_per_step)},
             "verified_against_oracle": verified,
