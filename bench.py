@@ -120,8 +120,11 @@ def main():
     # stdout carries exactly ONE line, the JSON result: libraries that write banners there (RCCL prints its version,
     # host name and library path on communicator creation) are sent to stderr until the result is ready
     sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
+    try:
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
+    except OSError:                     # no usable stderr: leave stdout alone
+        real_stdout = None
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -293,9 +296,11 @@ def main():
             except Exception as e:
                 res["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %s" % e}
         sys.stdout.flush()
-        os.dup2(real_stdout, 1)
+        if real_stdout is not None:
+            os.dup2(real_stdout, 1)
         print(json.dumps(res), flush=True)
-        os.dup2(2, 1)
+        if real_stdout is not None:
+            os.dup2(2, 1)
 
     if dist is not None:
         dist.barrier()
