@@ -146,6 +146,8 @@ SIGNATURES = {
     "cvs_subsample_dv_dev": (C.c_int, [P(coded_image), _F16, C.c_int, _vp]),
     "cvs_frame_to_bytes_dev": (C.c_int, [_vp, _F16, C.c_int, C.c_int, _vp]),
     "video_frame_to_bytes": (C.c_int, [_vp, _F16, C.c_int, C.c_int]),
+    "cvs_frame_to_rgba8_intent_dev": (C.c_int, [_vp, _F16, C.c_int, C.c_float, _vp]),
+    "video_frame_to_rgba8_intent": (C.c_int, [_vp, _F16, C.c_int, C.c_float]),
     "cvs_fir_blur_f16_dev": (C.c_int, [_F16, _F16, _f32p, C.c_int, _vp]),
     "cvs_blur_over_f16_dev": (C.c_int, [_F16, _F16, _f32p, C.c_int, P(_F16), C.c_int, _vp]),
     "cvs_resample_lanczos_f32_dev": (C.c_int, [_F32, _F32, C.c_float, C.c_float, C.c_int, _vp]),

@@ -1,46 +1,81 @@
 /*
  * display.c -- the display / export edge: an f16 frame to 4 bytes per pixel on the device.
  *
- * The reference has three copies of this loop, all through the gamma-0.45 byte ramp (gammatab.c:13-38):
- *   src/cprocess/widget_gl.c:291-307    video_transfer_linear_to_sRGB over all four halfs, then ramp -> rgba_u8
- *   src/libav/writeVideo.c:328-340      ramp -> rgba_u8
- *   src/process/RgbaFrameF16.c:114-149  ramp -> premultiplied ARGB32 (to_argb32_bytes)
- * Here they are one kernel (kernels/display_ops.hip) over one 64 KiB byte table per choice of transfer table:
+ * The reference turns pulled f16 frames into bytes in three places, each through a 65536-entry half -> u8 ramp:
+ *   src/process/RgbaFrameF16.c:114-149  the gamma-0.45 ramp of gammatab.c:13-38 -> premultiplied ARGB32 (to_argb32_bytes)
+ *   src/libav/writeVideo.c:108-115,328-340  its own ramp, (int)(clamp(x,0,1)^0.45 * 255): the same bytes as gammatab's -> rgba_u8
+ *   src/cprocess/widget_gl.c:291-307    video_transfer_linear_to_sRGB over all four halfs, then the WIDGET's ramp
+ *                                       lrint(clamp(x^intent * 255, 0, 255)) (:947-968, intent 1.25 by default) -> rgba_u8
+ * Here they are one kernel (kernels/display_ops.hip) over one 64 KiB byte table per (transfer table, ramp) pair:
  * table[c] = ramp[transfer[c]] is index plumbing done once on the host and cached on the device; it is rebuilt
  * when cvs_lut_install replaces the transfer table it was made from.
  */
 #include "internal.h"
+#include <math.h>
 #include <pthread.h>
 
 unsigned cvs_lut_generation(int which);       /* halfconv.c: bumped by every install */
+const float *cvs_codes_as_float(void);        /* halfconv.c */
 
+enum { RAMP_GAMMA45 = 0, RAMP_INTENT = 1 };
+typedef struct { bool have; int pre_lut, kind; unsigned gen; uint32_t intent_bits; uint64_t stamp; uint8_t *dev; } disp_entry;
+#define DISP_CACHE 8
 static pthread_mutex_t disp_lock = PTHREAD_MUTEX_INITIALIZER;
-static uint8_t *disp_dev[CVS_LUT_COUNT + 1];  /* slot 0: the bare ramp; slot 1 + id: ramp after table id */
-static unsigned disp_gen[CVS_LUT_COUNT + 1];
-static bool disp_have[CVS_LUT_COUNT + 1];
+static disp_entry disp_cache[DISP_CACHE];
+static uint64_t disp_clock;
 
-static const uint8_t *display_table(int pre_lut) {
+static const uint8_t *display_table(int pre_lut, int kind, float intent) {
     if (pre_lut != CVS_LUT_NONE && (pre_lut < 0 || pre_lut >= CVS_LUT_COUNT)) { cvs_set_error("no such transfer table: %d", pre_lut); return NULL; }
-    const uint8_t *ramp = video_get_gamma45_ramp();
+    const uint8_t *ramp45 = kind == RAMP_GAMMA45 ? video_get_gamma45_ramp() : NULL;
+    const float *codes = kind == RAMP_INTENT ? cvs_codes_as_float() : NULL;
     const half *pre = pre_lut == CVS_LUT_NONE ? NULL : cvs_lut_host(pre_lut);
-    if (!ramp || (pre_lut != CVS_LUT_NONE && !pre)) return NULL;
-    const int slot = pre_lut == CVS_LUT_NONE ? 0 : 1 + pre_lut;
+    if ((kind == RAMP_GAMMA45 && !ramp45) || (kind == RAMP_INTENT && !codes) || (pre_lut != CVS_LUT_NONE && !pre)) return NULL;
     const unsigned gen = pre_lut == CVS_LUT_NONE ? 0 : cvs_lut_generation(pre_lut);
+    uint32_t ibits = 0;
+    if (kind == RAMP_INTENT) memcpy(&ibits, &intent, 4);
     const uint8_t *result = NULL;
     pthread_mutex_lock(&disp_lock);
-    if (!disp_have[slot] || disp_gen[slot] != gen) {
+    int victim = 0;
+    for (int i = 0; i < DISP_CACHE && !result; i++) {
+        disp_entry *e = &disp_cache[i];
+        if (e->have && e->pre_lut == pre_lut && e->kind == kind && e->gen == gen && e->intent_bits == ibits) { e->stamp = ++disp_clock; result = e->dev; }
+        else if (!e->have) victim = i;
+        else if (disp_cache[victim].have && e->stamp < disp_cache[victim].stamp) victim = i;
+    }
+    if (!result) {
         uint8_t *host = malloc(HALF_COUNT);
         bool ok = host != NULL;
-        if (ok) for (int c = 0; c < HALF_COUNT; c++) host[c] = ramp[pre ? pre[c] : c];
-        if (ok && !disp_dev[slot]) ok = hipMalloc((void **)&disp_dev[slot], HALF_COUNT) == hipSuccess;
-        if (ok) ok = hipMemcpy(disp_dev[slot], host, HALF_COUNT, hipMemcpyHostToDevice) == hipSuccess;
+        for (int c = 0; ok && c < HALF_COUNT; c++) {
+            const int code = pre ? pre[c] : c;
+            if (kind == RAMP_GAMMA45) host[c] = ramp45[code];
+            else host[c] = (uint8_t)lrint(clampf(powf(codes[code], intent) * 255.0f, 0.0f, 255.0f));     /* widget_gl.c:966 */
+        }
+        disp_entry *e = &disp_cache[victim];
+        if (ok && e->have) { (void)hipDeviceSynchronize(); }         /* a launch may still be reading the evicted table */
+        if (ok && !e->dev) ok = hipMalloc((void **)&e->dev, HALF_COUNT) == hipSuccess;
+        if (ok) ok = hipMemcpy(e->dev, host, HALF_COUNT, hipMemcpyHostToDevice) == hipSuccess;
         free(host);
-        if (ok) { disp_have[slot] = true; disp_gen[slot] = gen; }
-        else cvs_set_error("display table %d could not be built", pre_lut);
+        if (ok) { e->have = true; e->pre_lut = pre_lut; e->kind = kind; e->gen = gen; e->intent_bits = ibits; e->stamp = ++disp_clock; result = e->dev; }
+        else { e->have = false; cvs_set_error("display table (transfer %d) could not be built", pre_lut); }
     }
-    if (disp_have[slot] && disp_gen[slot] == gen) result = disp_dev[slot];
     pthread_mutex_unlock(&disp_lock);
     return result;
+}
+
+static int to_bytes_dev(void *dst_dev, const rgba_frame_f16 *frame, const uint8_t *table, int kmode, hipStream_t s) {
+    if (box2i_is_empty(&frame->current_window)) return 0;
+    if (!cvs_box_contains(&frame->full_window, &frame->current_window)) { cvs_set_error("frame to bytes: current window outside the buffer"); return -1; }
+    if (!table) return -1;
+    CVS_KERNEL(cvk_display(dst_dev, cvs_view(frame->data, &frame->full_window), cvs_rect(&frame->current_window), table, kmode, cvs_cus(), s));
+    return 0;
+}
+
+/* the software widget's conversion (widget_gl.c:291-307): transfer table over all four halfs, then the ramp
+ * lrint(clamp(x^rendering_intent * 255)) -> bytes r,g,b,a.  The widget's defaults: CVS_LUT_LINEAR_TO_SRGB, 1.25. */
+CVS_EXPORT int cvs_frame_to_rgba8_intent_dev(void *dst_dev, const rgba_frame_f16 *frame, int pre_lut, float rendering_intent, cvs_stream_t stream) {
+    if (cvs_enter() != 0) return -1;
+    if (box2i_is_empty(&frame->current_window)) return 0;
+    return to_bytes_dev(dst_dev, frame, display_table(pre_lut, RAMP_INTENT, rendering_intent), CVK_DISPLAY_RGBA8, cvs_pick_stream(stream));
 }
 
 /* dst_dev: room for 4 bytes per pixel of frame->current_window, packed row by row */
@@ -48,16 +83,13 @@ CVS_EXPORT int cvs_frame_to_bytes_dev(void *dst_dev, const rgba_frame_f16 *frame
     if (cvs_enter() != 0) return -1;
     if (mode != CVS_DISPLAY_RGBA8 && mode != CVS_DISPLAY_ARGB32_PREMUL) { cvs_set_error("frame to bytes: unknown mode %d", mode); return -1; }
     if (box2i_is_empty(&frame->current_window)) return 0;
-    if (!cvs_box_contains(&frame->full_window, &frame->current_window)) { cvs_set_error("frame to bytes: current window outside the buffer"); return -1; }
-    const uint8_t *table = display_table(pre_lut);
-    if (!table) return -1;
-    CVS_KERNEL(cvk_display(dst_dev, cvs_view(frame->data, &frame->full_window), cvs_rect(&frame->current_window), table,
-                           mode == CVS_DISPLAY_RGBA8 ? CVK_DISPLAY_RGBA8 : CVK_DISPLAY_ARGB32_PREMUL, cvs_cus(), cvs_pick_stream(stream)));
-    return 0;
+    return to_bytes_dev(dst_dev, frame, display_table(pre_lut, RAMP_GAMMA45, 0.0f), mode == CVS_DISPLAY_RGBA8 ? CVK_DISPLAY_RGBA8 : CVK_DISPLAY_ARGB32_PREMUL,
+                        cvs_pick_stream(stream));
 }
 
-/* the same on a HOST frame into a HOST buffer: rows of the current window go up, bytes come back */
-CVS_EXPORT int video_frame_to_bytes(void *dst_host, const rgba_frame_f16 *frame, int pre_lut, int mode) {
+/* the same on a HOST frame into a HOST buffer: rows of the current window go up, bytes come back.
+ * kind < 0: gamma-0.45 ramp in `mode`; otherwise the widget's ramp with that rendering intent. */
+static int host_to_bytes(void *dst_host, const rgba_frame_f16 *frame, int pre_lut, int mode, bool widget, float intent) {
     if (cvs_enter() != 0) return -1;
     const box2i *w = &frame->current_window;
     if (box2i_is_empty(w)) return 0;
@@ -72,8 +104,19 @@ CVS_EXPORT int video_frame_to_bytes(void *dst_host, const rgba_frame_f16 *frame,
     cvs_staged din = { 0 }, dout = { 0 };
     int rc = cvs_stage_in(&din, first, in_bytes, 1, s);
     if (rc == 0) rc = cvs_stage_in(&dout, NULL, out_bytes, 0, s);
-    if (rc == 0) { band.data = din.dev; rc = cvs_frame_to_bytes_dev(dout.dev, &band, pre_lut, mode, s); }
+    if (rc == 0) {
+        band.data = din.dev;
+        rc = widget ? cvs_frame_to_rgba8_intent_dev(dout.dev, &band, pre_lut, intent, s) : cvs_frame_to_bytes_dev(dout.dev, &band, pre_lut, mode, s);
+    }
     if (rc == 0) rc = cvs_stage_out(&dout, dst_host, s);
     cvs_stage_free(&din); cvs_stage_free(&dout);
     return rc;
+}
+
+CVS_EXPORT int video_frame_to_bytes(void *dst_host, const rgba_frame_f16 *frame, int pre_lut, int mode) {
+    return host_to_bytes(dst_host, frame, pre_lut, mode, false, 0.0f);
+}
+
+CVS_EXPORT int video_frame_to_rgba8_intent(void *dst_host, const rgba_frame_f16 *frame, int pre_lut, float rendering_intent) {
+    return host_to_bytes(dst_host, frame, pre_lut, CVS_DISPLAY_RGBA8, true, rendering_intent);
 }

@@ -148,6 +148,15 @@ static int install_locked(int which, const half *table) {
     return 0;
 }
 
+/* h2f of every half code (computed once, on the GPU): what ramps over the whole code space are built from */
+const float *cvs_codes_as_float(void) {
+    if (cvs_enter() != 0) return NULL;
+    pthread_mutex_lock(&lut_lock);
+    int rc = ensure_codes();
+    pthread_mutex_unlock(&lut_lock);
+    return rc == 0 ? codes_as_float : NULL;
+}
+
 unsigned cvs_lut_generation(int which) { return (which >= 0 && which < CVS_LUT_COUNT) ? __atomic_load_n(&lut_gen[which], __ATOMIC_ACQUIRE) : 0; }
 
 static int ensure_lut(int which) {

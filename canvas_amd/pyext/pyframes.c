@@ -85,13 +85,21 @@ PyObject *py_get_frame_f32(PyObject *self, PyObject *args, PyObject *kw) {
     return result;
 }
 
-/* Preview / thumbnail pulls: render on the device, convert to bytes on the device (cvs_frame_to_bytes_dev), and
- * bring back 4 bytes per pixel of the current window instead of the 8-byte halfs.  Returns
- * (bytearray or None, current_window).  The two conversions are the reference's display edges:
- * RgbaFrameF16.to_argb32_bytes (RgbaFrameF16.c:114-149) and the software widget's rgba_u8 (widget_gl.c:291-307). */
-static PyObject *pull_bytes(PyObject *self, PyObject *args, PyObject *kw, int mode, int pre_lut) {
+/* Preview / thumbnail pulls: render on the device, convert to bytes on the device, and bring back 4 bytes per
+ * pixel of the current window instead of the 8-byte halfs.  Returns (bytearray or None, current_window).
+ * The two conversions are the reference's display edges:
+ *   get_frame_argb32(frame_index, data_window): RgbaFrameF16.to_argb32_bytes (RgbaFrameF16.c:114-149);
+ *   get_frame_rgba8(frame_index, data_window, rendering_intent=1.25): the software widget's rgba_u8
+ *     (widget_gl.c:291-307: linear->sRGB table, then the ramp of widget_gl_set_rendering_intent, :955-968). */
+static PyObject *pull_bytes(PyObject *self, PyObject *args, PyObject *kw, bool widget) {
     int frame_index; box2i window;
-    if (!parse_pull_args(args, kw, &frame_index, &window)) return NULL;
+    float intent = 1.25f;                                /* widget_gl.c:428-429 */
+    if (widget) {
+        static char *kwlist[] = { "frame_index", "data_window", "rendering_intent", NULL };
+        PyObject *window_obj = NULL;
+        if (!PyArg_ParseTupleAndKeywords(args, kw, "iO|f", kwlist, &frame_index, &window_obj, &intent)) return NULL;
+        if (!py_parse_box2i(window_obj, &window)) return NULL;
+    } else if (!parse_pull_args(args, kw, &frame_index, &window)) return NULL;
     video_source *source = NULL;
     if (!py_video_take_source(self, &source)) return NULL;
     PyObject *bytes = NULL, *result = NULL;
@@ -115,7 +123,8 @@ static PyObject *pull_bytes(PyObject *self, PyObject *args, PyObject *kw, int mo
             char *host = PyByteArray_AS_STRING(bytes);
             Py_BEGIN_ALLOW_THREADS
             packed = cvs_pool_malloc(out, NULL);
-            rc = packed ? cvs_frame_to_bytes_dev(packed, &f, pre_lut, mode, NULL) : -1;
+            rc = !packed ? -1 : widget ? cvs_frame_to_rgba8_intent_dev(packed, &f, CVS_LUT_LINEAR_TO_SRGB, intent, NULL)
+                                       : cvs_frame_to_bytes_dev(packed, &f, CVS_LUT_NONE, CVS_DISPLAY_ARGB32_PREMUL, NULL);
             if (rc == 0) rc = cvs_memcpy_d2h(host, packed, out, NULL);
             Py_END_ALLOW_THREADS
         } else rc = -2;
@@ -131,8 +140,8 @@ static PyObject *pull_bytes(PyObject *self, PyObject *args, PyObject *kw, int mo
     return result;
 }
 
-PyObject *py_get_frame_argb32(PyObject *self, PyObject *args, PyObject *kw) { return pull_bytes(self, args, kw, CVS_DISPLAY_ARGB32_PREMUL, CVS_LUT_NONE); }
-PyObject *py_get_frame_rgba8(PyObject *self, PyObject *args, PyObject *kw) { return pull_bytes(self, args, kw, CVS_DISPLAY_RGBA8, CVS_LUT_LINEAR_TO_SRGB); }
+PyObject *py_get_frame_argb32(PyObject *self, PyObject *args, PyObject *kw) { return pull_bytes(self, args, kw, false); }
+PyObject *py_get_frame_rgba8(PyObject *self, PyObject *args, PyObject *kw) { return pull_bytes(self, args, kw, true); }
 
 static PyObject *frame16_full(py_frame16 *self, void *c) { return py_make_box2i(&self->frame.full_window); }
 static PyObject *frame16_current(py_frame16 *self, void *c) { return py_make_box2i(&self->frame.current_window); }

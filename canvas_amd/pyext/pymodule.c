@@ -248,8 +248,8 @@ static PyMethodDef VideoSource_methods[] = {
       "(bytearray or None, current_window) = source.get_frame_argb32(frame_index, data_window): premultiplied ARGB32 of the "
       "defined window, converted on the device (what get_frame_f16(...).to_argb32_bytes() returns, for half the download)" },
     { "get_frame_rgba8", (PyCFunction)py_get_frame_rgba8, METH_VARARGS | METH_KEYWORDS,
-      "(bytearray or None, current_window) = source.get_frame_rgba8(frame_index, data_window): sRGB-encoded r,g,b,a bytes of the "
-      "defined window, converted on the device (the software widget's display conversion)" },
+      "(bytearray or None, current_window) = source.get_frame_rgba8(frame_index, data_window, rendering_intent=1.25): "
+      "sRGB-encoded r,g,b,a bytes of the defined window, converted on the device (the software widget's display conversion)" },
     { NULL }
 };
 

@@ -317,14 +317,21 @@ CVS_EXPORT int cvs_reconstruct_dv_dev(rgba_frame_f16 *frame, const coded_image *
 CVS_EXPORT int cvs_subsample_dv_dev(coded_image *planar, rgba_frame_f16 *frame, int encode_input_in_place, cvs_stream_t stream);
 
 /* Display / export edge: the current window of an f16 frame as 4 bytes per pixel, packed row by row.
- * pre_lut: a transfer table applied to all four halfs first (CVS_LUT_NONE for none); then the half->u8 ramp of
- * video_get_gamma45_ramp().  CVS_DISPLAY_RGBA8: bytes r,g,b,a -- with CVS_LUT_LINEAR_TO_SRGB the software
- * widget's conversion (src/cprocess/widget_gl.c:291-307), without a table the exporter's (src/libav/
- * writeVideo.c:328-340).  CVS_DISPLAY_ARGB32_PREMUL: a<<24 | (r*a>>8)<<16 | (g*a>>8)<<8 | (b*a>>8), what
- * RgbaFrameF16.to_argb32_bytes returns (src/process/RgbaFrameF16.c:114-149). */
+ * pre_lut: a transfer table applied to all four halfs first (CVS_LUT_NONE for none); then a half->u8 ramp.
+ *
+ * cvs_frame_to_bytes_dev / video_frame_to_bytes use the gamma-0.45 ramp of video_get_gamma45_ramp():
+ *   CVS_DISPLAY_RGBA8: bytes r,g,b,a -- with CVS_LUT_NONE the exporter's conversion (src/libav/writeVideo.c:328-340,
+ *     whose own ramp at :108-115 holds the same bytes).
+ *   CVS_DISPLAY_ARGB32_PREMUL: a<<24 | (r*a>>8)<<16 | (g*a>>8)<<8 | (b*a>>8), what RgbaFrameF16.to_argb32_bytes
+ *     returns (src/process/RgbaFrameF16.c:114-149).
+ * cvs_frame_to_rgba8_intent_dev / video_frame_to_rgba8_intent use the software widget's ramp,
+ *   lrint(clamp(x^rendering_intent * 255, 0, 255)) (src/cprocess/widget_gl.c:955-968): with CVS_LUT_LINEAR_TO_SRGB
+ *   and the widget's default intent 1.25 (:428-429) they are its frame conversion (:291-307), bytes r,g,b,a. */
 enum { CVS_DISPLAY_RGBA8 = 0, CVS_DISPLAY_ARGB32_PREMUL = 1 };
 CVS_EXPORT int cvs_frame_to_bytes_dev(void *dst_dev, const rgba_frame_f16 *frame, int pre_lut, int mode, cvs_stream_t stream);
 CVS_EXPORT int video_frame_to_bytes(void *dst_host, const rgba_frame_f16 *host_frame, int pre_lut, int mode);
+CVS_EXPORT int cvs_frame_to_rgba8_intent_dev(void *dst_dev, const rgba_frame_f16 *frame, int pre_lut, float rendering_intent, cvs_stream_t stream);
+CVS_EXPORT int video_frame_to_rgba8_intent(void *dst_host, const rgba_frame_f16 *host_frame, int pre_lut, float rendering_intent);
 
 /* blur node between two f16 frames (widen on load, f32 passes, truncate on store), one launch */
 CVS_EXPORT int cvs_fir_blur_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, const float *taps, int ntaps, cvs_stream_t stream);

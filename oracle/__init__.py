@@ -69,6 +69,8 @@ def _bind(lib):
         "orc_reconstruct_dv": (None, [P(rgba_frame_f16), P(C.c_void_p), P(C.c_int)]),
         "orc_subsample_dv": (None, [P(C.c_void_p), P(C.c_int), P(rgba_frame_f16)]),
         "orc_frame_to_bytes": (None, [P(C.c_uint32), P(rgba_frame_f16), u16p, C.c_int]),
+        "orc_widget_ramp": (None, [P(C.c_uint8), C.c_float]),
+        "orc_frame_to_rgba8_intent": (None, [P(C.c_uint32), P(rgba_frame_f16), u16p, C.c_float]),
         "orc_chain_color_over_f16": (None, [P(rgba_frame_f16), P(P(rgba_frame_f16)), C.c_int, f32p, u16p, u16p]),
     }
     for name, (res, args) in sig.items():

@@ -145,15 +145,15 @@ void orc_chain_color_over_f16(orc_frame16 *out, orc_frame16 *const *layers, int 
 }
 
 /* ---- display / export edge ----
- * mode 0: bytes r,g,b,a.  With `pre` = the linear->sRGB table this is the software widget's conversion
- *   (src/cprocess/widget_gl.c:291-307: the table over all four halfs of the row, then the ramp); with pre == NULL
- *   the exporter's (src/libav/writeVideo.c:328-340).
- * mode 1: premultiplied ARGB32 (src/process/RgbaFrameF16.c:114-149).
+ * Every reference edge is: optional transfer table over all four halfs, a 65536-entry half->u8 ramp, then packing.
+ * mode 0: bytes r,g,b,a.  With the gamma-0.45 ramp and pre == NULL this is the exporter's conversion
+ *   (src/libav/writeVideo.c:328-340); with pre = the linear->sRGB table and the widget's ramp, the software widget's
+ *   (src/cprocess/widget_gl.c:291-307).
+ * mode 1: premultiplied ARGB32 (src/process/RgbaFrameF16.c:114-149, gamma-0.45 ramp).
  * dst is packed over current_window. */
-void orc_frame_to_bytes(uint32_t *dst, const orc_frame16 *frame, const orc_half *pre, int mode) {
+static void frame_to_bytes(uint32_t *dst, const orc_frame16 *frame, const orc_half *pre, const uint8_t *ramp, int mode) {
     const orc_box2i *w = &frame->current_window;
     if (w->max.x < w->min.x || w->max.y < w->min.y) return;
-    const uint8_t *ramp = orc_gamma45_ramp();
     const int width = w->max.x - w->min.x + 1;
     for (int y = w->min.y; y <= w->max.y; y++) {
         const orc_px16 *row = PX((orc_frame16 *)frame, w->min.x, y);
@@ -170,4 +170,16 @@ void orc_frame_to_bytes(uint32_t *dst, const orc_frame16 *frame, const orc_half 
             }
         }
     }
+}
+
+void orc_frame_to_bytes(uint32_t *dst, const orc_frame16 *frame, const orc_half *pre, int mode) {
+    frame_to_bytes(dst, frame, pre, orc_gamma45_ramp(), mode);
+}
+
+/* widget_gl.c:291-307: transfer table, then the widget's ramp, bytes r,g,b,a */
+void orc_frame_to_rgba8_intent(uint32_t *dst, const orc_frame16 *frame, const orc_half *pre, float rendering_intent) {
+    uint8_t *ramp = malloc(65536);
+    orc_widget_ramp(ramp, rendering_intent);
+    frame_to_bytes(dst, frame, pre, ramp, 0);
+    free(ramp);
 }

@@ -150,6 +150,17 @@ static void build_luts(void) {
     free(codes); free(f); free(g);
 }
 
+/* the software widget's ramp: src/cprocess/widget_gl.c:955-968 (rendering intent 1.25 by default, :428-429) */
+void orc_widget_ramp(uint8_t *ramp, float rendering_intent) {
+    orc_half *codes = malloc(65536 * sizeof(orc_half));
+    float *f = malloc(65536 * sizeof(float));
+    for (int i = 0; i < 65536; i++) codes[i] = (orc_half)i;
+    orc_half_to_float(f, codes, 65536);
+    for (int i = 0; i < 65536; i++)
+        ramp[i] = (uint8_t)lrint(clampf_(powf(f[i], rendering_intent) * 255.0f, 0.0f, 255.0f));
+    free(codes); free(f);
+}
+
 const orc_half *orc_transfer_table(int which) {
     pthread_once(&lut_once, build_luts);
     return (which >= 0 && which < 4) ? lut[which] : NULL;

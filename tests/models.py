@@ -129,6 +129,16 @@ def bytes_model(codes, ramp, pre, premultiplied_argb):
     return (a << 24) | ((((r * a) >> 8) & 0xFF) << 16) | ((((g * a) >> 8) & 0xFF) << 8) | (((b * a) >> 8) & 0xFF)
 
 
+def widget_ramp_model(intent):
+    """widget_gl.c:955-968: ramp[i] = (uint8_t) lrint(clampf(powf(h2f(i), intent) * 255, 0, 255)); clampf sends NaN to 0."""
+    with np.errstate(all="ignore"):
+        x = np.arange(65536, dtype=np.uint16).view(np.float16).astype(F32)
+        v = (np.power(x, F32(intent)).astype(F32) * F32(255.0)).astype(F32)
+        v = np.where(v > F32(0.0), v, F32(0.0))                  # framework.h clampf: max first (NaN -> lo), then min
+        v = np.where(v < F32(255.0), v, F32(255.0))
+        return np.rint(v).astype(np.uint8)                       # lrint: to nearest, ties to even
+
+
 def _fir_pass(src, valid, taps_for_line, axis):
     """One gather pass along `axis` (0: rows, 1: columns) over a whole array.  taps_for_line(t) -> [(source index, weight)]
     ascending; `valid` marks the source lines that exist (others are skipped taps).  Sums start at 0.0f."""

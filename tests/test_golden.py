@@ -79,6 +79,14 @@ def test_library_reproduces_golden_graph_and_edges(golden):
         got = np.zeros((16, 32), np.uint32)
         _lib.check(lib.video_frame_to_bytes(got.ctypes.data, disp.ref(), pre, mode))
         assert np.array_equal(got, golden["display_" + tag]), tag
+    got = np.zeros((16, 32), np.uint32)
+    _lib.check(lib.video_frame_to_rgba8_intent(got.ctypes.data, disp.ref(), _lib.LUT_LINEAR_TO_SRGB, C.c_float(1.25)))
+    assert np.array_equal(got, golden["display_widget"]), "widget"
+    # the widget's ramp itself, through an identity frame of all codes (no transfer table)
+    allc = HostFrame((0, 0, 127, 127), np.uint16, np.arange(65536, dtype=np.uint16).reshape(128, 128, 4))
+    got = np.zeros((128, 128), np.uint32)
+    _lib.check(lib.video_frame_to_rgba8_intent(got.ctypes.data, allc.ref(), _lib.LUT_NONE, C.c_float(1.25)))
+    assert np.array_equal(got.view(np.uint8).reshape(-1), golden["widget_ramp_125"]), "widget ramp"
     img = _lib.coded_image()
     import sys
     sys.path.insert(0, os.path.join(HERE, "golden"))

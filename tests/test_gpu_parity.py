@@ -938,6 +938,46 @@ def test_frame_to_bytes(cvs, orc, mode, pre, geom):
     assert np.array_equal(got2, want)
 
 
+@pytest.mark.parametrize("intent", [1.25, 1.0, 0.7])
+@pytest.mark.parametrize("pre", [_lib.LUT_NONE, _lib.LUT_LINEAR_TO_SRGB])
+def test_frame_to_rgba8_with_the_widget_ramp(cvs, orc, pre, intent):
+    """widget_gl.c:291-307: transfer table, then the ramp lrint(clamp(x^intent * 255)) -- every half code, several intents
+    (each (table, intent) pair is its own cached byte table; more pairs than cache slots are exercised across the suite)."""
+    full, cur = (-3, -2, 200, 90), (5, 1, 150, 77)
+    frame = _all_codes_frame(full, cur)
+    w, h = cur[2] - cur[0] + 1, cur[3] - cur[1] + 1
+    want = np.zeros((h, w), np.uint32)
+    table = None if pre == _lib.LUT_NONE else orc.transfer_table(pre)
+    orc.lib().orc_frame_to_rgba8_intent(want.ctypes.data_as(C.POINTER(C.c_uint32)), frame.ref(), None if table is None else u16p(table), C.c_float(intent))
+    dev = DeviceFrame.from_host(frame)
+    out = cvs.cvs_malloc(w * h * 4)
+    try:
+        _lib.check(cvs.cvs_frame_to_rgba8_intent_dev(out, dev.ref(), pre, C.c_float(intent), None))
+        got = np.zeros((h, w), np.uint32)
+        _lib.check(cvs.cvs_memcpy_d2h(got.ctypes.data, out, w * h * 4, None))
+    finally:
+        cvs.cvs_free(out)
+    assert np.array_equal(got, want)
+    got2 = np.zeros((h, w), np.uint32)
+    _lib.check(cvs.video_frame_to_rgba8_intent(got2.ctypes.data, frame.ref(), pre, C.c_float(intent)))
+    assert np.array_equal(got2, want)
+
+
+def test_display_table_cache_evicts_and_rebuilds(cvs, orc):
+    """More (table, ramp) pairs than the cache holds, revisited: an evicted pair must come back right."""
+    frame = _all_codes_frame((0, 0, 63, 63), (0, 0, 63, 63))
+    intents = [0.5 + 0.1 * k for k in range(12)]
+    for intent in intents + intents[:3]:
+        want = np.zeros((64, 64), np.uint32)
+        got = np.zeros((64, 64), np.uint32)
+        orc.lib().orc_frame_to_rgba8_intent(want.ctypes.data_as(C.POINTER(C.c_uint32)), frame.ref(), None, C.c_float(intent))
+        _lib.check(cvs.video_frame_to_rgba8_intent(got.ctypes.data, frame.ref(), _lib.LUT_NONE, C.c_float(intent)))
+        assert np.array_equal(got, want), intent
+    _lib.check(cvs.video_frame_to_bytes(got.ctypes.data, frame.ref(), _lib.LUT_NONE, _lib.DISPLAY_RGBA8))
+    orc.lib().orc_frame_to_bytes(want.ctypes.data_as(C.POINTER(C.c_uint32)), frame.ref(), None, 0)
+    assert np.array_equal(got, want)
+
+
 def test_frame_to_bytes_follows_an_installed_table(cvs, orc):
     """cvs_lut_install replaces a transfer table: the byte table composed from it must follow."""
     frame = _all_codes_frame((0, 0, 63, 63), (0, 0, 63, 63))

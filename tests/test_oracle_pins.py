@@ -373,6 +373,24 @@ def test_gain_offset_and_bytes_match_models(orc):
         orc.lib().orc_frame_to_bytes(packed.ctypes.data_as(C.POINTER(C.c_uint32)), src.ref(),
                                      None if table is None else table.ctypes.data_as(C.POINTER(C.c_uint16)), mode)
         assert np.array_equal(packed, bytes_model(codes, ramp, table, mode == 1))
+    # the software widget's ramp (rendering intent) and its frame conversion
+    from tests.models import widget_ramp_model
+    for intent in (1.25, 1.0, 0.8):
+        got = np.zeros(65536, np.uint8)
+        orc.lib().orc_widget_ramp(got.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_float(intent))
+        want = widget_ramp_model(intent)
+        # numpy's powf and libm's may differ in the last place: a byte may move only where x^intent*255 sits on a rounding tie
+        diff = np.flatnonzero(got != want)
+        assert diff.size <= 4 and np.all(np.abs(got[diff].astype(int) - want[diff].astype(int)) == 1), (intent, diff)
+        packed = np.zeros((36, 64), np.uint32)
+        orc.lib().orc_frame_to_rgba8_intent(packed.ctypes.data_as(C.POINTER(C.c_uint32)), src.ref(),
+                                            orc.transfer_table(3).ctypes.data_as(C.POINTER(C.c_uint16)), C.c_float(intent))
+        assert np.array_equal(packed, bytes_model(codes, got, orc.transfer_table(3), False))
+    ramp125 = np.zeros(65536, np.uint8)
+    orc.lib().orc_widget_ramp(ramp125.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_float(1.25))
+    # known answers: 0 -> 0, 1.0 -> 255, 0.5 -> lrint(0.5^1.25 * 255) = 107, negatives and NaN -> 0, +inf -> 255
+    assert ramp125[0x0000] == 0 and ramp125[0x3C00] == 255 and ramp125[0x3800] == 107
+    assert ramp125[0xBC00] == 0 and ramp125[0x7E00] == 0 and ramp125[0x7C00] == 255
 
 
 def test_blur_and_lanczos_match_models(orc):

@@ -309,7 +309,10 @@ def test_preview_pulls_convert_on_the_device(process, bt, orc):
     assert bytes(raw) == want.tobytes()
     rgba, cur2 = ws.get_frame_rgba8(3, window)
     table = orc.transfer_table(3)
-    orc.lib().orc_frame_to_bytes(want.ctypes.data_as(C.POINTER(C.c_uint32)), host.ref(), table.ctypes.data_as(C.POINTER(C.c_uint16)), 0)
+    orc.lib().orc_frame_to_rgba8_intent(want.ctypes.data_as(C.POINTER(C.c_uint32)), host.ref(), table.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_float(1.25))
+    assert cur2 == cur and bytes(rgba) == want.tobytes()           # the widget's default rendering intent
+    rgba, cur2 = ws.get_frame_rgba8(3, window, rendering_intent=1.0)
+    orc.lib().orc_frame_to_rgba8_intent(want.ctypes.data_as(C.POINTER(C.c_uint32)), host.ref(), table.ctypes.data_as(C.POINTER(C.c_uint16)), C.c_float(1.0))
     assert cur2 == cur and bytes(rgba) == want.tobytes()
     nothing, cur3 = process.EmptyVideoSource().get_frame_argb32(0, window)
     assert nothing is None and cur3.empty()
