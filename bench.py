@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--translucent-base", action="store_true",
                     help="NOT the BASELINE input: random alpha on layer 0 as well, so every divide of the over operator is live")
     ap.add_argument("--no-arena", action="store_true", help="one hipMalloc per frame instead of one arena for the ring")
+    ap.add_argument("--slot-pad", type=int, default=0, help="extra bytes between consecutive frames of the arena (placement experiment; multiple of 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -161,7 +162,7 @@ def main():
     # one arena for the whole ring: a single large allocation maps with far fewer page-table entries than
     # dozens of 66 MB ones, and the TLB reach of the chip is what a multi-GB streaming working set leans on
     frame_bytes = w * h * 8
-    slot = (frame_bytes + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+    slot = (frame_bytes + (2 << 20) - 1) // (2 << 20) * (2 << 20) + args.slot_pad
     arena = None if args.no_arena else lib.cvs_malloc(slot * (nl + 1) * len(my_frames))
     at = [arena]
 
