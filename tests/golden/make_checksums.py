@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""SHA-256 of the oracle's outputs for the BASELINE configs at their FULL sizes, frame 0 of the
+synthetic stream: tests/golden/full_size_sha256.json.  The inputs are the counter-based synthetic frames of
+canvas_amd.synth, the outputs are hashed after canonicalisation (both zeros -> +0, every NaN -> 0x7E00: neither is
+pinned by the reference build).  Run here, with this container's libm; the GPU box compares the library's outputs
+with the committed hashes, so a libm or generator drift shows up as a mismatch rather than silently moving both sides.
+
+    python tests/golden/make_checksums.py            # takes about a minute
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def canon_sha256(codes):
+    from tests.util import canon_f16
+    return hashlib.sha256(canon_f16(codes).tobytes()).hexdigest()
+
+
+def config2(oracle):
+    from canvas_amd import REC709_RGB_TO_YPBPR, synth
+    layers = [synth.layer_frame(3840, 2160, k, 0) for k in range(2)]
+    out = oracle.chain_color_over(layers, np.array(REC709_RGB_TO_YPBPR, np.float32), oracle.transfer_table(0), None)
+    return out.array
+
+
+def config3(oracle):
+    from canvas_amd import synth
+    from canvas_amd.abi import HostFrame
+    f32p = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    taps = synth.gaussian_taps(9, 1.5)
+    src16 = synth.layer_frame(3840, 2160, 1, 0)
+    src32 = HostFrame(src16.full_window, np.float32, oracle.half_to_float(src16.array))
+    blurred = HostFrame(src16.full_window, np.float32)
+    oracle.lib().orc_fir_blur_f32(blurred.ref(), src32.ref(), f32p(taps), 9)
+    small = HostFrame((0, 0, 1919, 1079), np.float32)
+    oracle.lib().orc_resample_lanczos_f32(small.ref(), blurred.ref(), C.c_float(0.5), C.c_float(0.5), 3)
+    return oracle.float_to_half(small.array)
+
+
+def config4(oracle):
+    from canvas_amd import synth
+    layers = [synth.layer_frame(7680, 4320, k, 0) for k in range(3)]
+    return oracle.chain_color_over(layers, None).array
+
+
+def config5(oracle):
+    from canvas_amd import REC709_RGB_TO_YPBPR, synth
+    from tests.util import oracle_graph
+    layers = [synth.layer_frame(3840, 2160, k, 0) for k in range(4)]
+    return oracle_graph(oracle, layers, np.array(REC709_RGB_TO_YPBPR, np.float32), oracle.transfer_table(0), None, synth.gaussian_taps(9, 1.5)).array
+
+
+CASES = {"config2_3840x2160": config2, "config3_3840x2160_to_1920x1080": config3, "config4_7680x4320": config4, "config5_3840x2160": config5}
+
+
+def checksums(only=None):
+    import oracle
+    oracle.lib()
+    out = {}
+    for name, fn in CASES.items():
+        if only and name not in only:
+            continue
+        t0 = time.perf_counter()
+        arr = fn(oracle)
+        out[name] = {"shape": list(arr.shape), "sha256": canon_sha256(arr)}
+        print("%-34s %s  (%.1f s)" % (name, out[name]["sha256"][:16], time.perf_counter() - t0), file=sys.stderr)
+    return out
+
+
+if __name__ == "__main__":
+    path = os.path.join(HERE, "full_size_sha256.json")
+    with open(path, "w") as f:
+        json.dump(checksums(), f, indent=1, sort_keys=True)
+        f.write("\n")
+    print("wrote", path)

@@ -33,6 +33,69 @@ def test_oracle_reproduces_every_golden_vector(orc, golden):
             assert np.array_equal(a, b), k
 
 
+@pytest.fixture(scope="module")
+def full_size_sums():
+    import json
+    with open(os.path.join(HERE, "golden", "full_size_sha256.json")) as f:
+        return json.load(f)
+
+
+def test_oracle_reproduces_full_size_checksums(orc, full_size_sums):
+    """Configs 2 and 3 at 3840x2160 (the 8K and the graph cases are left to make_checksums.py: they take half a minute)."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_checksums
+    names = ["config2_3840x2160", "config3_3840x2160_to_1920x1080"]
+    fresh = make_checksums.checksums(only=names)
+    for n in names:
+        assert fresh[n] == full_size_sums[n], n
+
+
+@pytest.mark.gpu
+def test_library_reproduces_full_size_checksums(full_size_sums):
+    """Every BASELINE config at its full size, frame 0: the library's output hashes to the committed value (no oracle run
+    on the GPU box: the fixture was made by the oracle in the build container)."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_checksums import canon_sha256
+    from canvas_amd import REC709_RGB_TO_YPBPR, _lib, synth
+    from canvas_amd.device import DeviceFrame, chain_color_over
+    from canvas_amd.stream import GraphStream
+    lib = _lib.load()
+    assert lib.cvs_init(0) == 0
+    lib.init_half()
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    f32p = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+
+    def chain(w, h, n, matrix, pre):
+        dl = [DeviceFrame.from_host(synth.layer_frame(w, h, k, 0)) for k in range(n)]
+        out = DeviceFrame((0, 0, w - 1, h - 1), np.uint16)
+        chain_color_over([(out, dl)], matrix, pre, _lib.LUT_NONE)
+        _lib.check(lib.cvs_stream_sync(None))
+        assert lib.cvs_chain_last_was_fused() == 1
+        got = out.download().array
+        for d in dl + [out]:
+            d.free()
+        return got
+
+    got = {"config2_3840x2160": chain(3840, 2160, 2, m, _lib.LUT_REC709_TO_LINEAR_SCENE)}
+    taps = synth.gaussian_taps(9, 1.5)
+    src = DeviceFrame.from_host(synth.layer_frame(3840, 2160, 1, 0))
+    small = DeviceFrame((0, 0, 1919, 1079), np.uint16)
+    _lib.check(lib.cvs_blur_lanczos_f16_dev(small.ref(), src.ref(), f32p(taps), 9, C.c_float(0.5), C.c_float(0.5), 3, None))
+    got["config3_3840x2160_to_1920x1080"] = small.download().array
+    src.free(); small.free()
+    got["config4_7680x4320"] = chain(7680, 4320, 3, None, _lib.LUT_NONE)
+    g = GraphStream(3840, 2160, ring=1)
+    out = g.render(0)
+    _lib.check(lib.cvs_stream_sync(None))
+    got["config5_3840x2160"] = out.download().array
+    assert sorted(got) == sorted(full_size_sums)
+    for name, arr in got.items():
+        assert list(arr.shape) == full_size_sums[name]["shape"], name
+        assert canon_sha256(arr) == full_size_sums[name]["sha256"], name
+
+
 @pytest.mark.gpu
 def test_library_reproduces_golden_chain_and_tables(golden):
     from canvas_amd import REC709_RGB_TO_YPBPR, _lib, synth
