@@ -12,5 +12,8 @@ mkdir -p gpurun_out
   echo "### tools/time_ops.py (single 4K frames, every device entry point)"; timeout -k 10 200 python tools/time_ops.py 2>&1
   echo "### tools/time_scale.py (triangle scaler)"; timeout -k 10 200 python tools/time_scale.py 2>&1
   echo "### tools/time_config1.py (config 1 through the Python surface)"; timeout -k 10 200 python tools/time_config1.py 2>&1
+  echo "### tools/time_host_frames.py (config 2 from host buffers: PCIe included)"; timeout -k 10 200 python tools/time_host_frames.py 2>&1
+  echo "### tools/time_fixed_cost.py (per-launch fixed cost of the chain kernel)"; timeout -k 10 200 python tools/time_fixed_cost.py 2>&1
+  echo "### tools/time_graph.py (HIP graph replay against direct enqueue)"; timeout -k 10 200 python tools/time_graph.py 2>&1
 } > $out 2>&1
 tail -5 $out
