@@ -17,6 +17,7 @@
 //
 // Bound: HBM.  Algorithmic bytes: colour = 8 r + 8 w per pixel; lookup = 2 r + 2 w per half;
 // chain = 8 * nlayers r + 8 w per output pixel (config 2: 24 B/px).
+#include <cstdlib>
 #include "lut_common.hpp"
 #include "grade.hpp"
 #include "chain_math.hpp"
@@ -67,23 +68,31 @@ __global__ __launch_bounds__(kWG) void k_color(cvk_view dst, cvk_view src, cvk_r
     }
 }
 
-// whole rows, both buffers packed the same way: a flat stream of pixel pairs (16 B per lane, non-temporal),
-// 512 lanes per CU as in the chain kernel.  8 B read + 8 B written per pixel.
+// whole rows, both buffers packed the same way: a flat stream of pixel pairs (16 B per lane, non-temporal), one
+// 1024-lane workgroup per CU, every load a trip ahead of its use (measured on single 4K frames: 0.0345 ms without the
+// prefetch at 512 lanes, 0.030 with it, 0.025 at 1024 lanes; CVS_COLOR_BLOCK overrides the lane count).
+// 8 B read + 8 B written per pixel.
 template <bool PRE, bool POST>
 __global__ __launch_bounds__(kWG) void k_color_flat(uint16_t *__restrict__ dst, const uint16_t *__restrict__ src, size_t npixels, Mat kmat,
                                                     const uint16_t *__restrict__ pre, const uint16_t *__restrict__ post) {
     const MatR mat = CVS_MAT_REGS(kmat);
     __shared__ uint16_t lut[(PRE || POST) ? kLutHalfs : 1];
+    const size_t npairs = npixels / 2, stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the first pair is requested before the table is staged, every later one a trip ahead of its use
+    u32x4 cur = { 0u, 0u, 0u, 0u };
+    if (i < npairs) cur = __builtin_nontemporal_load((g_cu4)src + i);
     if (PRE || POST) {
         const uint4 *t = reinterpret_cast<const uint4 *>(PRE ? pre : post);
         uint4 *d = reinterpret_cast<uint4 *>(lut);
-        for (int i = threadIdx.x; i < kLutHalfs * 2 / 16; i += blockDim.x) d[i] = t[i];
+        for (int k = threadIdx.x; k < kLutHalfs * 2 / 16; k += blockDim.x) d[k] = t[k];
         __syncthreads();
     }
-    const size_t npairs = npixels / 2, stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += stride) {
-        const u32x4 p = __builtin_nontemporal_load((g_cu4)src + i);
-        __builtin_nontemporal_store(color_pair_codes<PRE, POST>(p, mat, lut, post), (g_u4)dst + i);
+    for (; i < npairs; i += stride) {
+        u32x4 nxt = cur;
+        if (i + stride < npairs) nxt = __builtin_nontemporal_load((g_cu4)src + i + stride);
+        __builtin_nontemporal_store(color_pair_codes<PRE, POST>(cur, mat, lut, post), (g_u4)dst + i);
+        cur = nxt;
     }
     if ((npixels & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
         const uint2 p = reinterpret_cast<const uint2 *>(src)[npixels - 1];
@@ -112,7 +121,9 @@ extern "C" int cvk_color_matrix(cvk_view dst, cvk_view src, cvk_rect r, const fl
         uint16_t *d = reinterpret_cast<uint16_t *>(dst.data) + (size_t)(r.y0 - dst.fy0) * (size_t)dst.pitch * 4;
         const uint16_t *q = reinterpret_cast<const uint16_t *>(src.data) + (size_t)(r.y0 - src.fy0) * (size_t)src.pitch * 4;
         if (((((uintptr_t)d) | ((uintptr_t)q)) & 15u) == 0) {
-            dim3 grid((unsigned)(cus > 0 ? cus : 256)), block(512);
+            static int env_block = -1;
+            if (env_block < 0) { const char *e = getenv("CVS_COLOR_BLOCK"); env_block = e ? atoi(e) : 0; }
+            dim3 grid((unsigned)(cus > 0 ? cus : 256)), block(env_block ? env_block : kWG);
             if (pre && post)  hipLaunchKernelGGL((k_color_flat<true, true>), grid, block, 0, s, d, q, n, mat, pre, post);
             else if (pre)     hipLaunchKernelGGL((k_color_flat<true, false>), grid, block, 0, s, d, q, n, mat, pre, post);
             else if (post)    hipLaunchKernelGGL((k_color_flat<false, true>), grid, block, 0, s, d, q, n, mat, pre, post);

@@ -50,12 +50,18 @@ __global__ __launch_bounds__(kLanes) void k_display(uint32_t *__restrict__ dst, 
 template <int MODE>
 __global__ __launch_bounds__(kLanes) void k_display_flat(uint32_t *__restrict__ dst, const uint2 *__restrict__ src, size_t npixels, const uint8_t *__restrict__ table) {
     __shared__ __attribute__((aligned(16))) uint8_t t[kTable];
-    stage(t, table);
     const size_t npairs = npixels / 2, stride = (size_t)gridDim.x * kLanes;
-    for (size_t i = (size_t)blockIdx.x * kLanes + threadIdx.x; i < npairs; i += stride) {
-        const v4 p = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(src) + i);
-        const v2 o = { pack<MODE>(t, make_uint2(p.x, p.y)), pack<MODE>(t, make_uint2(p.z, p.w)) };
+    size_t i = (size_t)blockIdx.x * kLanes + threadIdx.x;
+    // the first pair is requested before the table is staged, every later one a trip ahead of its use
+    v4 cur = { 0u, 0u, 0u, 0u };
+    if (i < npairs) cur = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(src) + i);
+    stage(t, table);
+    for (; i < npairs; i += stride) {
+        v4 nxt = cur;
+        if (i + stride < npairs) nxt = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(src) + i + stride);
+        const v2 o = { pack<MODE>(t, make_uint2(cur.x, cur.y)), pack<MODE>(t, make_uint2(cur.z, cur.w)) };
         __builtin_nontemporal_store(o, reinterpret_cast<v2 *>(dst) + i);
+        cur = nxt;
     }
     if ((npixels & 1) && blockIdx.x == 0 && threadIdx.x == 0) dst[npixels - 1] = pack<MODE>(t, src[npixels - 1]);
 }
