@@ -648,6 +648,7 @@ CVS_EXPORT int cvs_blur_over_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *
     if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
     CVS_REQUIRE_INSIDE(source, out, "cvs_blur_over_f16_dev");
     if (ntaps < 1 || !taps || noverlays < 0 || (noverlays > 0 && !overlays)) { cvs_set_error("blur+over: bad arguments"); box2i_set_empty(&out->current_window); return -1; }
+    if (noverlays == 0) return cvs_fir_blur_f16_dev(out, source, taps, ntaps, stream);       /* a stack of one: the blur node pulled as f16 */
     hipStream_t s = cvs_pick_stream(stream);
     const box2i *full = &out->full_window;
     if (box2i_is_empty(full)) { box2i_set_empty(&out->current_window); return 0; }

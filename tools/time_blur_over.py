@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""The blur node with 0..3 layers blended over it in the same launch (3840x2160 f16, 9 taps): what the epilogue costs.
+Ten launches between two events, median of 7."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from canvas_amd import _lib, synth  # noqa: E402
+from canvas_amd.device import DeviceFrame  # noqa: E402
+
+lib = _lib.load()
+_lib.check(lib.cvs_init(0))
+lib.init_half()
+stream = lib.cvs_stream_create()
+w, h = 3840, 2160
+full = (0, 0, w - 1, h - 1)
+src = DeviceFrame.from_host(synth.layer_frame(w, h, 0, 0))
+over = [DeviceFrame.from_host(synth.layer_frame(w, h, k, 0)) for k in (1, 2, 3)]
+out = DeviceFrame(full, np.uint16)
+taps = synth.gaussian_taps(9, 1.5)
+tp = taps.ctypes.data_as(C.POINTER(C.c_float))
+e0, e1 = lib.cvs_event_create(), lib.cvs_event_create()
+for n in range(4):
+    refs = (C.POINTER(_lib.rgba_frame_f16_t) * max(n, 1))(*[C.pointer(o.c) for o in over[:max(n, 1)]])
+    fn = lambda: _lib.check(lib.cvs_blur_over_f16_dev(out.ref(), src.ref(), tp, 9, refs, n, stream))
+    fn()
+    lib.cvs_stream_sync(stream)
+    ts = []
+    for _ in range(7):
+        lib.cvs_event_record(e0, stream)
+        for _ in range(10):
+            fn()
+        lib.cvs_event_record(e1, stream)
+        lib.cvs_stream_sync(stream)
+        ts.append(lib.cvs_event_elapsed_ms(e0, e1) / 10)
+    ms = sorted(ts)[3]
+    bpp = 16 + 8 * n
+    print("blur + %d over: %.4f ms, %d B/px -> %.0f GB/s" % (n, ms, bpp, w * h * bpp / ms / 1e6))
