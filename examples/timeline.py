@@ -64,8 +64,11 @@ timeline.get_frame_rgba8(0, window)                       # first use: tables, c
 t0 = time.perf_counter()
 for i in range(FRAMES):
     rgba, cur = timeline.get_frame_rgba8(i, window)      # sRGB bytes made on the device, 4 B/px downloaded
-    if out_dir and rgba is not None and i % 10 == 0:
-        os.makedirs(out_dir, exist_ok=True)
-        write_png(os.path.join(out_dir, "frame_%03d.png" % i), rgba, cur.max.x - cur.min.x + 1, cur.max.y - cur.min.y + 1)
 dt = time.perf_counter() - t0
 print("%d frames of %dx%d in %.1f ms: %.0f Mpx/s through the Python surface (preview bytes included)" % (FRAMES, W, H, dt * 1e3, FRAMES * W * H / dt / 1e6))
+if out_dir:
+    os.makedirs(out_dir, exist_ok=True)
+    for i in range(0, FRAMES, 10):
+        rgba, cur = timeline.get_frame_rgba8(i, window)
+        if rgba is not None:
+            write_png(os.path.join(out_dir, "frame_%03d.png" % i), rgba, cur.max.x - cur.min.x + 1, cur.max.y - cur.min.y + 1)
