@@ -122,7 +122,11 @@ extern "C" int cvk_color_matrix(cvk_view dst, cvk_view src, cvk_rect r, const fl
         const uint16_t *q = reinterpret_cast<const uint16_t *>(src.data) + (size_t)(r.y0 - src.fy0) * (size_t)src.pitch * 4;
         if (((((uintptr_t)d) | ((uintptr_t)q)) & 15u) == 0) {
             static int env_block = -1;
-            if (env_block < 0) { const char *e = getenv("CVS_COLOR_BLOCK"); env_block = e ? atoi(e) : 0; }
+            if (env_block < 0) {
+                const char *e = getenv("CVS_COLOR_BLOCK");
+                env_block = e ? atoi(e) : 0;
+                if (env_block < 64 || env_block > kWG || (env_block & 63)) env_block = 0;
+            }
             dim3 grid((unsigned)(cus > 0 ? cus : 256)), block(env_block ? env_block : kWG);
             if (pre && post)  hipLaunchKernelGGL((k_color_flat<true, true>), grid, block, 0, s, d, q, n, mat, pre, post);
             else if (pre)     hipLaunchKernelGGL((k_color_flat<true, false>), grid, block, 0, s, d, q, n, mat, pre, post);
