@@ -53,6 +53,7 @@ SIGNATURES = {
     "video_get_frame_dev": (None, [P(video_source), C.c_int, P(rgba_frame_dev)]),
     "video_copy_frame_f16": (None, [_F16, _F16]),
     "video_copy_frame_alpha_f32": (None, [_F32, _F32, C.c_float]),
+    "video_attenuate_f32": (None, [_F32, C.c_float]),
     "video_mix_cross_f32": (None, [_F32, _F32, _F32, C.c_float]),
     "video_mix_cross_f32_pull": (None, [_F32, P(video_source), C.c_int, P(video_source), C.c_int, C.c_float]),
     "video_mix_over_f32": (None, [_F32, _F32, C.c_float]),

@@ -195,6 +195,9 @@ CVS_EXPORT void video_copy_frame_alpha_f32(rgba_frame_f32 *out, rgba_frame_f32 *
     cvs_stage_free(&d_in); cvs_stage_free(&d_out);
 }
 
+/* framework.h:236 (declared there, defined nowhere in the reference): the in-place case of the copy above */
+CVS_EXPORT void video_attenuate_f32(rgba_frame_f32 *frame, float alpha) { video_copy_frame_alpha_f32(frame, frame, alpha); }
+
 CVS_EXPORT void video_mix_cross_f32(rgba_frame_f32 *out, rgba_frame_f32 *a, rgba_frame_f32 *b, float mix_b) {
     if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return; }
     hipStream_t s = cvs_pick_stream(NULL);

@@ -157,6 +157,10 @@ CVS_EXPORT void video_get_frame_dev(video_source *source, int frame_index, rgba_
 /* src/cprocess/video_mix.c:27-44, 73-105, 107-235, 46-71, 237-370 */
 CVS_EXPORT void video_copy_frame_f16(rgba_frame_f16 *out, rgba_frame_f16 *in);
 CVS_EXPORT void video_copy_frame_alpha_f32(rgba_frame_f32 *out, rgba_frame_f32 *in, float alpha);
+/* include/framework.h:236 declares video_attenuate_f32 and no reference source defines it; here it is the in-place
+ * case of video_copy_frame_alpha_f32 (video_mix.c:73-105 with out == in): alpha 1 leaves the frame alone, alpha 0
+ * empties its window, anything between multiplies the alpha channel over the current window. */
+CVS_EXPORT void video_attenuate_f32(rgba_frame_f32 *frame, float alpha);
 CVS_EXPORT void video_mix_cross_f32(rgba_frame_f32 *out, rgba_frame_f32 *a, rgba_frame_f32 *b, float mix_b);
 CVS_EXPORT void video_mix_cross_f32_pull(rgba_frame_f32 *out, video_source *a, int frame_a, video_source *b, int frame_b, float mix_b);
 CVS_EXPORT void video_mix_over_f32(rgba_frame_f32 *out, rgba_frame_f32 *b, float mix_b);

@@ -214,6 +214,18 @@ def test_copy_frame_alpha_f32(cvs, orc, out_full, in_full, in_cur, alpha):
     assert_same_f32(a.array, b.array, "copy_alpha")
 
 
+@pytest.mark.parametrize("alpha", [1.0, 0.4, 0.0, 1.5, -2.0])
+def test_attenuate_f32_is_the_in_place_copy(cvs, orc, alpha):
+    """framework.h:236 (no definition in the reference): defined as video_copy_frame_alpha_f32 with out == in."""
+    rng = np.random.default_rng(12)
+    a = rand_f32_frame(rng, (-2, -1, 20, 9), (1, 0, 15, 7))
+    b = a.copy()
+    cvs.video_attenuate_f32(a.ref(), C.c_float(alpha))
+    orc.lib().orc_copy_frame_alpha_f32(b.ref(), b.ref(), C.c_float(alpha))
+    assert same_window(a.current_window, b.current_window)
+    assert_same_f32(a.array, b.array, "attenuate")
+
+
 # ------------------------------------------------------------------ A6 / A7 mixers
 
 FULL = (0, 0, 23, 11)
