@@ -54,6 +54,8 @@ SIGNATURES = {
     "video_copy_frame_f16": (None, [_F16, _F16]),
     "video_copy_frame_alpha_f32": (None, [_F32, _F32, C.c_float]),
     "video_attenuate_f32": (None, [_F32, C.c_float]),
+    "cvs_pulldown23_frames": (C.c_int, [C.c_int, C.c_int, P(C.c_int), P(C.c_int)]),
+    "cvs_weave_fields_f16_dev": (C.c_int, [_F16, _F16, _vp]),
     "video_mix_cross_f32": (None, [_F32, _F32, _F32, C.c_float]),
     "video_mix_cross_f32_pull": (None, [_F32, P(video_source), C.c_int, P(video_source), C.c_int, C.c_float]),
     "video_mix_over_f32": (None, [_F32, _F32, C.c_float]),

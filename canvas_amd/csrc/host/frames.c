@@ -29,6 +29,36 @@ CVS_EXPORT int cvs_copy_frame_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 
     return 0;
 }
 
+/* src/process/Pulldown23RemovalFilter.c:51-71: which source frames make output frame `frame_index` of a 2:3 cadence
+ * with phase `offset` (0..4).  Returns 0 and *first for a whole frame, 1 and *first (odd rows) + *second (even rows)
+ * for a frame woven from two fields.  The arithmetic is the reference's, in int, shifts on negative values included. */
+CVS_EXPORT int cvs_pulldown23_frames(int offset, int frame_index, int *first, int *second) {
+    const int frame_offset = offset == 4 ? ((frame_index + 3) & 3) : ((frame_index + offset) & 3);
+    const int base = ((frame_index + offset) >> 2) * 5 - offset;
+    *second = base + 3;
+    switch (frame_offset) {
+    case 0: *first = base; return 0;
+    case 1: *first = base + 1; return 0;
+    case 3: *first = base + 4; return 0;
+    default: *first = base + 2; return 1;
+    }
+}
+
+/* :88-104: `other` was pulled into a buffer allocated for frame->current_window; its even rows replace the frame's */
+CVS_EXPORT int cvs_weave_fields_f16_dev(rgba_frame_f16 *frame, const rgba_frame_f16 *other, cvs_stream_t s) {
+    if (cvs_enter() != 0) return -1;
+    if (box2i_is_empty(&frame->current_window)) return 0;
+    if (!cvs_box_contains(&frame->full_window, &frame->current_window)) { cvs_set_error("cvs_weave_fields_f16_dev: current window outside the buffer"); return -1; }
+    if (memcmp(&other->full_window, &frame->current_window, sizeof(box2i)) != 0) {
+        cvs_set_error("cvs_weave_fields_f16_dev: the second field's buffer must be allocated for the frame's current window");
+        return -1;
+    }
+    box2i ocur;
+    box2i_intersect(&ocur, &other->current_window, &other->full_window);
+    CVS_KERNEL(cvk_weave_f16(cvs_view(frame->data, &frame->full_window), cvs_rect(&frame->current_window), other->data, cvs_rect(&ocur), cvs_pick_stream(s)));
+    return 0;
+}
+
 CVS_EXPORT int cvs_copy_frame_alpha_f32_dev(rgba_frame_f32 *out, const rgba_frame_f32 *in, float alpha, cvs_stream_t s) {
     if (cvs_enter() != 0) { box2i_set_empty(&out->current_window); return -1; }
     CVS_REQUIRE_INSIDE(in, out, "cvs_copy_frame_alpha_f32_dev");

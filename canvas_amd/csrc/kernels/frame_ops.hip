@@ -101,6 +101,26 @@ __global__ __launch_bounds__(kBlock) void k_copy16(cvk_view out, cvk_view in, cv
     *at<uint2>(out, x, y) = *at<const uint2>(in, x, y);
 }
 
+// 2:3 pulldown removal, the mixed-field case (src/process/Pulldown23RemovalFilter.c:88-104): the even rows of the
+// frame's current window are replaced by rows of `other`, a packed frame allocated for exactly that window.  The
+// reference addresses `other` from x = 0, not from the window's min.x (:101): the row it copies starts cur.x0 pixels
+// before the row it means.  Reproduced as linear addressing inside the allocation; outside it (the reference reads
+// foreign memory there) and outside other's current window (uninitialised there) the pixel is zero.
+__global__ __launch_bounds__(kBlock) void k_weave16(cvk_view frame, cvk_rect cur, const uint2 *__restrict__ other, cvk_rect ocur, int first) {
+    const int width = cur.x1 - cur.x0 + 1;
+    const int c = (int)(blockIdx.x * kBlock + threadIdx.x);
+    if (c >= width) return;
+    const int i = first + 2 * (int)blockIdx.y;
+    const long long n = (long long)width * (long long)(cur.y1 - cur.y0 + 1);
+    const long long l = (long long)(i - cur.y0) * (long long)width - (long long)cur.x0 + (long long)c;
+    uint2 v = make_uint2(0u, 0u);
+    if (l >= 0 && l < n) {
+        const int ty = cur.y0 + (int)(l / width), tx = cur.x0 + (int)(l % width);
+        if (tx >= ocur.x0 && tx <= ocur.x1 && ty >= ocur.y0 && ty <= ocur.y1) v = other[l];
+    }
+    *at<uint2>(frame, cur.x0 + c, i) = v;
+}
+
 __global__ __launch_bounds__(kBlock) void k_copy_alpha32(cvk_view out, cvk_view in, cvk_rect r, float alpha, int scale) {
     CVK_PIXEL_XY(r)
     float4 v = *at<const float4>(in, x, y);
@@ -189,6 +209,14 @@ extern "C" int cvk_float_to_half(uint16_t *out, const float *in, size_t count, i
 extern "C" int cvk_copy_f16(cvk_view out, cvk_view in, cvk_rect r, void *stream) {
     if (rect_empty(r)) return 0;
     LAUNCH(k_copy16, rect_grid(r), out, in, r)
+}
+
+extern "C" int cvk_weave_f16(cvk_view frame, cvk_rect cur, const void *other, cvk_rect other_cur, void *stream) {
+    if (rect_empty(cur)) return 0;
+    const int first = (cur.y0 + 1) & ~1;                  // Pulldown23RemovalFilter.c:100
+    if (first > cur.y1) return 0;
+    dim3 grid((unsigned)((cur.x1 - cur.x0 + 1 + kBlock - 1) / kBlock), (unsigned)((cur.y1 - first) / 2 + 1));
+    LAUNCH(k_weave16, grid, frame, cur, reinterpret_cast<const uint2 *>(other), other_cur, first)
 }
 
 extern "C" int cvk_copy_alpha_f32(cvk_view out, cvk_view in, cvk_rect r, float alpha, void *stream) {

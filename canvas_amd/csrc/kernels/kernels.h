@@ -31,6 +31,8 @@ int cvk_half_lookup(const uint16_t *table, uint16_t *out, const uint16_t *in, si
 /* windowed frame ops; rect must lie inside every view involved */
 int cvk_copy_f16(cvk_view out, cvk_view in, cvk_rect r, void *stream);
 int cvk_copy_alpha_f32(cvk_view out, cvk_view in, cvk_rect r, float alpha, void *stream);
+/* even rows of `cur` in `frame` <- rows of `other` (packed, allocated for exactly `cur`), Pulldown23RemovalFilter.c:88-104 */
+int cvk_weave_f16(cvk_view frame, cvk_rect cur, const void *other, cvk_rect other_cur, void *stream);
 int cvk_widen(cvk_view out32, cvk_view in16, cvk_rect r, void *stream);
 int cvk_narrow(cvk_view out16, cvk_view in32, cvk_rect r, void *stream);
 int cvk_fill_f16(cvk_view out, cvk_rect r, const float rgba[4], void *stream);      /* truncates to half in the kernel */

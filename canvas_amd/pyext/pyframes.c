@@ -345,11 +345,86 @@ static PyTypeObject py_type_LerpFunc = {
     .tp_base = &py_type_FrameFunction, .tp_new = PyType_GenericNew, .tp_init = (initproc)lerp_init, .tp_getset = lerp_getset,
 };
 
+/* FrameFuncPassThroughFilter(source, offset=0.0): the upstream function evaluated at frame + offset; a constant
+ * source passes through as that constant (src/process/FrameFuncPassThroughFilter.c:24-190).  Reader lock around the
+ * upstream call, writer lock where the source is replaced (:60,121-130). */
+typedef struct { PyObject_HEAD FrameFunctionHolder source; double offset; pthread_rwlock_t lock; bool ready; } py_ffpass;
+static PyObject *ffpass_capsule;
+static int ffpass_init(py_ffpass *self, PyObject *args, PyObject *kw) {
+    static char *kwlist[] = { "source", "offset", NULL };
+    PyObject *src;
+    self->offset = 0.0;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "O|d", kwlist, &src, &self->offset)) return -1;
+    if (!self->ready) { pthread_rwlock_init(&self->lock, NULL); self->ready = true; }
+    return py_framefunc_take_source(src, &self->source) ? 0 : -1;
+}
+static void ffpass_dealloc(py_ffpass *self) {
+    py_framefunc_take_source(NULL, &self->source);
+    if (self->ready) pthread_rwlock_destroy(&self->lock);
+    Py_TYPE(self)->tp_free((PyObject *)self);
+}
+static void ffpass_values(py_ffpass *self, ssize_t count, double *frames, double (*out)[4]) {
+    pthread_rwlock_rdlock(&self->lock);
+    if (self->source.funcs && self->source.funcs->get_values) {
+        double *shifted = NULL;
+        if (self->offset != 0.0 && count > 0) {
+            shifted = malloc(sizeof(double) * (size_t)count);
+            for (ssize_t i = 0; shifted && i < count; i++) shifted[i] = frames[i] + self->offset;
+        }
+        self->source.funcs->get_values(self->source.source, count, shifted ? shifted : frames, out);
+        free(shifted);
+    } else {
+        for (ssize_t i = 0; i < count; i++) memcpy(out[i], self->source.constant, sizeof self->source.constant);
+    }
+    pthread_rwlock_unlock(&self->lock);
+}
+static FrameFunctionFuncs ffpass_funcs = { 0, (framefunc_get_values_func)ffpass_values };
+static PyObject *ffpass_get_source(py_ffpass *self, PyObject *noargs) {
+    PyObject *o = self->source.source ? self->source.source : Py_None;
+    Py_INCREF(o);
+    return o;
+}
+static PyObject *ffpass_set_source(py_ffpass *self, PyObject *args) {
+    PyObject *src;
+    if (!PyArg_ParseTuple(args, "O", &src)) return NULL;
+    pthread_rwlock_wrlock(&self->lock);
+    const bool ok = py_framefunc_take_source(src, &self->source);
+    pthread_rwlock_unlock(&self->lock);
+    if (!ok) return NULL;
+    Py_RETURN_NONE;
+}
+static PyObject *ffpass_get_offset(py_ffpass *self, void *c) { return PyFloat_FromDouble(self->offset); }
+static int ffpass_set_offset(py_ffpass *self, PyObject *value, void *c) {
+    const double v = value ? PyFloat_AsDouble(value) : 0.0;
+    if (!value) { PyErr_SetString(PyExc_TypeError, "offset cannot be deleted"); return -1; }
+    if (v == -1.0 && PyErr_Occurred()) return -1;
+    self->offset = v;
+    return 0;
+}
+static PyMethodDef ffpass_methods[] = {
+    { "source", (PyCFunction)ffpass_get_source, METH_NOARGS, "Gets the source frame function." },
+    { "set_source", (PyCFunction)ffpass_set_source, METH_VARARGS, "Sets the source frame function." },
+    { NULL }
+};
+static PyGetSetDef ffpass_getset[] = {
+    { FRAME_FUNCTION_FUNCS, pyext_capsule_getter, NULL, "Frame function C API.", &ffpass_capsule },
+    { "offset", (getter)ffpass_get_offset, (setter)ffpass_set_offset, "Get or set the offset." },
+    { NULL }
+};
+static PyTypeObject py_type_FrameFuncPassThroughFilter = {
+    PyVarObject_HEAD_INIT(NULL, 0)
+    .tp_name = "fluggo.media.process.FrameFuncPassThroughFilter", .tp_basicsize = sizeof(py_ffpass),
+    .tp_flags = Py_TPFLAGS_DEFAULT | Py_TPFLAGS_BASETYPE, .tp_base = &py_type_FrameFunction, .tp_new = PyType_GenericNew,
+    .tp_init = (initproc)ffpass_init, .tp_dealloc = (destructor)ffpass_dealloc, .tp_getset = ffpass_getset, .tp_methods = ffpass_methods,
+};
+
 int init_framefuncs(PyObject *module) {
+    ffpass_capsule = PyCapsule_New(&ffpass_funcs, FRAME_FUNCTION_FUNCS, NULL);
+    if (!ffpass_capsule || pyext_add_type(module, "FrameFunction", &py_type_FrameFunction) < 0) return -1;
+    if (pyext_add_type(module, "FrameFuncPassThroughFilter", &py_type_FrameFuncPassThroughFilter) < 0) return -1;
     linear_capsule = PyCapsule_New(&linear_funcs, FRAME_FUNCTION_FUNCS, NULL);
     lerp_capsule = PyCapsule_New(&lerp_funcs, FRAME_FUNCTION_FUNCS, NULL);
     if (!linear_capsule || !lerp_capsule) return -1;
-    if (pyext_add_type(module, "FrameFunction", &py_type_FrameFunction) < 0) return -1;
     if (pyext_add_type(module, "LinearFrameFunc", &py_type_LinearFrameFunc) < 0) return -1;
     return pyext_add_type(module, "LerpFunc", &py_type_LerpFunc);
 }

@@ -11,6 +11,7 @@
  *   VideoScaler(source, target_point, source_point, scale_factors, source_rect)   src/process/VideoScaler.c:38-135
  *   VideoPassThroughFilter(source, offset=0, start_frame=None, end_frame=None)    src/process/VideoPassThroughFilter.c:46-283
  *   VideoSequence() list of (source, offset, length)    src/process/VideoSequence.c:58-343
+ *   Pulldown23RemovalFilter(source, offset)             src/process/Pulldown23RemovalFilter.c:31-107
  * Locking rule kept (VideoPassThroughFilter.c:121-148): reader lock around any upstream pull, writer
  * lock where a source reference is replaced.
  */
@@ -533,14 +534,61 @@ static PyTypeObject py_type_Seq = {
     .tp_getset = seq_getset, .tp_methods = seq_methods, .tp_as_sequence = &seq_as_sequence,
 };
 
+/* ---------------------------------------------------------------- Pulldown23RemovalFilter(source, offset)
+ * src/process/Pulldown23RemovalFilter.c:31-107: 2:3 pulldown removal (30 -> 24 frames/s).  Four of every five source
+ * frames map to output frames whole; the fifth output frame is woven from the odd rows of one source frame and the even
+ * rows of the next.  Index arithmetic and weave are the library's (cvs_pulldown23_frames, cvs_weave_fields_f16_dev);
+ * both source frames are pulled into device frames, nothing crosses PCIe. */
+
+typedef struct { node1 n; int offset; } py_pulldown;
+
+static int pulldown_init(py_pulldown *self, PyObject *args, PyObject *kw) {
+    PyObject *src;
+    if (!PyArg_ParseTuple(args, "Oi", &src, &self->offset)) return -1;
+    pthread_rwlock_init(&self->n.lock, NULL);
+    return py_video_take_source(src, &self->n.source) ? 0 : -1;
+}
+static void pulldown_dealloc(py_pulldown *self) {
+    py_video_take_source(NULL, &self->n.source);
+    pthread_rwlock_destroy(&self->n.lock);
+    Py_TYPE(self)->tp_free((PyObject *)self);
+}
+static void pulldown_render(PyObject *o, int frame_index, rgba_frame_dev *f) {      /* native: f16 */
+    py_pulldown *self = (py_pulldown *)o;
+    pthread_rwlock_rdlock(&self->n.lock);
+    if (!self->n.source) { box2i_set_empty(&f->current_window); pthread_rwlock_unlock(&self->n.lock); return; }
+    int first, second;
+    const int mixed = cvs_pulldown23_frames(self->offset, frame_index, &first, &second);
+    pull_dev(self->n.source, first, f);
+    if (mixed && !box2i_is_empty(&f->current_window)) {
+        rgba_frame_dev other = scratch_like(f, CVS_FORMAT_F16, &f->current_window);       /* :92-95: a buffer for exactly that window */
+        if (other.data) {
+            pull_dev(self->n.source, second, &other);
+            rgba_frame_f16 frame = { f->data, f->full_window, f->current_window }, field = { other.data, other.full_window, other.current_window };
+            if (cvs_weave_fields_f16_dev(&frame, &field, f->stream) != 0) box2i_set_empty(&f->current_window);
+            cvs_pool_free(other.data, f->stream);
+        } else box2i_set_empty(&f->current_window);
+    }
+    pthread_rwlock_unlock(&self->n.lock);
+}
+DEFINE_NODE_VTABLE(pulldown, CVS_FORMAT_F16, 1, 0)
+static void *pulldown_unused[] UNUSED = { (void *)pulldown_slot_32 };
+static PyGetSetDef pulldown_getset[] = { { VIDEO_FRAME_SOURCE_FUNCS, pyext_capsule_getter, NULL, "Video frame source C API.", &pulldown_capsule }, { NULL } };
+static PyTypeObject py_type_Pulldown = {
+    PyVarObject_HEAD_INIT(NULL, 0)
+    .tp_name = "fluggo.media.process.Pulldown23RemovalFilter", .tp_basicsize = sizeof(py_pulldown), .tp_flags = Py_TPFLAGS_DEFAULT,
+    .tp_base = &py_type_VideoSource, .tp_new = PyType_GenericNew, .tp_init = (initproc)pulldown_init,
+    .tp_dealloc = (destructor)pulldown_dealloc, .tp_getset = pulldown_getset,
+};
+
 int init_sources(PyObject *module) {
     if (pyext_make_capsule(&solid_capsule, &solid_funcs) < 0 || pyext_make_capsule(&empty_capsule, &empty_funcs) < 0 ||
         pyext_make_capsule(&gain_capsule, &gain_funcs) < 0 || pyext_make_capsule(&mix_capsule, &mix_funcs) < 0 ||
         pyext_make_capsule(&scaler_capsule, &scaler_funcs) < 0 || pyext_make_capsule(&pass_capsule, &pass_funcs) < 0 ||
-        pyext_make_capsule(&seq_capsule, &seq_funcs) < 0) return -1;
+        pyext_make_capsule(&seq_capsule, &seq_funcs) < 0 || pyext_make_capsule(&pulldown_capsule, &pulldown_funcs) < 0) return -1;
     if (pyext_add_type(module, "SolidColorVideoSource", &py_type_Solid) < 0 || pyext_add_type(module, "EmptyVideoSource", &py_type_Empty) < 0 ||
         pyext_add_type(module, "VideoGainOffsetFilter", &py_type_Gain) < 0 || pyext_add_type(module, "VideoMixFilter", &py_type_Mix) < 0 ||
         pyext_add_type(module, "VideoScaler", &py_type_Scaler) < 0 || pyext_add_type(module, "VideoPassThroughFilter", &py_type_Pass) < 0 ||
-        pyext_add_type(module, "VideoSequence", &py_type_Seq) < 0) return -1;
+        pyext_add_type(module, "VideoSequence", &py_type_Seq) < 0 || pyext_add_type(module, "Pulldown23RemovalFilter", &py_type_Pulldown) < 0) return -1;
     return 0;
 }

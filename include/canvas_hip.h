@@ -320,6 +320,17 @@ CVS_EXPORT coded_image *video_subsample_dv(rgba_frame_f16 *frame);              
 CVS_EXPORT int cvs_reconstruct_dv_dev(rgba_frame_f16 *frame, const coded_image *planar, cvs_stream_t stream);
 CVS_EXPORT int cvs_subsample_dv_dev(coded_image *planar, rgba_frame_f16 *frame, int encode_input_in_place, cvs_stream_t stream);
 
+/* 2:3 pulldown removal (src/process/Pulldown23RemovalFilter.c:43-107; the reference keeps this inside the Python
+ * node, the arithmetic and the field weave are entry points here so that the node is a thin caller).
+ * cvs_pulldown23_frames: output frame -> source frame(s) for cadence phase `offset` (:51-71); returns 1 when the
+ *   frame is woven from two (odd rows from *first, even rows from *second), else 0 and *first alone.
+ * cvs_weave_fields_f16_dev: :88-104 on device frames -- `other` must be allocated for exactly frame->current_window,
+ *   as the reference allocates it; the even rows (first even y >= min.y) of the frame are replaced.  The reference
+ *   addresses the second buffer from x = 0 instead of min.x (:101); inside the allocation that shift is reproduced,
+ *   outside it (and outside other->current_window, uninitialised in the reference) the pixel is zero. */
+CVS_EXPORT int cvs_pulldown23_frames(int offset, int frame_index, int *first, int *second);
+CVS_EXPORT int cvs_weave_fields_f16_dev(rgba_frame_f16 *frame, const rgba_frame_f16 *other, cvs_stream_t stream);
+
 /* Display / export edge: the current window of an f16 frame as 4 bytes per pixel, packed row by row.
  * pre_lut: a transfer table applied to all four halfs first (CVS_LUT_NONE for none); then a half->u8 ramp.
  *

@@ -70,6 +70,8 @@ def _bind(lib):
         "orc_subsample_dv": (None, [P(C.c_void_p), P(C.c_int), P(rgba_frame_f16)]),
         "orc_frame_to_bytes": (None, [P(C.c_uint32), P(rgba_frame_f16), u16p, C.c_int]),
         "orc_widget_ramp": (None, [P(C.c_uint8), C.c_float]),
+        "orc_pulldown23_frames": (C.c_int, [C.c_int, C.c_int, P(C.c_int), P(C.c_int)]),
+        "orc_weave_fields_f16": (None, [P(rgba_frame_f16), P(rgba_frame_f16)]),
         "orc_frame_to_rgba8_intent": (None, [P(C.c_uint32), P(rgba_frame_f16), u16p, C.c_float]),
         "orc_chain_color_over_f16": (None, [P(rgba_frame_f16), P(P(rgba_frame_f16)), C.c_int, f32p, u16p, u16p]),
     }

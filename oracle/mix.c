@@ -252,3 +252,57 @@ void orc_workspace_get_frame_f32(const orc_ws_item *items, int n, int frame_inde
     }
     free(live);
 }
+
+/* ---- 2:3 pulldown removal: src/process/Pulldown23RemovalFilter.c:43-107 ----
+ * Cadence table of the reference (:51-57): source frames AA BB BC CD DD -> film frames A B C D, C woven from the
+ * odd rows of BC and the even rows of CD. */
+int orc_pulldown23_frames(int offset, int frame_index, int *first, int *second) {
+    int frame_offset;
+    if (offset == 4) frame_offset = (frame_index + 3) & 3;                  /* :61-64 */
+    else frame_offset = (frame_index + offset) & 3;
+    int base = ((frame_index + offset) >> 2) * 5 - offset;                  /* :66 */
+    *second = base + 3;
+    if (frame_offset == 0) { *first = base; return 0; }                     /* :69-77 */
+    if (frame_offset == 1) { *first = base + 1; return 0; }
+    if (frame_offset == 3) { *first = base + 4; return 0; }
+    *first = base + 2;                                                      /* :80-81 */
+    return 1;
+}
+
+/* :83-104 on two pulled frames.  `other` is the reference's temp frame: allocated for frame->current_window.  The
+ * reference takes its rows from x = 0 (:101), whatever the window's min.x; where that lands outside the allocation
+ * (foreign memory there) or outside other's current window (uninitialised there) this restatement reads zero. */
+void orc_weave_fields_f16(orc_frame16 *frame, const orc_frame16 *other) {
+    const orc_box2i *cw = &frame->current_window;
+    if (box_is_empty(cw)) return;
+    const int height = cw->max.y - cw->min.y + 1, width = cw->max.x - cw->min.x + 1;
+    const long long n = (long long)height * width;
+    for (int i = ((cw->min.y + 1) & ~1); i <= cw->max.y; i += 2) {          /* :100 */
+        orc_px16 *dst = PX(frame, cw->min.x, i);
+        const long long row0 = (long long)(i - cw->min.y) * width + (0 - cw->min.x);    /* video_get_pixel_f16(&temp, 0, i) */
+        for (int c = 0; c < width; c++) {
+            const long long l = row0 + c;
+            orc_px16 v = { 0, 0, 0, 0 };
+            if (l >= 0 && l < n) {
+                const int ty = cw->min.y + (int)(l / width), tx = cw->min.x + (int)(l % width);
+                if (tx >= other->current_window.min.x && tx <= other->current_window.max.x &&
+                    ty >= other->current_window.min.y && ty <= other->current_window.max.y) v = other->data[l];
+            }
+            dst[c] = v;
+        }
+    }
+}
+
+void orc_pulldown23_get_frame_f16(orc_source *source, int offset, int frame_index, orc_frame16 *frame) {
+    if (!source) { box_empty(&frame->current_window); return; }             /* :45-49 */
+    int first, second;
+    const int mixed = orc_pulldown23_frames(offset, frame_index, &first, &second);
+    orc_get_frame_f16(source, first, frame);
+    if (!mixed) return;
+    const orc_box2i *cw = &frame->current_window;
+    size_t pixels = box_is_empty(cw) ? 0 : (size_t)(cw->max.y - cw->min.y + 1) * (size_t)(cw->max.x - cw->min.x + 1);
+    orc_frame16 temp = { calloc(pixels ? pixels : 1, sizeof(orc_px16)), *cw, *cw };     /* :92-95 */
+    orc_get_frame_f16(source, second, &temp);                                           /* :97 */
+    orc_weave_fields_f16(frame, &temp);
+    free(temp.data);
+}

@@ -129,6 +129,28 @@ def bytes_model(codes, ramp, pre, premultiplied_argb):
     return (a << 24) | ((((r * a) >> 8) & 0xFF) << 16) | ((((g * a) >> 8) & 0xFF) << 8) | (((b * a) >> 8) & 0xFF)
 
 
+def weave_model(frame, full, cur, other, ocur):
+    """Pulldown23RemovalFilter.c:88-104 as flat-array arithmetic: `other` is a packed buffer for `cur`; every even row i of
+    cur takes `width` pixels from flat index (i - cur.y0) * width - cur.x0 (the x = 0 addressing of :101); indices outside
+    the buffer and pixels outside `ocur` read as zero."""
+    out = frame.copy()
+    x0, y0, x1, y1 = cur
+    width, height = x1 - x0 + 1, y1 - y0 + 1
+    if width <= 0 or height <= 0:
+        return out
+    flat = other.reshape(-1, 4).copy()
+    ys, xs = np.divmod(np.arange(width * height), width)
+    inside = (xs + x0 >= ocur[0]) & (xs + x0 <= ocur[2]) & (ys + y0 >= ocur[1]) & (ys + y0 <= ocur[3])
+    flat[~inside] = 0
+    for i in range((y0 + 1) & ~1, y1 + 1, 2):
+        idx = (i - y0) * width - x0 + np.arange(width)
+        ok = (idx >= 0) & (idx < width * height)
+        row = np.zeros((width, 4), frame.dtype)
+        row[ok] = flat[idx[ok]]
+        out[i - full[1], x0 - full[0]:x1 - full[0] + 1] = row
+    return out
+
+
 def widget_ramp_model(intent):
     """widget_gl.c:955-968: ramp[i] = (uint8_t) lrint(clampf(powf(h2f(i), intent) * 255, 0, 255)); clampf sends NaN to 0."""
     with np.errstate(all="ignore"):

@@ -226,6 +226,33 @@ def test_attenuate_f32_is_the_in_place_copy(cvs, orc, alpha):
     assert_same_f32(a.array, b.array, "attenuate")
 
 
+@pytest.mark.parametrize("full,cur,ocur", [
+    ((0, 0, 31, 17), (0, 0, 31, 17), (0, 0, 31, 17)),          # whole frame
+    ((0, -1, 31, 16), (0, -1, 31, 16), (0, -1, 31, 16)),       # DV raster: first line at y = -1, first even row is 0
+    ((-4, -3, 40, 20), (0, 1, 29, 14), (0, 1, 29, 14)),        # window inside the buffer, odd first row
+    ((-4, -3, 40, 20), (3, 2, 29, 14), (3, 2, 29, 14)),        # min.x > 0: the reference's row address starts 3 pixels early
+    ((-8, -3, 40, 20), (-5, 2, 20, 9), (-5, 2, 20, 9)),        # min.x < 0: it starts 5 pixels late and runs into the next row
+    ((0, 0, 31, 17), (0, 0, 31, 17), (4, 3, 20, 9)),           # the second field defined on part of the window only
+    ((0, 0, 31, 17), (0, 0, 31, 17), (0, 0, -1, -1)),          # the second field empty
+    ((0, 0, 9, 9), (2, 5, 7, 5), (2, 5, 7, 5)),                # one odd row: nothing to weave
+])
+def test_weave_fields(cvs, orc, full, cur, ocur):
+    """Pulldown23RemovalFilter.c:88-104 on device frames against the oracle's restatement (x = 0 addressing included)."""
+    rng = np.random.default_rng(77)
+    frame = rand_f16_frame(rng, full, cur)
+    other = rand_f16_frame(rng, cur, ocur)
+    want = frame.copy()
+    orc.lib().orc_weave_fields_f16(want.ref(), other.ref())
+    d_frame, d_other = DeviceFrame.from_host(frame), DeviceFrame.from_host(other)
+    _lib.check(cvs.cvs_weave_fields_f16_dev(d_frame.ref(), d_other.ref(), None))
+    got = d_frame.download()
+    assert same_window(got.current_window, want.current_window)
+    assert np.array_equal(got.array, want.array)                # whole buffer: odd rows and everything outside stay untouched
+    wrong = DeviceFrame.from_host(rand_f16_frame(rng, full, cur))
+    if full != cur:
+        assert cvs.cvs_weave_fields_f16_dev(d_frame.ref(), wrong.ref(), None) != 0      # not allocated for the current window
+
+
 # ------------------------------------------------------------------ A6 / A7 mixers
 
 FULL = (0, 0, 23, 11)

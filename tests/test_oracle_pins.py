@@ -393,6 +393,22 @@ def test_gain_offset_and_bytes_match_models(orc):
     assert ramp125[0xBC00] == 0 and ramp125[0x7E00] == 0 and ramp125[0x7C00] == 255
 
 
+def test_field_weave_matches_model(orc):
+    from tests.models import weave_model
+    rng = np.random.default_rng(305)
+    for full, cur, ocur in [((0, 0, 31, 17), (0, 0, 31, 17), (0, 0, 31, 17)), ((0, -1, 31, 16), (0, -1, 31, 16), (0, -1, 31, 16)),
+                            ((-4, -3, 40, 20), (3, 2, 29, 14), (3, 2, 29, 14)), ((-8, -3, 40, 20), (-5, 1, 20, 9), (-5, 1, 20, 9)),
+                            ((0, 0, 31, 17), (0, 0, 31, 17), (4, 3, 20, 9)), ((0, 0, 31, 17), (0, 0, 31, 17), (0, 0, -1, -1))]:
+        fa = rng.integers(0, 65536, (full[3] - full[1] + 1, full[2] - full[0] + 1, 4), dtype=np.uint16)
+        oa = rng.integers(0, 65536, (cur[3] - cur[1] + 1, cur[2] - cur[0] + 1, 4), dtype=np.uint16)
+        frame, other = HostFrame(full, np.uint16, fa, cur), HostFrame(cur, np.uint16, oa, ocur)
+        before = fa.copy()
+        want = weave_model(fa, full, cur, oa, ocur)
+        assert not np.array_equal(want, before)                  # the model does something
+        orc.lib().orc_weave_fields_f16(frame.ref(), other.ref())
+        assert np.array_equal(frame.array, want), (full, cur, ocur)
+
+
 def test_blur_and_lanczos_match_models(orc):
     from tests.models import blur_model, lanczos_model
     rng = np.random.default_rng(303)

@@ -25,7 +25,7 @@ def test_surface_is_complete(process):
     for name in ["VideoSource", "RgbaFrameF16", "RgbaFrameF32", "SolidColorVideoSource", "EmptyVideoSource",
                  "VideoGainOffsetFilter", "VideoMixFilter", "VideoScaler", "VideoPassThroughFilter", "VideoSequence",
                  "VideoWorkspace", "VideoPullQueue", "FrameFunction", "LerpFunc", "LinearFrameFunc",
-                 "AnimationFunc", "AnimationPoint", "POINT_HOLD", "POINT_LINEAR",
+                 "AnimationFunc", "AnimationPoint", "POINT_HOLD", "POINT_LINEAR", "FrameFuncPassThroughFilter", "Pulldown23RemovalFilter",
                  "CodedImageSource", "CodedImage", "DVReconstructionFilter", "DVSubsampleFilter",
                  "get_frame_time", "get_time_frame", "time_get_frame", "enable_glib_logging",
                  "create_offscreen_gl_context", "set_current_gl_context", "check_context_supported"]:
@@ -198,6 +198,52 @@ def test_animation_func_drives_filter_parameters(process):
     process.VideoMixFilter(a, b, mix)
     process.VideoGainOffsetFilter(a, gain=mix, offset=0.0)
     assert hasattr(mix, "_frame_function_funcs")
+
+
+def test_frame_func_pass_through_filter(process):
+    """src/process/FrameFuncPassThroughFilter.c:59-88: the upstream function at frame + offset; constants pass as they are."""
+    inner = process.LerpFunc((0.0, 10.0, 0.0, 0.0), (10.0, 20.0, 0.0, 0.0), 10.0)
+    f = process.FrameFuncPassThroughFilter(inner, offset=2.5)
+    assert isinstance(f, process.FrameFunction) and f.source() is inner and f.offset == 2.5
+    assert f.get_values([0, 1]) == inner.get_values([2.5, 3.5])
+    f.offset = 0.0
+    assert f.get_values(4) == inner.get_values(4)
+    const = process.FrameFuncPassThroughFilter((1.0, 2.0, 3.0, 4.0), offset=9.0)
+    assert const.source() is None and const.get_values([0, 5]) == [(1.0, 2.0, 3.0, 4.0)] * 2
+    const.set_source(inner)
+    assert const.get_values(1) == inner.get_values(10.0)
+    # it is itself a frame function: a filter parameter can be driven through it
+    gain = process.VideoGainOffsetFilter(process.SolidColorVideoSource((0, 0, 0, 1)), gain=process.FrameFuncPassThroughFilter(inner, 1.0))
+    assert gain.gain.source() is inner
+
+    class Shifted(process.FrameFuncPassThroughFilter):       # Py_TPFLAGS_BASETYPE there (:176)
+        pass
+    assert Shifted(inner, 1.0).get_values(0) == inner.get_values(1.0)
+
+
+def test_pulldown_cadence_table(process):
+    """Pulldown23RemovalFilter.c:51-71.  The comment table there lists, per cadence offset, which source frame each of
+    the four output frames of a cycle comes from; offsets 0-3 follow it.  For offset 4 the CODE sends the whole-frame
+    case `frameOffset == 3` to base + 4 with base already a cycle ahead, so output 0 maps to source 5 where the comment
+    says 0 -- what the code does is what is reproduced."""
+    import ctypes as C
+    import oracle
+    from canvas_amd import _lib
+    lib, orc = _lib.load(), oracle.lib()
+    a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+
+    def frames(fn, offset, i, x, y):
+        mixed = fn(offset, i, C.byref(x), C.byref(y))
+        return (x.value, y.value) if mixed else (x.value,)
+    table = {0: [(0,), (1,), (2, 3), (4,)], 1: [(0,), (1, 2), (3,), (4,)], 2: [(0, 1), (2,), (3,), (4,)], 3: [(1,), (2,), (3,), (4, 5)]}
+    for offset, cycle in table.items():
+        for k in range(3):                                    # three cycles: +5 source frames per 4 output frames
+            for i, want in enumerate(cycle):
+                assert frames(lib.cvs_pulldown23_frames, offset, 4 * k + i, a, b) == tuple(w + 5 * k for w in want), (offset, k, i)
+    assert [frames(lib.cvs_pulldown23_frames, 4, i, a, b) for i in range(5)] == [(5,), (1,), (2,), (3, 4), (10,)]
+    for offset in range(5):
+        for i in range(-9, 40):
+            assert frames(lib.cvs_pulldown23_frames, offset, i, a, b) == frames(orc.orc_pulldown23_frames, offset, i, c, d), (offset, i)
 
 
 def test_diagnostics_reach_python_logging(process):

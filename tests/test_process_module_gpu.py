@@ -350,6 +350,34 @@ def test_dv_nodes_against_oracle(process, bt, orc):
     almost(frame.pixel(300, 200), (0.2, 0.45, 0.7, 1.0), 1)
 
 
+@pytest.mark.parametrize("offset", [0, 1, 2, 3, 4])
+def test_pulldown_removal_node(process, bt, offset):
+    """Pulldown23RemovalFilter over a source whose every frame is a different colour: whole frames come through as they
+    are, the woven frame has the odd rows of one source frame and the even rows of the next (Pulldown23RemovalFilter.c:51-104)."""
+    import ctypes as C
+    from canvas_amd import _lib
+    lib = _lib.load()
+    source = process.SolidColorVideoSource(process.LerpFunc((0.0, 1.0, 0.25, 1.0), (1.0, 0.0, 0.75, 1.0), 32.0), bt.box2i(0, -1, 23, 12))
+    node = process.Pulldown23RemovalFilter(source, offset)
+    window = bt.box2i(0, -1, 23, 10)
+    a, b = C.c_int(), C.c_int()
+    seen_mixed = 0
+    for i in range(0, 9):
+        got = node.get_frame_f16(i, window)
+        mixed = lib.cvs_pulldown23_frames(offset, i, C.byref(a), C.byref(b))
+        first, second = source.get_frame_f16(a.value, window), source.get_frame_f16(b.value, window)
+        assert got.current_window == first.current_window == window
+        for y in range(window.min.y, window.max.y + 1):
+            want = second if (mixed and y % 2 == 0) else first
+            for x in (0, 11, 23):
+                assert got.pixel(x, y) == want.pixel(x, y), (i, x, y)
+        seen_mixed += mixed
+        # pulled as f32 through the f16-native node (main.c:105-144): the same halfs, widened
+        assert node.get_frame_f32(i, window).pixel(5, 0) == got.pixel(5, 0)
+    assert seen_mixed >= 2
+    assert process.Pulldown23RemovalFilter(None, 0).get_frame_f16(0, window).current_window.empty()
+
+
 @pytest.mark.parametrize("nlayers", [1, 3, 5])
 def test_workspace_of_half_native_clips_takes_the_fused_stack(process, bt, orc, nlayers):
     """Half-native items (here gain/offset nodes over solids: f16 slot only) pulled as f16: the workspace hands the
