@@ -18,13 +18,16 @@ unsigned cvs_lut_generation(int which);       /* halfconv.c: bumped by every ins
 const float *cvs_codes_as_float(void);        /* halfconv.c */
 
 enum { RAMP_GAMMA45 = 0, RAMP_INTENT = 1 };
-typedef struct { bool have; int pre_lut, kind; unsigned gen; uint32_t intent_bits; uint64_t stamp; uint8_t *dev; } disp_entry;
+typedef struct { bool have; int pre_lut, kind, pins; unsigned gen; uint32_t intent_bits; uint64_t stamp; uint8_t *dev; } disp_entry;     /* pins: captured graphs whose kernels read the table */
 #define DISP_CACHE 8
 static pthread_mutex_t disp_lock = PTHREAD_MUTEX_INITIALIZER;
 static disp_entry disp_cache[DISP_CACHE];
 static uint64_t disp_clock;
 
-static const uint8_t *display_table(int pre_lut, int kind, float intent) {
+/* Call with disp_lock held, and keep it until the kernel that reads the table has been enqueued: an eviction waits for
+ * the device (under the same lock) before it overwrites a slot, so a table is never rewritten under a launch that was
+ * handed its address. */
+static const uint8_t *display_table(int pre_lut, int kind, float intent, int *slot) {
     if (pre_lut != CVS_LUT_NONE && (pre_lut < 0 || pre_lut >= CVS_LUT_COUNT)) { cvs_set_error("no such transfer table: %d", pre_lut); return NULL; }
     const uint8_t *ramp45 = kind == RAMP_GAMMA45 ? video_get_gamma45_ramp() : NULL;
     const float *codes = kind == RAMP_INTENT ? cvs_codes_as_float() : NULL;
@@ -34,14 +37,14 @@ static const uint8_t *display_table(int pre_lut, int kind, float intent) {
     uint32_t ibits = 0;
     if (kind == RAMP_INTENT) memcpy(&ibits, &intent, 4);
     const uint8_t *result = NULL;
-    pthread_mutex_lock(&disp_lock);
-    int victim = 0;
+    int victim = -1;
     for (int i = 0; i < DISP_CACHE && !result; i++) {
         disp_entry *e = &disp_cache[i];
-        if (e->have && e->pre_lut == pre_lut && e->kind == kind && e->gen == gen && e->intent_bits == ibits) { e->stamp = ++disp_clock; result = e->dev; }
-        else if (!e->have) victim = i;
-        else if (disp_cache[victim].have && e->stamp < disp_cache[victim].stamp) victim = i;
+        if (e->have && e->pre_lut == pre_lut && e->kind == kind && e->gen == gen && e->intent_bits == ibits) { e->stamp = ++disp_clock; result = e->dev; *slot = i; }
+        else if (e->have && e->pins > 0) continue;
+        else if (victim < 0 || (disp_cache[victim].have && (!e->have || e->stamp < disp_cache[victim].stamp))) victim = i;
     }
+    if (!result && victim < 0) { cvs_set_error("display tables: every cache slot belongs to a captured graph"); return NULL; }
     if (!result) {
         uint8_t *host = malloc(HALF_COUNT);
         bool ok = host != NULL;
@@ -55,19 +58,30 @@ static const uint8_t *display_table(int pre_lut, int kind, float intent) {
         if (ok && !e->dev) ok = hipMalloc((void **)&e->dev, HALF_COUNT) == hipSuccess;
         if (ok) ok = hipMemcpy(e->dev, host, HALF_COUNT, hipMemcpyHostToDevice) == hipSuccess;
         free(host);
-        if (ok) { e->have = true; e->pre_lut = pre_lut; e->kind = kind; e->gen = gen; e->intent_bits = ibits; e->stamp = ++disp_clock; result = e->dev; }
+        if (ok) { e->have = true; e->pre_lut = pre_lut; e->kind = kind; e->gen = gen; e->intent_bits = ibits; e->stamp = ++disp_clock; result = e->dev; *slot = victim; }
         else { e->have = false; cvs_set_error("display table (transfer %d) could not be built", pre_lut); }
     }
-    pthread_mutex_unlock(&disp_lock);
     return result;
 }
 
-static int to_bytes_dev(void *dst_dev, const rgba_frame_f16 *frame, const uint8_t *table, int kmode, hipStream_t s) {
+static void display_unpin(void *slot) {
+    pthread_mutex_lock(&disp_lock);
+    disp_cache[(int)(intptr_t)slot].pins--;
+    pthread_mutex_unlock(&disp_lock);
+}
+
+static int to_bytes_dev(void *dst_dev, const rgba_frame_f16 *frame, int pre_lut, int ramp, float intent, int kmode, hipStream_t s) {
     if (box2i_is_empty(&frame->current_window)) return 0;
     if (!cvs_box_contains(&frame->full_window, &frame->current_window)) { cvs_set_error("frame to bytes: current window outside the buffer"); return -1; }
-    if (!table) return -1;
-    CVS_KERNEL(cvk_display(dst_dev, cvs_view(frame->data, &frame->full_window), cvs_rect(&frame->current_window), table, kmode, cvs_cus(), s));
-    return 0;
+    pthread_mutex_lock(&disp_lock);
+    int slot = -1;
+    const uint8_t *table = display_table(pre_lut, ramp, intent, &slot);
+    int rc = table ? cvk_display(dst_dev, cvs_view(frame->data, &frame->full_window), cvs_rect(&frame->current_window), table, kmode, cvs_cus(), s) : -1;
+    /* recorded into a graph: the table stays where it is until the graph is destroyed */
+    if (table && rc == 0 && cvs_capture_hold(s, display_unpin, (void *)(intptr_t)slot)) disp_cache[slot].pins++;
+    pthread_mutex_unlock(&disp_lock);
+    if (table && rc != 0) { cvs_set_error("frame to bytes: launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
+    return rc;
 }
 
 /* the software widget's conversion (widget_gl.c:291-307): transfer table over all four halfs, then the ramp
@@ -75,7 +89,7 @@ static int to_bytes_dev(void *dst_dev, const rgba_frame_f16 *frame, const uint8_
 CVS_EXPORT int cvs_frame_to_rgba8_intent_dev(void *dst_dev, const rgba_frame_f16 *frame, int pre_lut, float rendering_intent, cvs_stream_t stream) {
     if (cvs_enter() != 0) return -1;
     if (box2i_is_empty(&frame->current_window)) return 0;
-    return to_bytes_dev(dst_dev, frame, display_table(pre_lut, RAMP_INTENT, rendering_intent), CVK_DISPLAY_RGBA8, cvs_pick_stream(stream));
+    return to_bytes_dev(dst_dev, frame, pre_lut, RAMP_INTENT, rendering_intent, CVK_DISPLAY_RGBA8, cvs_pick_stream(stream));
 }
 
 /* dst_dev: room for 4 bytes per pixel of frame->current_window, packed row by row */
@@ -83,8 +97,7 @@ CVS_EXPORT int cvs_frame_to_bytes_dev(void *dst_dev, const rgba_frame_f16 *frame
     if (cvs_enter() != 0) return -1;
     if (mode != CVS_DISPLAY_RGBA8 && mode != CVS_DISPLAY_ARGB32_PREMUL) { cvs_set_error("frame to bytes: unknown mode %d", mode); return -1; }
     if (box2i_is_empty(&frame->current_window)) return 0;
-    return to_bytes_dev(dst_dev, frame, display_table(pre_lut, RAMP_GAMMA45, 0.0f), mode == CVS_DISPLAY_RGBA8 ? CVK_DISPLAY_RGBA8 : CVK_DISPLAY_ARGB32_PREMUL,
-                        cvs_pick_stream(stream));
+    return to_bytes_dev(dst_dev, frame, pre_lut, RAMP_GAMMA45, 0.0f, mode == CVS_DISPLAY_RGBA8 ? CVK_DISPLAY_RGBA8 : CVK_DISPLAY_ARGB32_PREMUL, cvs_pick_stream(stream));
 }
 
 /* the same on a HOST frame into a HOST buffer: rows of the current window go up, bytes come back.

@@ -27,6 +27,9 @@ void cvs_clear_error(void);
         }                                                                                      \
     } while (0)
 
+/* runtime.c: see there -- 1 when a graph being captured on `st` took over the hold on a cached table */
+int cvs_capture_hold(hipStream_t st, void (*release)(void *), void *arg);
+
 #define CVS_KERNEL(expr)                                                                       \
     do {                                                                                       \
         int cvs_k_ = (expr);                                                                   \

@@ -206,7 +206,18 @@ CVS_EXPORT void *cvs_pool_malloc(size_t bytes, cvs_stream_t s) {
 
 /* ---- graph capture state of the calling thread (see cvs_graph_begin below) */
 #define GRAPH_BLOCKS 64
-static __thread struct { int active, overflow; hipStream_t stream; void *blocks[GRAPH_BLOCKS]; int n; } t_capture;
+typedef struct { void (*release)(void *); void *arg; } cvs_hold;
+static __thread struct { int active, overflow; hipStream_t stream; void *blocks[GRAPH_BLOCKS]; int n; cvs_hold holds[GRAPH_BLOCKS]; int nholds; } t_capture;
+
+/* A cached device table (FIR taps, display bytes) that a launch has just been handed: outside a capture the caller
+ * lets go of it as soon as the launch is enqueued; inside one, the recorded kernels will read it at every replay, so
+ * the hold passes to the graph and `release(arg)` runs when the graph is destroyed.  Returns 1 when the graph took it. */
+int cvs_capture_hold(hipStream_t st, void (*release)(void *), void *arg) {
+    if (!t_capture.active || st != t_capture.stream) return 0;
+    if (t_capture.nholds < GRAPH_BLOCKS) { t_capture.holds[t_capture.nholds].release = release; t_capture.holds[t_capture.nholds].arg = arg; t_capture.nholds++; return 1; }
+    t_capture.overflow = 1;
+    return 0;
+}
 
 CVS_EXPORT void cvs_pool_free(void *dev, cvs_stream_t s) {
     if (!dev || cvs_enter() != 0) return;
@@ -255,9 +266,9 @@ CVS_EXPORT void cvs_pool_trim(void) {
  * and replayed with one submission.  Everything between begin and end must be device-frame entry points on the
  * capturing stream, called from the capturing thread, and must have run once before (so that tables, occupancy
  * figures and pool blocks exist: nothing may allocate or synchronise while a stream is capturing).  Scratch blocks
- * the sequence takes from the pool belong to the graph until it is destroyed.  Frame pointers and parameters are
+ * the sequence takes from the pool, and the cached tables its kernels read, belong to the graph until it is destroyed.  Frame pointers and parameters are
  * baked in; the CONTENTS of the frames are whatever they hold at replay time. */
-typedef struct { hipGraph_t graph; hipGraphExec_t exec; void *blocks[GRAPH_BLOCKS]; int n; hipStream_t stream; } cvs_graph;
+typedef struct { hipGraph_t graph; hipGraphExec_t exec; void *blocks[GRAPH_BLOCKS]; int n; cvs_hold holds[GRAPH_BLOCKS]; int nholds; hipStream_t stream; } cvs_graph;
 
 CVS_EXPORT int cvs_graph_begin(cvs_stream_t s) {
     if (cvs_enter() != 0) return -1;
@@ -286,10 +297,13 @@ CVS_EXPORT cvs_graph_t cvs_graph_end(cvs_stream_t s) {
         cvs_set_error("graph capture failed: %s", t_capture.overflow ? "too many scratch blocks" : hipGetErrorString(e));
         if (graph) hipGraphDestroy(graph);
         for (int i = 0; i < t_capture.n; i++) cvs_pool_free(t_capture.blocks[i], st);     /* not capturing any more: back to the pool */
+        for (int i = 0; i < t_capture.nholds; i++) t_capture.holds[i].release(t_capture.holds[i].arg);
         return NULL;
     }
     memcpy(g->blocks, t_capture.blocks, sizeof(void *) * (size_t)t_capture.n);
     g->n = t_capture.n;
+    memcpy(g->holds, t_capture.holds, sizeof(cvs_hold) * (size_t)t_capture.nholds);
+    g->nholds = t_capture.nholds;
     g->stream = st;
     return g;
 }
@@ -308,6 +322,7 @@ CVS_EXPORT void cvs_graph_destroy(cvs_graph_t graph) {
     hipGraphExecDestroy(g->exec);
     hipGraphDestroy(g->graph);
     for (int i = 0; i < g->n; i++) cvs_pool_free(g->blocks[i], g->stream);
+    for (int i = 0; i < g->nholds; i++) g->holds[i].release(g->holds[i].arg);
     free(g);
 }
 

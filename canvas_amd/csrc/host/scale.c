@@ -144,7 +144,8 @@ static int run_table(const tap_table *tb, cvk_view target, cvk_view source, int 
 
 /* device-resident, cached form of plan_triangle's table (defined with the table cache below) */
 static int triangle_table_cached(float tmin, float smin, float factor, int s0, int s1, int t0, int t1, bool count_touch,
-                                 cvk_fir_axis *axis, int *used_lo, int *used_hi);
+                                 cvk_fir_axis *axis, int *used_lo, int *used_hi, int *pin);
+static void axis_done(int pin, hipStream_t s);
 
 /* one pass of video_scale.c:34-127 (axis 0) or :129-229 (axis 1) on device frames */
 /* a frame of either pixel format, as the passes see it */
@@ -166,8 +167,8 @@ static int triangle_pass(any_frame *target, float tmin, const any_frame *source,
     /* the per-line taps depend only on the geometry, which repeats from frame to frame: planned once, kept on the
      * device; steady state is the zero fill and one gather launch, nothing synchronous */
     cvk_fir_axis table;
-    int used_lo, used_hi;
-    int rc = triangle_table_cached(tmin, smin, factor, s0, s1, t0, t1, axis == 0 || lo <= hi, &table, &used_lo, &used_hi);
+    int used_lo, used_hi, pin = -1;
+    int rc = triangle_table_cached(tmin, smin, factor, s0, s1, t0, t1, axis == 0 || lo <= hi, &table, &used_lo, &used_hi, &pin);
     if (rc != 0) return rc;
     if (used_hi >= used_lo && hi >= lo) {
         /* the gather reads source lines named in the table; they lie inside the source window by construction */
@@ -179,8 +180,10 @@ static int triangle_pass(any_frame *target, float tmin, const any_frame *source,
         fp.ntaps = table.ntaps + first; fp.tap_src = table.src + first * (size_t)table.stride; fp.taps = table.taps + first * (size_t)table.stride;
         fp.stride = table.stride;
         fp.in_half = source->half; fp.out_half = target->half;
-        CVS_KERNEL(cvk_fir_gather(&fp, s));
+        rc = cvk_fir_gather(&fp, s);
     }
+    axis_done(pin, s);
+    if (rc != 0) { cvs_set_error("FIR gather launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     if (axis) box2i_set(&target->cur, used_lo, lo, used_hi, hi);
     else      box2i_set(&target->cur, lo, used_lo, hi, used_hi);
     return 0;
@@ -381,6 +384,7 @@ typedef struct {
 typedef struct {
     axis_key key;
     int valid;
+    int pins;                 /* calls that hold the table's address and have not enqueued their launch yet (+ captured graphs) */
     uint64_t stamp;
     char *dev;                /* one block: ntaps | src | taps | foot */
     cvk_fir_axis axis;
@@ -390,7 +394,7 @@ typedef struct {
 
 typedef struct { const float *taps; float factor, tmin, smin; } axis_plan;    /* what the planner of the key's kind needs */
 
-#define AXIS_CACHE 16
+#define AXIS_CACHE 32
 static axis_entry g_axis[AXIS_CACHE];
 static uint64_t g_axis_clock;
 static pthread_mutex_t g_axis_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -455,20 +459,28 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     return 0;
 }
 
-/* cached table for one axis */
-static int axis_get_ex(const axis_key *key, const axis_plan *pl, cvk_fir_axis *out, int *max_foot, int *used_lo, int *used_hi) {
+/* cached table for one axis.  The entry comes back PINNED (*pin = its slot): it cannot be evicted -- its device block
+ * freed -- until axis_done() says the launch that reads it is on its stream.  An eviction then waits for the device. */
+static int axis_get_ex(const axis_key *key, const axis_plan *pl, cvk_fir_axis *out, int *max_foot, int *used_lo, int *used_hi, int *pin) {
     pthread_mutex_lock(&g_axis_lock);
-    int victim = 0;
+    int victim = -1;
     for (int i = 0; i < AXIS_CACHE; i++) {
         if (g_axis[i].valid && memcmp(&g_axis[i].key, key, sizeof *key) == 0) {
             g_axis[i].stamp = ++g_axis_clock;
+            g_axis[i].pins++;
+            *pin = i;
             *out = g_axis[i].axis; *max_foot = g_axis[i].max_foot;
             if (used_lo) { *used_lo = g_axis[i].used_lo; *used_hi = g_axis[i].used_hi; }
             pthread_mutex_unlock(&g_axis_lock);
             return 0;
         }
-        if (!g_axis[i].valid) victim = i;
-        else if (g_axis[victim].valid && g_axis[i].stamp < g_axis[victim].stamp) victim = i;
+        if (g_axis[i].valid && g_axis[i].pins > 0) continue;
+        if (victim < 0 || (g_axis[victim].valid && (!g_axis[i].valid || g_axis[i].stamp < g_axis[victim].stamp))) victim = i;
+    }
+    if (victim < 0) {
+        pthread_mutex_unlock(&g_axis_lock);
+        cvs_set_error("FIR tables: every cache slot is held by a launch in preparation or a captured graph");
+        return -1;
     }
     tap_table tb;
     int rc = key->kind == 1 ? plan_blur(&tb, key->t0, key->t1, key->s0, key->s1, pl->taps, key->ksize)
@@ -480,9 +492,10 @@ static int axis_get_ex(const axis_key *key, const axis_plan *pl, cvk_fir_axis *o
     else cvs_set_error("FIR planning: out of memory");
     if (rc == 0) {
         axis_entry *e = &g_axis[victim];
-        if (e->valid && e->dev) { hipDeviceSynchronize(); hipFree(e->dev); }     /* eviction is rare; nothing may still read it */
-        fresh.key = *key; fresh.valid = 1; fresh.stamp = ++g_axis_clock;
+        if (e->valid && e->dev) { hipDeviceSynchronize(); hipFree(e->dev); }     /* unpinned: every launch that read it is on a stream; wait for them */
+        fresh.key = *key; fresh.valid = 1; fresh.pins = 1; fresh.stamp = ++g_axis_clock;
         *e = fresh;
+        *pin = victim;
         *out = e->axis; *max_foot = e->max_foot;
         if (used_lo) { *used_lo = e->used_lo; *used_hi = e->used_hi; }
     }
@@ -490,19 +503,31 @@ static int axis_get_ex(const axis_key *key, const axis_plan *pl, cvk_fir_axis *o
     return rc;
 }
 
-static int axis_get(const axis_key *key, const float *taps, float factor, cvk_fir_axis *out, int *max_foot) {
+static void axis_unpin(void *slot) {
+    pthread_mutex_lock(&g_axis_lock);
+    g_axis[(int)(intptr_t)slot].pins--;
+    pthread_mutex_unlock(&g_axis_lock);
+}
+
+/* the launch that reads the table is enqueued on `s` (or failed): let go of it, or hand the hold to the graph being captured */
+static void axis_done(int pin, hipStream_t s) {
+    if (pin < 0) return;
+    if (!cvs_capture_hold(s, axis_unpin, (void *)(intptr_t)pin)) axis_unpin((void *)(intptr_t)pin);
+}
+
+static int axis_get(const axis_key *key, const float *taps, float factor, cvk_fir_axis *out, int *max_foot, int *pin) {
     const axis_plan pl = { taps, factor, 0.0f, 0.0f };
-    return axis_get_ex(key, &pl, out, max_foot, NULL, NULL);
+    return axis_get_ex(key, &pl, out, max_foot, NULL, NULL, pin);
 }
 
 static int triangle_table_cached(float tmin, float smin, float factor, int s0, int s1, int t0, int t1, bool count_touch,
-                                 cvk_fir_axis *axis, int *used_lo, int *used_hi) {
+                                 cvk_fir_axis *axis, int *used_lo, int *used_hi, int *pin) {
     uint32_t fb, tb, sb;
     memcpy(&fb, &factor, 4); memcpy(&tb, &tmin, 4); memcpy(&sb, &smin, 4);
     const axis_key key = make_key(3, fb, count_touch ? 1 : 0, ((uint64_t)tb << 32) | sb, t0, t1, s0, s1, CVK_FIR2D_TILE_X);
     const axis_plan pl = { NULL, factor, tmin, smin };
     int foot;
-    return axis_get_ex(&key, &pl, axis, &foot, used_lo, used_hi);
+    return axis_get_ex(&key, &pl, axis, &foot, used_lo, used_hi, pin);
 }
 
 /* 0 = launched, 1 = does not fit an LDS tile (caller falls back), <0 = error */
@@ -553,9 +578,12 @@ static int blur_fused_over(void *tdata, const box2i *tfull, int out_half, const 
     const uint64_t th = fnv1a(taps, sizeof(float) * (size_t)ntaps);
     axis_key kh = make_key(1, 0, ntaps, th, win->min.x, win->max.x, sw->min.x, sw->max.x, CVK_FIR2D_TILE_X);
     axis_key kv = make_key(1, 0, ntaps, th, win->min.y, win->max.y, sw->min.y, sw->max.y, CVK_FIR2D_TILE_Y);
-    cvk_fir_axis h, v; int hf, vf;
-    if (axis_get(&kh, taps, 0.0f, &h, &hf) != 0 || axis_get(&kv, taps, 0.0f, &v, &vf) != 0) return -1;
-    return fir2d_launch(tdata, tfull, out_half, sdata, sfull, in_half, win, &h, hf, &v, vf, s);
+    cvk_fir_axis h, v; int hf, vf, ph = -1, pv = -1;
+    int rc = axis_get(&kh, taps, 0.0f, &h, &hf, &ph);
+    if (rc == 0) rc = axis_get(&kv, taps, 0.0f, &v, &vf, &pv);
+    rc = rc == 0 ? fir2d_launch(tdata, tfull, out_half, sdata, sfull, in_half, win, &h, hf, &v, vf, s) : -1;
+    axis_done(ph, s); axis_done(pv, s);
+    return rc;
 }
 
 static int blur_fused(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
@@ -594,9 +622,12 @@ static int lanczos_fused(void *tdata, const box2i *tfull, int out_half, const vo
     memcpy(&bx, &fx, 4); memcpy(&by, &fy, 4);
     axis_key kh = make_key(2, bx, ksize, 0, tfull->min.x, tfull->max.x, sw->min.x, sw->max.x, CVK_FIR2D_TILE_X);
     axis_key kv = make_key(2, by, ksize, 0, tfull->min.y, tfull->max.y, sw->min.y, sw->max.y, CVK_FIR2D_TILE_Y);
-    cvk_fir_axis h, v; int hf, vf;
-    if (axis_get(&kh, NULL, fx, &h, &hf) != 0 || axis_get(&kv, NULL, fy, &v, &vf) != 0) return -1;
-    return fir2d_launch(tdata, tfull, out_half, sdata, sfull, in_half, tfull, &h, hf, &v, vf, s);
+    cvk_fir_axis h, v; int hf, vf, ph = -1, pv = -1;
+    int rc = axis_get(&kh, NULL, fx, &h, &hf, &ph);
+    if (rc == 0) rc = axis_get(&kv, NULL, fy, &v, &vf, &pv);
+    rc = rc == 0 ? fir2d_launch(tdata, tfull, out_half, sdata, sfull, in_half, tfull, &h, hf, &v, vf, s) : -1;
+    axis_done(ph, s); axis_done(pv, s);
+    return rc;
 }
 
 CVS_EXPORT int cvs_fir_blur_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, const float *taps, int ntaps, cvs_stream_t stream) {

@@ -1344,6 +1344,47 @@ def test_concurrent_callers_each_get_their_own_results(cvs, orc):
     assert not errors, errors
 
 
+def test_animated_zoom_from_several_threads_churns_the_table_cache(cvs, orc):
+    """Four threads, each scaling with a factor that changes every call (an animated zoom): far more distinct tap tables
+    than the cache holds, so entries are evicted all the time while other threads are between looking a table up and
+    enqueueing the launch that reads it.  A table in that state is pinned; every result must equal the oracle's."""
+    import threading
+    errors = []
+
+    def worker(seed):
+        try:
+            rng = np.random.default_rng(9500 + seed)
+            full = (0, 0, 47, 26)
+            src = rand_f32_frame(rng, full)
+            d_src = DeviceFrame.from_host(src)
+            for it in range(30):
+                fx, fy = 0.6 + 0.013 * (4 * it + seed), 1.4 - 0.011 * (4 * it + seed)
+                t_full = (0, 0, 63, 35)
+                want = HostFrame(t_full, np.float32)
+                orc.lib().orc_scale_bilinear_f32(want.ref(), v2f(0, 0), src.ref(), v2f(0, 0), v2f(fx, fy))
+                d_out = DeviceFrame(t_full, np.float32)
+                _lib.check(cvs.cvs_scale_bilinear_f32_dev(d_out.ref(), v2f(0, 0), d_src.ref(), v2f(0, 0), v2f(fx, fy), None))
+                got = d_out.download()
+                assert same_window(got.current_window, want.current_window), (fx, fy)
+                assert_same_f32(got.window_view(), want.window_view(), "zoom %r" % ((fx, fy),))
+                # and a resample whose tables come from the same cache
+                small = DeviceFrame((0, 0, 23, 13), np.float32)
+                want_l = HostFrame((0, 0, 23, 13), np.float32)
+                lf = 0.45 + 0.002 * (4 * it + seed)
+                orc.lib().orc_resample_lanczos_f32(want_l.ref(), src.ref(), C.c_float(lf), C.c_float(lf), 3)
+                _lib.check(cvs.cvs_resample_lanczos_f32_dev(small.ref(), d_src.ref(), C.c_float(lf), C.c_float(lf), 3, None))
+                assert_same_f32(small.download().array, want_l.array, "lanczos %r" % lf)
+        except Exception as e:          # noqa: BLE001 -- reported on the main thread
+            errors.append("thread %d: %r" % (seed, e))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+
+
 @pytest.mark.parametrize("tfull,sfull,scur,tp,sp,fac", SCALE_CASES)
 def test_scale_bilinear_f16_twin(cvs, orc, tfull, sfull, scur, tp, sp, fac):
     """The scaler between two f16 frames = widen -> video_scale_bilinear_f32 -> truncate, without those two copies."""
