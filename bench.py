@@ -43,6 +43,9 @@ def parse():
                     help="NOT the BASELINE input: random alpha on layer 0 as well, so every divide of the over operator is live")
     ap.add_argument("--no-arena", action="store_true", help="one hipMalloc per frame instead of one arena for the ring")
     ap.add_argument("--slot-pad", type=int, default=0, help="extra bytes between consecutive frames of the arena (placement experiment; multiple of 256)")
+    ap.add_argument("--pre-alloc-mb", type=int, default=0, help="allocate (and keep) this much device memory before the ring (placement experiment)")
+    ap.add_argument("--arena-align-mb", type=int, default=0, help="round the ring's base address up to this many MiB (placement experiment)")
+    ap.add_argument("--report-base", action="store_true", help="print the ring's base address on stderr (placement experiment)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -163,8 +166,12 @@ def main():
     # dozens of 66 MB ones, and the TLB reach of the chip is what a multi-GB streaming working set leans on
     frame_bytes = w * h * 8
     slot = (frame_bytes + (2 << 20) - 1) // (2 << 20) * (2 << 20) + args.slot_pad
-    arena = None if args.no_arena else lib.cvs_malloc(slot * (nl + 1) * len(my_frames))
-    at = [arena]
+    dummy = lib.cvs_malloc(args.pre_alloc_mb << 20) if args.pre_alloc_mb else None      # noqa: F841 -- kept alive on purpose
+    align = args.arena_align_mb << 20
+    arena = None if args.no_arena else lib.cvs_malloc(slot * (nl + 1) * len(my_frames) + align)
+    at = [arena if not align or arena is None else (arena + align - 1) // align * align]
+    if rank == 0 and (args.pre_alloc_mb or align or args.report_base):
+        print("ring base %#x (arena %#x)" % (at[0], arena), file=sys.stderr)
 
     def place():
         if arena is None:
