@@ -28,8 +28,9 @@ e0, e1 = lib.cvs_event_create(), lib.cvs_event_create()
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 kept = []
 arenas = []
-for trial in range(8):                 # eight rings alive at the same time: eight different places for certain
-    kept.append(lib.cvs_malloc(rng.choice([2, 6, 30, 62, 126, 254, 510, 1022]) * MiB))
+spacer_gib = int(sys.argv[2]) if len(sys.argv) > 2 else 0      # > 0: that much device memory between consecutive rings
+for trial in range(8 if not spacer_gib else 4):    # rings alive at the same time: different places for certain
+    kept.append(lib.cvs_malloc((spacer_gib << 30) if spacer_gib else rng.choice([2, 6, 30, 62, 126, 254, 510, 1022]) * MiB))
     arenas.append(lib.cvs_malloc(24 * 64 * MiB))
 for trial, arena in enumerate(arenas * 2):
     for k in range(24):
