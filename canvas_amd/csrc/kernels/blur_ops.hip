@@ -67,7 +67,7 @@ __device__ __forceinline__ void each_slot(F &f, std::integer_sequence<int, Js...
 // every source row is pushed into the ring, and an output row leaves every STEP-th step.
 template <int NT, int W, bool INH, bool EPI, int STEP>
 __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
-    constexpr int C = NT / 2, OUTW = (STEP * W - NT) / STEP + 1, PITCH = W + 16;
+    constexpr int C = NT / 2, OUTW = (STEP * W - NT) / STEP + 1, PITCH = W + (NT <= 17 ? 16 : 32), CH = NT <= 15 ? NT : 8;
     static_assert(!(EPI && STEP != 1), "the over epilogue is for the 1:1 blur");
     __shared__ float4 rowbuf[2][STEP][PITCH];
     const int lane = threadIdx.x;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
     char *tbase = reinterpret_cast<char *>(bp.target.data) + (ptrdiff_t)(tcol - bp.target.fx0) * (ptrdiff_t)tpx;
     const size_t trow = (size_t)bp.target.pitch * tpx;
 
-    if (lane < 16) {
+    if (lane < PITCH - W) {
 #pragma unroll
         for (int r = 0; r < STEP; r++) { rowbuf[0][r][W + lane] = make_float4(0.f, 0.f, 0.f, 0.f); rowbuf[1][r][W + lane] = make_float4(0.f, 0.f, 0.f, 0.f); }
     }
@@ -155,41 +155,48 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
             cur = nxt;
             nxt = far;
             __syncthreads();
-            float4 v[NT];
-#pragma unroll
-            for (int k = 0; k < NT; k++) v[k] = buf[k % STEP][lane + k / STEP];
-            // all products first, then the two add chains interleaved: a packed add right behind the packed multiply it
-            // depends on costs a hazard slot (s_nop) per tap; the rounding and the order of the additions do not change
-            f32x2 prg[NT], pba[NT];
-#pragma unroll
-            for (int k = 0; k < NT; k++) {
-                prg[k] = f32x2{ v[k].x, v[k].y } * w[k];
-                pba[k] = f32x2{ v[k].z, v[k].w } * w[k];
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            // all products (of a group of CH taps) first, then the two add chains interleaved: a packed add right behind the
+            // packed multiply it depends on costs a hazard slot (s_nop) per tap; the rounding and the order of the
+            // additions do not change.  Up to 15 taps are one group; longer lists go in groups of 8 to stay in registers.
             f32x2 rg = { 0.0f, 0.0f }, ba = { 0.0f, 0.0f };
 #pragma unroll
-            for (int k = 0; k < NT; k++) {
-                rg = rg + prg[k];
-                ba = ba + pba[k];
+            for (int k0 = 0; k0 < NT; k0 += CH) {
+                float4 v[CH];
+#pragma unroll
+                for (int c = 0; c < CH; c++) if (k0 + c < NT) v[c] = buf[(k0 + c) % STEP][lane + (k0 + c) / STEP];
+                f32x2 prg[CH], pba[CH];
+#pragma unroll
+                for (int c = 0; c < CH; c++) if (k0 + c < NT) {
+                    prg[c] = f32x2{ v[c].x, v[c].y } * w[k0 + c];
+                    pba[c] = f32x2{ v[c].z, v[c].w } * w[k0 + c];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < CH; c++) if (k0 + c < NT) {
+                    rg = rg + prg[c];
+                    ba = ba + pba[c];
+                }
             }
             ring[j].rg = rg;
             ring[j].ba = ba;
             if (emits) {
                 // ring[(j+1) % NT] is the oldest row = tap 0
-                f32x2 qrg[NT], qba[NT];
-#pragma unroll
-                for (int k = 0; k < NT; k++) {
-                    const Px &p = ring[(j + 1 + k) % NT];
-                    qrg[k] = p.rg * w[k];
-                    qba[k] = p.ba * w[k];
-                }
-                __builtin_amdgcn_sched_barrier(0);
                 f32x2 org = { 0.0f, 0.0f }, oba = { 0.0f, 0.0f };
 #pragma unroll
-                for (int k = 0; k < NT; k++) {
-                    org = org + qrg[k];
-                    oba = oba + qba[k];
+                for (int k0 = 0; k0 < NT; k0 += CH) {
+                    f32x2 qrg[CH], qba[CH];
+#pragma unroll
+                    for (int c = 0; c < CH; c++) if (k0 + c < NT) {
+                        const Px &p = ring[(j + 1 + k0 + c) % NT];
+                        qrg[c] = p.rg * w[k0 + c];
+                        qba[c] = p.ba * w[k0 + c];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < CH; c++) if (k0 + c < NT) {
+                        org = org + qrg[c];
+                        oba = oba + qba[c];
+                    }
                 }
                 if constexpr (EPI) {
                     cvs::px1 acc = { org, oba.x, oba.y };
@@ -274,14 +281,26 @@ int pick(const cvk_blur_params *bp, int cus, hipStream_t s) {
     case 11: return launch<11, W, 1>(*bp, cus, s);
     case 13: return launch<13, W, 1>(*bp, cus, s);
     case 15: return launch<15, W, 1>(*bp, cus, s);
-    default: return (int)hipErrorInvalidValue;
     }
+    if constexpr (W == 256) {                      // long blurs: one strip width only (these instances are large)
+        switch (bp->ntaps) {
+        case 17: return launch<17, W, 1>(*bp, cus, s);
+        case 19: return launch<19, W, 1>(*bp, cus, s);
+        case 21: return launch<21, W, 1>(*bp, cus, s);
+        case 23: return launch<23, W, 1>(*bp, cus, s);
+        case 25: return launch<25, W, 1>(*bp, cus, s);
+        case 27: return launch<27, W, 1>(*bp, cus, s);
+        case 29: return launch<29, W, 1>(*bp, cus, s);
+        case 31: return launch<31, W, 1>(*bp, cus, s);
+        }
+    }
+    return (int)hipErrorInvalidValue;
 }
 
 }  // namespace
 
 extern "C" int cvk_blur_supported(int ntaps, int step) {
-    if (step == 1) return ntaps >= 3 && ntaps <= 15 && (ntaps & 1);
+    if (step == 1) return ntaps >= 3 && ntaps <= 31 && (ntaps & 1);
     if (step == 2) return ntaps == 3 || ntaps == 7 || ntaps == 11 || ntaps == 15;
     return 0;
 }
@@ -297,7 +316,7 @@ extern "C" int cvk_blur(const cvk_blur_params *bp_in, int cus, void *stream) {
     static int env_w = -1, env_rows = -1;
     if (env_w < 0) { const char *e = getenv("CVS_BLUR_WIDTH"); env_w = e ? atoi(e) : 0; }
     if (env_rows < 0) { const char *e = getenv("CVS_BLUR_ROWS"); env_rows = e ? atoi(e) : 0; }
-    const int width = env_w ? env_w : (cols <= 128 ? 128 : 256);
+    const int width = bp.ntaps > 15 ? 256 : env_w ? env_w : (cols <= 128 ? 128 : 256);
     if (bp.rows_per_wg <= 0 && env_rows > 0) bp.rows_per_wg = env_rows;
     return width == 128 ? pick<128>(&bp, cus, (hipStream_t)stream) : pick<256>(&bp, cus, (hipStream_t)stream);
 }

@@ -113,7 +113,7 @@ typedef struct {
 size_t cvk_fir2d_lds_bytes(const cvk_fir2d_params *fp);     /* dynamic LDS the launch would need */
 int cvk_fir2d(const cvk_fir2d_params *fp, void *stream);
 
-/* separable FIR with one tap list for every line (odd, 3..15 taps, all finite), optionally decimating by 2:
+/* separable FIR with one tap list for every line (odd, 3..31 taps, all finite), optionally decimating by 2:
  * both passes in one sweep, the vertical window in registers.  Source pixels outside (sx0..sx1, sy0..sy1) count as skipped taps. */
 #define CVK_BLUR_MAX_OVER 4
 typedef struct {
@@ -124,7 +124,7 @@ typedef struct {
     int ntaps;
     int rows_per_wg;           /* 0: let the launcher choose */
     int step;                  /* target line t reads source lines step*t - ntaps/2 + k; 0 or 1: blur, 2: halving resampler */
-    float taps[16];
+    float taps[32];
     int nover;                 /* f16 frames blended over the blur result before the (f16) store; 0..CVK_BLUR_MAX_OVER */
     int pad;
     const void *over[CVK_BLUR_MAX_OVER];       /* rgba_f16 device buffers laid out exactly like `target` */

@@ -639,12 +639,12 @@ def test_scale_pull(cvs, orc):
 
 
 @pytest.mark.parametrize("scur", [(0, 0, 47, 26), (5, 3, 40, 20)])
-@pytest.mark.parametrize("ntaps", [9, 5, 1, 4])
+@pytest.mark.parametrize("ntaps", [9, 5, 1, 4, 17, 21, 31, 33])
 def test_fir_blur(cvs, orc, scur, ntaps):
     rng = np.random.default_rng(51)
     full = (0, 0, 47, 26)
     src = rand_f32_frame(rng, full, scur)
-    taps = synth.gaussian_taps(ntaps, 1.5)
+    taps = synth.gaussian_taps(ntaps, max(1.5, ntaps / 6.0))
     want = HostFrame(full, np.float32)
     orc.lib().orc_fir_blur_f32(want.ref(), src.ref(), f32p(taps), ntaps)
     d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(full, np.float32)
@@ -855,7 +855,7 @@ def test_colour_matrix_out_of_place(cvs, orc, pre, post, geom):
 
 
 @pytest.mark.parametrize("scur", [(0, 0, 47, 26), (5, 3, 40, 20)])
-@pytest.mark.parametrize("ntaps", [9, 1, 4])
+@pytest.mark.parametrize("ntaps", [9, 1, 4, 19, 27])
 def test_fir_blur_f16(cvs, orc, scur, ntaps):
     rng = np.random.default_rng(52)
     full = (0, 0, 47, 26)
@@ -898,7 +898,7 @@ def _blur_over(cvs, out_full, src, taps, overlays):
 
 
 @pytest.mark.parametrize("nover", [1, 3, 4])
-@pytest.mark.parametrize("ntaps", [9, 3, 15])
+@pytest.mark.parametrize("ntaps", [9, 3, 15, 23])
 @pytest.mark.parametrize("size", [(300, 41), (64, 36)])         # two strips / one narrow strip
 def test_blur_over_fused(cvs, orc, nover, ntaps, size):
     """Blur node as the lowest workspace item, f16 layers above it, f16 pull: one launch."""
@@ -1501,14 +1501,14 @@ def test_scale_bilinear_random_geometry(cvs, orc):
 
 
 def test_fir_blur_random_geometry(cvs, orc):
-    """150 random blurs: tap counts 1..16 (odd ones up to 15 take the register-window kernel, the rest the tiled
+    """150 random blurs: tap counts 1..34 (odd ones from 3 to 31 take the register-window kernel, the rest the tiled
     gather kernel), source windows inside their buffers, targets with other origins, f32 and f16 entry points."""
     rng = np.random.default_rng(20261006)
     for case in range(150):
         sfull = (int(rng.integers(-5, 3)), int(rng.integers(-4, 3)), int(rng.integers(20, 300)), int(rng.integers(8, 50)))
         tfull = (int(rng.integers(-5, 3)), int(rng.integers(-4, 3)), int(rng.integers(20, 300)), int(rng.integers(8, 50)))
         scur = _random_window(rng, sfull)
-        ntaps = int(rng.integers(1, 17))
+        ntaps = int(rng.integers(1, 35))
         taps = rng.uniform(-0.2, 1.0, ntaps).astype(np.float32)
         taps /= np.float32(taps.sum())
         src = rand_f32_frame(rng, sfull, scur, lo=-0.5, hi=1.5)
