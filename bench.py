@@ -10,7 +10,7 @@ only the parameter block (matrix + 128 KiB LUT) once at start and the timings at
 
 A "step" = one batch of --batch frames per GPU through the fused chain kernel (one launch).
 The input ring (--ring frame sets, default 8 x 199 MB = 1.6 GB) is several times the 256 MiB Infinity
-Cache, so every launch streams from HBM (a 16-frame step walks the ring twice).
+Cache, so every launch streams from HBM (a 64-frame step walks the ring eight times).
 """
 import argparse
 import ctypes as C
