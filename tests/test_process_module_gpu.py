@@ -350,6 +350,51 @@ def test_dv_nodes_against_oracle(process, bt, orc):
     almost(frame.pixel(300, 200), (0.2, 0.45, 0.7, 1.0), 1)
 
 
+def test_dv_footage_pipeline_against_oracle(process, bt, orc):
+    """The chain real DV footage goes through: a coded-image source with different planes per frame ->
+    DVReconstructionFilter -> Pulldown23RemovalFilter -> preview bytes.  Every stage against the oracle: reconstruct
+    both source frames (orc_reconstruct_dv), weave them (orc_weave_fields_f16), convert (orc_frame_to_bytes)."""
+    from canvas_amd import _lib
+    from canvas_amd.abi import HostFrame
+    lib = _lib.load()
+    rng = np.random.default_rng(31)
+    coded = {}
+
+    def planes_of(frame):
+        if frame not in coded:
+            coded[frame] = [rng.integers(16, 236, (480, s), dtype=np.uint8) for s in (720, 180, 180)]
+        return coded[frame]
+
+    class Tape(process.CodedImageSource):
+        def get_frame(self, frame):
+            return [process.CodedImage(bytearray(p.tobytes()), p.shape[1], 480) for p in planes_of(frame)]
+
+    film = process.Pulldown23RemovalFilter(process.DVReconstructionFilter(Tape()), 2)
+    window = bt.box2i(0, -1, 719, 478)
+    a, b = C.c_int(), C.c_int()
+    seen = set()
+    for i in (0, 1, 4, 5):
+        mixed = lib.cvs_pulldown23_frames(2, i, C.byref(a), C.byref(b))
+        seen.add(mixed)
+        want = HostFrame((0, -1, 719, 478), np.uint16)
+        pl = planes_of(a.value)
+        orc.lib().orc_reconstruct_dv(want.ref(), (C.c_void_p * 3)(*[p.ctypes.data for p in pl]), (C.c_int * 3)(720, 180, 180))
+        if mixed:
+            other = HostFrame((0, -1, 719, 478), np.uint16)
+            pl2 = planes_of(b.value)
+            orc.lib().orc_reconstruct_dv(other.ref(), (C.c_void_p * 3)(*[p.ctypes.data for p in pl2]), (C.c_int * 3)(720, 180, 180))
+            orc.lib().orc_weave_fields_f16(want.ref(), other.ref())
+        raw, cur = film.get_frame_argb32(i, window)
+        assert cur == window
+        packed = np.zeros((480, 720), np.uint32)
+        orc.lib().orc_frame_to_bytes(packed.ctypes.data_as(C.POINTER(C.c_uint32)), want.ref(), None, 1)
+        assert bytes(raw) == packed.tobytes(), i
+        got = film.get_frame_f16(i, window)
+        for x, y in [(0, -1), (1, 0), (359, 240), (719, 477), (718, 478)]:
+            assert np.array_equal(orc.float_to_half(np.array(got.pixel(x, y), np.float32)), want.array[y + 1, x]), (i, x, y)
+    assert seen == {0, 1}
+
+
 @pytest.mark.parametrize("offset", [0, 1, 2, 3, 4])
 def test_pulldown_removal_node(process, bt, offset):
     """Pulldown23RemovalFilter over a source whose every frame is a different colour: whole frames come through as they
