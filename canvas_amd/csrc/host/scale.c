@@ -436,6 +436,45 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
         foot[2 * t] = first; foot[2 * t + 1] = last;
         if (last - first + 1 > max_foot) max_foot = last - first + 1;
     }
+    /* what the streaming kernel needs to know about the table */
+    int max_taps = 0, wide_foot = 0, max_active = 0, streamable = 1;
+    {
+        int prev_a = INT_MIN, prev_b = INT_MIN;
+        for (int i = 0; i < lines; i++) {
+            const int n = ntaps[i];
+            if (n > max_taps) max_taps = n;
+            if (!n) continue;
+            const int *src = tb->tap_src + (size_t)i * tb->stride;
+            for (int k = 1; k < n; k++) if (src[k] != src[0] + k) streamable = 0;
+            if (src[0] < prev_a || src[n - 1] < prev_b) streamable = 0;
+            prev_a = src[0]; prev_b = src[n - 1];
+        }
+        for (int g = 0; g < lines; g += 128) {              /* the streaming kernel's strips (resample_ops.hip kW) */
+            int first = INT_MAX, last = INT_MIN;
+            for (int i = g; i < lines && i < g + 128; i++) {
+                if (!ntaps[i]) continue;
+                const int *src = tb->tap_src + (size_t)i * tb->stride;
+                if (src[0] < first) first = src[0];
+                if (src[ntaps[i] - 1] > last) last = src[ntaps[i] - 1];
+            }
+            if (last >= first && last - first + 1 > wide_foot) wide_foot = last - first + 1;
+        }
+        if (streamable) {
+            int j = 0;
+            for (int i = 0; i < lines; i++) {
+                if (!ntaps[i]) continue;
+                const int b = tb->tap_src[(size_t)i * tb->stride + ntaps[i] - 1];
+                if (j < i) j = i;
+                while (j + 1 < lines) {                       /* furthest later line that starts at or before b */
+                    int nxt = j + 1;
+                    while (nxt < lines && !ntaps[nxt]) nxt++;
+                    if (nxt >= lines || tb->tap_src[(size_t)nxt * tb->stride] > b) break;
+                    j = nxt;
+                }
+                if (j - i + 1 > max_active) max_active = j - i + 1;
+            }
+        }
+    }
     const size_t n_l = (size_t)(lines ? lines : 1), n_t = n_l * (size_t)tb->stride;
     const size_t off_src = (n_l * sizeof(int) + 255) & ~(size_t)255;
     const size_t off_tap = off_src + ((n_t * sizeof(int) + 255) & ~(size_t)255);
@@ -455,6 +494,7 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     e->axis.taps = (const float *)(dev + off_tap);
     e->axis.foot = (const int *)(dev + off_foot);
     e->axis.stride = tb->stride;
+    e->axis.max_taps = max_taps; e->axis.wide_foot = wide_foot; e->axis.max_active = max_active; e->axis.streamable = streamable;
     e->max_foot = max_foot;
     return 0;
 }
@@ -542,6 +582,22 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
     fp.h = *h; fp.v = *v;
     fp.max_sw = h_foot > 0 ? h_foot : 1;
     fp.max_sh = v_foot > 0 ? v_foot : 1;
+    /* Footprints that take most of the LDS leave the tiled kernel one or two workgroups per CU (a 0.4x Lanczos: 112 KiB per
+     * 32 x 16 target pixels); such table pairs are swept down the frame instead (resample_ops.hip; 4K -> 1536x864: 0.22 ->
+     * 0.08 ms) when the vertical table allows it (consecutive, non-decreasing tap lists) and the lists fit its registers.
+     * Small footprints (enlargements, blurs) stay with the tiles, which are as fast or faster there.
+     * CVS_FIR_TILED=1 / CVS_FIR_STREAM=1 force one or the other (A/B runs and tests). */
+    const char *force_stream = getenv("CVS_FIR_STREAM");
+    const bool can_stream = v->streamable && h->max_taps >= 1 && v->max_active >= 1 && cvk_fir_stream_supported(h->max_taps, v->max_active);
+    const bool want_stream = force_stream ? atoi(force_stream) != 0 : cvk_fir2d_lds_bytes(&fp) > 64 * 1024;
+    if (can_stream && want_stream && !getenv("CVS_FIR_TILED")) {
+        cvk_fir2d_params sp = fp;
+        sp.max_sw = h->wide_foot > 0 ? h->wide_foot : 1;
+        sp.max_sh = 0;
+        int rc = cvk_fir_stream(&sp, h->max_taps, v->max_active, cvs_cus(), s);
+        if (rc == 0) return 0;
+        (void)hipGetLastError();                              /* did not fit: the tiled kernel decides */
+    }
     if (cvk_fir2d_lds_bytes(&fp) > 150 * 1024 || h->stride > 64 || v->stride > 64) return 1;
     int rc = cvk_fir2d(&fp, s);
     if (rc != 0) { cvs_set_error("fused FIR launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }

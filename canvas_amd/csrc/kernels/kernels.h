@@ -100,6 +100,11 @@ typedef struct {
     const float *taps;
     const int *foot;
     int stride;
+    /* facts about the table the host worked out when it built it (for the streaming kernel, resample_ops.hip) */
+    int max_taps;              /* longest tap list */
+    int wide_foot;             /* widest source footprint of any run of 128 lines starting at a multiple of 128 */
+    int max_active;            /* as the vertical axis: the longest run of lines i..j such that line j starts at or before line i's last tap */
+    int streamable;            /* every list is consecutive source lines, first and last taps never decrease from line to line */
 } cvk_fir_axis;
 typedef struct {
     cvk_view target, source;
@@ -110,6 +115,9 @@ typedef struct {
 } cvk_fir2d_params;
 #define CVK_FIR2D_TILE_X 32
 #define CVK_FIR2D_TILE_Y 16
+/* the same tables, swept down the frame (resample_ops.hip): fp->max_sw = h.wide_foot; needs v.streamable */
+int cvk_fir_stream_supported(int h_taps, int v_active);
+int cvk_fir_stream(const cvk_fir2d_params *fp, int h_taps, int v_active, int cus, void *stream);
 size_t cvk_fir2d_lds_bytes(const cvk_fir2d_params *fp);     /* dynamic LDS the launch would need */
 int cvk_fir2d(const cvk_fir2d_params *fp, void *stream);
 

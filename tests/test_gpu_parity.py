@@ -668,6 +668,71 @@ def test_lanczos_resample(cvs, orc, fx, fy, tsize):
     assert_same_f32(got.array, want.array, "lanczos")
 
 
+@pytest.fixture
+def force_fir(request):
+    """CVS_FIR_STREAM / CVS_FIR_TILED are read on every call: pin the general FIR path to one of its two kernels."""
+    libc = C.CDLL(None)
+
+    def pin(which):
+        libc.unsetenv(b"CVS_FIR_STREAM")
+        libc.unsetenv(b"CVS_FIR_TILED")
+        if which == "stream":
+            libc.setenv(b"CVS_FIR_STREAM", b"1", 1)
+        elif which == "tiled":
+            libc.setenv(b"CVS_FIR_TILED", b"1", 1)
+    yield pin
+    pin(None)
+
+
+@pytest.mark.parametrize("kernel", ["stream", "tiled"])
+@pytest.mark.parametrize("ssize,scur,tsize,fx,fy", [
+    ((64, 36), None, (32, 18), 0.5, 0.5),
+    ((400, 300), None, (160, 120), 0.4, 0.4),                # several strips of 128 columns, several row segments
+    ((400, 300), (7, 5, 380, 290), (160, 120), 0.4, 0.4),    # source window inside its buffer: border lines have short tap lists
+    ((300, 200), None, (100, 150), 1.0 / 3.0, 0.75),         # a factor that is not a power of two: every line its own taps
+    ((96, 54), None, (240, 81), 2.5, 1.5),                   # enlarging: one source row feeds up to 15 target rows
+    ((130, 70), None, (40, 200), 0.3, 3.0),                  # more target rows than the source covers: lines without taps
+])
+def test_lanczos_resample_both_kernels(cvs, orc, force_fir, kernel, ssize, scur, tsize, fx, fy):
+    """The general resampler has two kernels (tiles in LDS, and the sweep down the frame that takes over when the tiles
+    would fill the LDS); whichever the footprint would choose, both must give the gather's sums bit for bit."""
+    rng = np.random.default_rng(62)
+    sfull = (0, 0, ssize[0] - 1, ssize[1] - 1)
+    src = rand_f32_frame(rng, sfull, scur, lo=-0.5, hi=1.5)
+    tfull = (0, 0, tsize[0] - 1, tsize[1] - 1)
+    want = HostFrame(tfull, np.float32)
+    orc.lib().orc_resample_lanczos_f32(want.ref(), src.ref(), C.c_float(fx), C.c_float(fy), 3)
+    force_fir(kernel)
+    d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(tfull, np.float32)
+    _lib.check(cvs.cvs_resample_lanczos_f32_dev(d_out.ref(), d_src.ref(), C.c_float(fx), C.c_float(fy), 3, None))
+    got = d_out.download()
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f32(got.array, want.array, "lanczos (%s)" % kernel)
+    # f16 on both sides through the same kernel
+    src16 = HostFrame(sfull, np.uint16, synth.truncate_to_half(src.array), scur or sfull)
+    want16 = _oracle_config3(orc, src16, tsize, np.array([1.0], np.float32), fx, fy)
+    d16, o16 = DeviceFrame.from_host(src16), DeviceFrame(tfull, np.uint16)
+    _lib.check(cvs.cvs_blur_lanczos_f16_dev(o16.ref(), d16.ref(), f32p(np.array([1.0], np.float32)), 1, C.c_float(fx), C.c_float(fy), 3, None))
+    assert_same_f16(o16.download().array, want16.array, "lanczos f16 (%s)" % kernel)
+
+
+@pytest.mark.parametrize("kernel", ["stream", "tiled"])
+@pytest.mark.parametrize("ntaps", [1, 2, 4, 10, 16])
+def test_even_and_short_blurs_both_kernels(cvs, orc, force_fir, kernel, ntaps):
+    rng = np.random.default_rng(63)
+    full, cur = (-3, -2, 300, 90), (5, 1, 280, 77)
+    src = rand_f32_frame(rng, full, cur, lo=-0.5, hi=1.5)
+    taps = rng.uniform(-0.2, 1.0, ntaps).astype(np.float32)
+    want = HostFrame(full, np.float32)
+    orc.lib().orc_fir_blur_f32(want.ref(), src.ref(), f32p(taps), ntaps)
+    force_fir(kernel)
+    d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(full, np.float32)
+    _lib.check(cvs.cvs_fir_blur_f32_dev(d_out.ref(), d_src.ref(), f32p(taps), ntaps, None))
+    got = d_out.download()
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f32(got.window_view(), want.window_view(), "blur %d taps (%s)" % (ntaps, kernel))
+
+
 def _oracle_config3(orc, src16, tsize, taps, fx, fy):
     """widen -> blur -> Lanczos -> truncate with the oracle's pieces."""
     src32 = HostFrame(src16.full_window, np.float32, orc.half_to_float(src16.array), src16.current_window)

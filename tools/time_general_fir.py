@@ -41,11 +41,13 @@ def timed(name, fn, nbytes):
 for f in (0.4, 0.75, 1.5):
     tw, th = int(w * f), int(h * f)
     out16 = DeviceFrame((0, 0, tw - 1, th - 1), np.uint16)
-    timed("Lanczos3 f16 -> f16, factor %.2f (%dx%d)" % (f, tw, th),
+    timed("1-tap blur + Lanczos3 f16 -> f16, factor %.2f (%dx%d)" % (f, tw, th),
           lambda: _lib.check(lib.cvs_resample_lanczos_f16_dev(out16.ref(), src16.ref(), C.c_float(f), C.c_float(f), 3, stream)) if hasattr(lib, "cvs_resample_lanczos_f16_dev")
           else _lib.check(lib.cvs_blur_lanczos_f16_dev(out16.ref(), src16.ref(), np.array([1.0], np.float32).ctypes.data_as(C.POINTER(C.c_float)), 1, C.c_float(f), C.c_float(f), 3, stream)),
           w * h * 8 + tw * th * 8)
     out32 = DeviceFrame((0, 0, tw - 1, th - 1), np.float32)
+    timed("Lanczos3 f32 -> f32, factor %.2f" % f,
+          lambda: _lib.check(lib.cvs_resample_lanczos_f32_dev(out32.ref(), src32.ref(), C.c_float(f), C.c_float(f), 3, stream)), w * h * 16 + tw * th * 16)
     timed("triangle scaler f32 -> f32, factor %.2f" % f,
           lambda: _lib.check(lib.cvs_scale_bilinear_f32_dev(out32.ref(), v2f(0, 0), src32.ref(), v2f(0, 0), v2f(f, f), stream)), w * h * 16 + tw * th * 16)
     out16.free(); out32.free()
