@@ -15,5 +15,8 @@ mkdir -p gpurun_out
   echo "### tools/time_host_frames.py (config 2 from host buffers: PCIe included)"; timeout -k 10 200 python tools/time_host_frames.py 2>&1
   echo "### tools/time_fixed_cost.py (per-launch fixed cost of the chain kernel)"; timeout -k 10 200 python tools/time_fixed_cost.py 2>&1
   echo "### tools/time_graph.py (HIP graph replay against direct enqueue)"; timeout -k 10 200 python tools/time_graph.py 2>&1
+  echo "### tools/time_general_fir.py (general FIR paths at 4K)"; timeout -k 10 200 python tools/time_general_fir.py 2>&1
+  echo "### tools/time_blur_over.py (blur node with 0..3 layers over it)"; timeout -k 10 200 python tools/time_blur_over.py 2>&1
+  echo "### tools/time_timeline.py (preview pulls through the Python surface, 1280x720)"; timeout -k 10 200 python tools/time_timeline.py 2>&1
 } > $out 2>&1
 tail -5 $out
