@@ -1,9 +1,11 @@
 // blur_ops.hip -- separable FIR blur with one fixed tap list, both passes in one sweep down the frame: dispatch and the
 // instances for 3-15 taps (1:1) and the Lanczos halving lists.  The kernel itself is in blur_kernel.hpp; the instances for
-// 17-31 taps are compiled in blur_long_ops.hip (they are large: a translation unit of their own builds in parallel).
+// 17-31 taps and for even counts are compiled in blur_long_ops.hip / blur_even_ops.hip (translation units of their own
+// build in parallel).
 #include "blur_kernel.hpp"
 
 extern "C" int cvk_blur_long(const cvk_blur_params *bp, int cus, void *stream);
+extern "C" int cvk_blur_even(const cvk_blur_params *bp, int cus, void *stream);
 
 namespace {
 
@@ -27,14 +29,17 @@ int pick(const cvk_blur_params *bp, int cus, hipStream_t s) {
     case 13: return launch<13, W, 1>(*bp, cus, s);
     case 15: return launch<15, W, 1>(*bp, cus, s);
     }
-    if constexpr (W == 256) { if (bp->ntaps > 15) return cvk_blur_long(bp, cus, s); }     // blur_long_ops.hip
+    if constexpr (W == 256) {
+        if (!(bp->ntaps & 1)) return cvk_blur_even(bp, cus, s);         // blur_even_ops.hip
+        if (bp->ntaps > 15) return cvk_blur_long(bp, cus, s);           // blur_long_ops.hip
+    }
     return (int)hipErrorInvalidValue;
 }
 
 }  // namespace
 
 extern "C" int cvk_blur_supported(int ntaps, int step) {
-    if (step == 1) return ntaps >= 3 && ntaps <= 31 && (ntaps & 1);
+    if (step == 1) return (ntaps >= 3 && ntaps <= 31 && (ntaps & 1)) || (ntaps >= 4 && ntaps <= 16);
     if (step == 2) return ntaps == 3 || ntaps == 7 || ntaps == 11 || ntaps == 15;
     return 0;
 }
@@ -50,7 +55,7 @@ extern "C" int cvk_blur(const cvk_blur_params *bp_in, int cus, void *stream) {
     static int env_w = -1, env_rows = -1;
     if (env_w < 0) { const char *e = getenv("CVS_BLUR_WIDTH"); env_w = e ? atoi(e) : 0; }
     if (env_rows < 0) { const char *e = getenv("CVS_BLUR_ROWS"); env_rows = e ? atoi(e) : 0; }
-    const int width = bp.ntaps > 15 ? 256 : env_w ? env_w : (cols <= 128 ? 128 : 256);
+    const int width = (bp.ntaps > 15 || !(bp.ntaps & 1)) ? 256 : env_w ? env_w : (cols <= 128 ? 128 : 256);      // long and even lists: 256-lane instances only
     if (bp.rows_per_wg <= 0 && env_rows > 0) bp.rows_per_wg = env_rows;
     return width == 128 ? pick<128>(&bp, cus, (hipStream_t)stream) : pick<256>(&bp, cus, (hipStream_t)stream);
 }

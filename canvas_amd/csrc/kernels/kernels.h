@@ -121,7 +121,7 @@ int cvk_fir_stream(const cvk_fir2d_params *fp, int h_taps, int v_active, int cus
 size_t cvk_fir2d_lds_bytes(const cvk_fir2d_params *fp);     /* dynamic LDS the launch would need */
 int cvk_fir2d(const cvk_fir2d_params *fp, void *stream);
 
-/* separable FIR with one tap list for every line (odd, 3..31 taps, all finite), optionally decimating by 2:
+/* separable FIR with one tap list for every line (3..31 taps odd, 4..16 even, all finite), optionally decimating by 2:
  * both passes in one sweep, the vertical window in registers.  Source pixels outside (sx0..sx1, sy0..sy1) count as skipped taps. */
 #define CVK_BLUR_MAX_OVER 4
 typedef struct {

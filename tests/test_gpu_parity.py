@@ -676,6 +676,9 @@ def force_fir(request):
     def pin(which):
         libc.unsetenv(b"CVS_FIR_STREAM")
         libc.unsetenv(b"CVS_FIR_TILED")
+        libc.unsetenv(b"CVS_BLUR_GENERIC")
+        if which:
+            libc.setenv(b"CVS_BLUR_GENERIC", b"1", 1)          # blurs too: past the register-window kernel, to the table kernels
         if which == "stream":
             libc.setenv(b"CVS_FIR_STREAM", b"1", 1)
         elif which == "tiled":
