@@ -736,6 +736,25 @@ def test_even_and_short_blurs_both_kernels(cvs, orc, force_fir, kernel, ntaps):
     assert_same_f32(got.window_view(), want.window_view(), "blur %d taps (%s)" % (ntaps, kernel))
 
 
+def test_full_size_resample_agrees_between_the_two_kernels(cvs, force_fir):
+    """3840x2160 -> 1536x864 Lanczos3 (f16 in and out): the footprint rule sends this to the sweep kernel; the tiled kernel,
+    forced, must produce the same frame bit for bit (each is checked against the oracle at small sizes)."""
+    w, h, f = 3840, 2160, 0.4
+    tw, th = int(w * f), int(h * f)
+    one = np.array([1.0], np.float32)
+    d_src = DeviceFrame.from_host(synth.layer_frame(w, h, 1, 0))
+    outs = []
+    for kernel in (None, "tiled", "stream"):
+        force_fir(kernel)
+        d_out = DeviceFrame((0, 0, tw - 1, th - 1), np.uint16)
+        _lib.check(cvs.cvs_blur_lanczos_f16_dev(d_out.ref(), d_src.ref(), f32p(one), 1, C.c_float(f), C.c_float(f), 3, None))
+        got = d_out.download()
+        assert got.current_window.tuple() == (0, 0, tw - 1, th - 1)
+        outs.append(got.array)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    assert len(np.unique(outs[0])) > 1000
+
+
 def _oracle_config3(orc, src16, tsize, taps, fx, fy):
     """widen -> blur -> Lanczos -> truncate with the oracle's pieces."""
     src32 = HostFrame(src16.full_window, np.float32, orc.half_to_float(src16.array), src16.current_window)
