@@ -30,6 +30,13 @@ graph = GraphStream(w, h, ring=2)
 taps = synth.gaussian_taps(9, 1.5)
 small = DeviceFrame((0, 0, w // 2 - 1, h // 2 - 1), np.uint16)
 f32p = taps.ctypes.data_as(C.POINTER(C.c_float))
+# the sweep resampler (4K -> 1536x864 Lanczos3 behind a 1-tap blur) and a 21-tap blur
+one = np.array([1.0], np.float32)
+onep = one.ctypes.data_as(C.POINTER(C.c_float))
+odd = DeviceFrame((0, 0, int(w * 0.4) - 1, int(h * 0.4) - 1), np.uint16)
+taps21 = synth.gaussian_taps(21, 3.5)
+t21p = taps21.ctypes.data_as(C.POINTER(C.c_float))
+wide = DeviceFrame(full, np.uint16)
 
 
 def once():
@@ -37,12 +44,14 @@ def once():
     graph.render(0, stream)
     graph.render(1, stream)
     _lib.check(lib.cvs_blur_lanczos_f16_dev(small.ref(), sets[0][1][1].ref(), f32p, 9, C.c_float(0.5), C.c_float(0.5), 3, stream))
+    _lib.check(lib.cvs_blur_lanczos_f16_dev(odd.ref(), sets[1][1][1].ref(), onep, 1, C.c_float(0.4), C.c_float(0.4), 3, stream))
+    _lib.check(lib.cvs_fir_blur_f16_dev(wide.ref(), sets[2][1][1].ref(), t21p, 21, stream))
 
 
 def snapshot():
     _lib.check(lib.cvs_stream_sync(stream))
     return [s[0].download().array.copy() for s in sets] + [graph.slots[0]["out"].download().array.copy(), graph.slots[1]["out"].download().array.copy(),
-                                                        small.download().array.copy()]
+                                                        small.download().array.copy(), odd.download().array.copy(), wide.download().array.copy()]
 
 
 once()
@@ -59,5 +68,5 @@ while time.perf_counter() - t0 < seconds:
             print("MISMATCH after %d iterations: %d values differ" % (n, bad))
             sys.exit(1)
     checks += 1
-print("soak ok: %d iterations (%d launches of the chain over 8 frames, %d config-5 frames, %d config-3 frames), %d full compares, %.1f s"
+print("soak ok: %d iterations (%d launches of the chain over 8 frames, %d config-5 frames, %d config-3 frames, as many 0.4x resamples and 21-tap blurs), %d full compares, %.1f s"
       % (n, n, 2 * n, n, checks, time.perf_counter() - t0))
