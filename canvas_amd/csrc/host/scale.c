@@ -570,6 +570,37 @@ static int triangle_table_cached(float tmin, float smin, float factor, int s0, i
     return axis_get_ex(&key, &pl, axis, &foot, used_lo, used_hi, pin);
 }
 
+/* The same two cached tables as two launches through an f32 frame in HBM (k_fir: one lane per target pixel, taps gathered
+ * through L1/L2): what a table pair falls back to when neither fused kernel takes it (footprints beyond the LDS and tap lists
+ * beyond the sweep kernel's registers: a Lanczos below about 0.2x).  Slower than either, but asynchronous like them: no
+ * allocation, upload or wait on the way.  Same sums in the same order: x pass, then y pass, f32 between them. */
+static int gather_pass(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, int in_half,
+                       const cvk_fir_axis *tab, int axis, int t0, int t1, int lo, int hi, hipStream_t s) {
+    if (t1 < t0 || hi < lo) return 0;
+    cvk_fir_params fp;
+    memset(&fp, 0, sizeof fp);
+    fp.target = cvs_view(tdata, tfull);
+    fp.source = cvs_view((void *)sdata, sfull);
+    fp.axis = axis;
+    fp.t0 = t0; fp.t1 = t1; fp.lo = lo; fp.hi = hi;
+    fp.ntaps = tab->ntaps; fp.tap_src = tab->src; fp.taps = tab->taps; fp.stride = tab->stride;
+    fp.in_half = in_half; fp.out_half = out_half;
+    return cvk_fir_gather(&fp, s);
+}
+
+static int fir_two_launches(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
+                            const box2i *rect, const cvk_fir_axis *h, const cvk_fir_axis *v, hipStream_t s) {
+    box2i mfull;
+    box2i_set(&mfull, rect->min.x, sw->min.y, rect->max.x, sw->max.y);
+    void *mid = cvs_pool_malloc(cvs_box_pixels(&mfull) * sizeof(rgba_f32), s);
+    if (!mid) return -1;
+    int rc = gather_pass(mid, &mfull, 0, sdata, sfull, in_half, h, 1, rect->min.x, rect->max.x, sw->min.y, sw->max.y, s);
+    if (rc == 0) rc = gather_pass(tdata, tfull, out_half, mid, &mfull, 0, v, 0, rect->min.y, rect->max.y, rect->min.x, rect->max.x, s);
+    cvs_pool_free(mid, s);
+    if (rc != 0) { cvs_set_error("FIR gather launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
+    return 0;
+}
+
 /* 0 = launched, 1 = does not fit an LDS tile (caller falls back), <0 = error */
 static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, int in_half,
                         const box2i *rect, const cvk_fir_axis *h, int h_foot, const cvk_fir_axis *v, int v_foot, hipStream_t s) {
@@ -638,6 +669,7 @@ static int blur_fused_over(void *tdata, const box2i *tfull, int out_half, const 
     int rc = axis_get(&kh, taps, 0.0f, &h, &hf, &ph);
     if (rc == 0) rc = axis_get(&kv, taps, 0.0f, &v, &vf, &pv);
     rc = rc == 0 ? fir2d_launch(tdata, tfull, out_half, sdata, sfull, in_half, win, &h, hf, &v, vf, s) : -1;
+    if (rc == 1) rc = fir_two_launches(tdata, tfull, out_half, sdata, sfull, sw, in_half, win, &h, &v, s);
     axis_done(ph, s); axis_done(pv, s);
     return rc;
 }
@@ -682,6 +714,7 @@ static int lanczos_fused(void *tdata, const box2i *tfull, int out_half, const vo
     int rc = axis_get(&kh, NULL, fx, &h, &hf, &ph);
     if (rc == 0) rc = axis_get(&kv, NULL, fy, &v, &vf, &pv);
     rc = rc == 0 ? fir2d_launch(tdata, tfull, out_half, sdata, sfull, in_half, tfull, &h, hf, &v, vf, s) : -1;
+    if (rc == 1) rc = fir_two_launches(tdata, tfull, out_half, sdata, sfull, sw, in_half, tfull, &h, &v, s);
     axis_done(ph, s); axis_done(pv, s);
     return rc;
 }

@@ -755,6 +755,23 @@ def test_full_size_resample_agrees_between_the_two_kernels(cvs, force_fir):
     assert len(np.unique(outs[0])) > 1000
 
 
+@pytest.mark.parametrize("ssize,tsize,fx,fy", [((600, 400), (60, 40), 0.1, 0.1), ((500, 64), (40, 64), 0.08, 1.0), ((300, 900), (150, 60), 0.5, 1.0 / 15.0)])
+def test_lanczos_far_below_one(cvs, orc, ssize, tsize, fx, fy):
+    """Tap lists of 59-90: beyond the sweep kernel's registers and the tiles' LDS.  The cached tables then run as two gather
+    launches through an f32 frame (no allocation, upload or wait on the way) -- same sums."""
+    rng = np.random.default_rng(64)
+    src = rand_f32_frame(rng, (0, 0, ssize[0] - 1, ssize[1] - 1), lo=-0.5, hi=1.5)
+    tfull = (0, 0, tsize[0] - 1, tsize[1] - 1)
+    want = HostFrame(tfull, np.float32)
+    orc.lib().orc_resample_lanczos_f32(want.ref(), src.ref(), C.c_float(fx), C.c_float(fy), 3)
+    d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(tfull, np.float32)
+    for _ in range(2):
+        _lib.check(cvs.cvs_resample_lanczos_f32_dev(d_out.ref(), d_src.ref(), C.c_float(fx), C.c_float(fy), 3, None))
+        got = d_out.download()
+        assert same_window(got.current_window, want.current_window)
+        assert_same_f32(got.array, want.array, "lanczos %r" % ((fx, fy),))
+
+
 def _oracle_config3(orc, src16, tsize, taps, fx, fy):
     """widen -> blur -> Lanczos -> truncate with the oracle's pieces."""
     src32 = HostFrame(src16.full_window, np.float32, orc.half_to_float(src16.array), src16.current_window)
