@@ -113,35 +113,6 @@ static int plan_triangle(tap_table *tb, float tmin, float smin, float factor, in
     return rc;
 }
 
-/* upload a table and run the gather over [used_lo, used_hi] x [lo, hi] */
-static int run_table(const tap_table *tb, cvk_view target, cvk_view source, int axis, int lo, int hi, hipStream_t s) {
-    if (tb->used_hi < tb->used_lo || hi < lo) return 0;
-    const int first = tb->used_lo - tb->t0, lines = tb->used_hi - tb->used_lo + 1;
-    size_t n_i = (size_t)lines, n_t = (size_t)lines * (size_t)tb->stride;
-    char *dev = NULL;
-    size_t off_src = (n_i * sizeof(int) + 255) & ~(size_t)255;
-    size_t off_tap = off_src + ((n_t * sizeof(int) + 255) & ~(size_t)255);
-    size_t total = off_tap + n_t * sizeof(float);
-    CVS_HIP(hipMalloc((void **)&dev, total));
-    hipError_t e = hipMemcpyAsync(dev, tb->ntaps + first, n_i * sizeof(int), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(dev + off_src, tb->tap_src + (size_t)first * tb->stride, n_t * sizeof(int), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(dev + off_tap, tb->taps + (size_t)first * tb->stride, n_t * sizeof(float), hipMemcpyHostToDevice, s);
-    int rc = (int)e;
-    if (rc == 0) {
-        cvk_fir_params fp;
-        memset(&fp, 0, sizeof fp);
-        fp.target = target; fp.source = source; fp.axis = axis;
-        fp.t0 = tb->used_lo; fp.t1 = tb->used_hi; fp.lo = lo; fp.hi = hi;
-        fp.ntaps = (const int *)dev; fp.tap_src = (const int *)(dev + off_src); fp.taps = (const float *)(dev + off_tap);
-        fp.stride = tb->stride;
-        rc = cvk_fir_gather(&fp, s);
-    }
-    if (rc == 0) rc = (int)hipStreamSynchronize(s);     /* the host table and `dev` go away now */
-    hipFree(dev);
-    if (rc != 0) cvs_set_error("FIR pass failed: %s", hipGetErrorString((hipError_t)rc));
-    return rc;
-}
-
 /* device-resident, cached form of plan_triangle's table (defined with the table cache below) */
 static int triangle_table_cached(float tmin, float smin, float factor, int s0, int s1, int t0, int t1, bool count_touch,
                                  cvk_fir_axis *axis, int *used_lo, int *used_hi, int *pin);
@@ -297,27 +268,6 @@ static int plan_blur(tap_table *tb, int t0, int t1, int s0, int s1, const float 
     return rc;
 }
 
-/* fallback: the two passes through an f32 intermediate in HBM (footprints too large for an LDS tile) */
-static int blur_two_pass(rgba_frame_f32 *target, const rgba_frame_f32 *source, const float *taps, int ntaps, hipStream_t s) {
-    box2i win;
-    box2i_intersect(&win, &source->current_window, &target->full_window);
-    target->current_window = win;
-    if (box2i_is_empty(&win)) return 0;
-    const box2i *sw = &source->current_window;
-    rgba_frame_f32 mid = { NULL, *sw, *sw };
-    mid.data = cvs_malloc(cvs_box_pixels(sw) * sizeof(rgba_f32));
-    if (!mid.data) { box2i_set_empty(&target->current_window); return -1; }
-    tap_table tb;
-    int rc = plan_blur(&tb, sw->min.x, sw->max.x, sw->min.x, sw->max.x, taps, ntaps);
-    if (rc == 0) rc = run_table(&tb, cvs_view(mid.data, &mid.full_window), cvs_view(source->data, &source->full_window), 1, sw->min.y, sw->max.y, s);
-    table_free(&tb);
-    if (rc == 0) rc = plan_blur(&tb, win.min.y, win.max.y, sw->min.y, sw->max.y, taps, ntaps);
-    if (rc == 0) { rc = run_table(&tb, cvs_view(target->data, &target->full_window), cvs_view(mid.data, &mid.full_window), 0, win.min.x, win.max.x, s); table_free(&tb); }
-    cvs_free(mid.data);
-    if (rc != 0) box2i_set_empty(&target->current_window);
-    return rc;
-}
-
 /* ---------------------------------------------------------------- Lanczos gather resample (repo-defined)
  * Per target line the taps come from filter_createLanczos(factor, kernel_size, frac(centre)) with
  * centre = t / factor (origin 0 on both sides); x pass then y pass; f32 accumulate from 0. */
@@ -341,27 +291,6 @@ static int plan_lanczos(tap_table *tb, int t0, int t1, int s0, int s1, float fac
         filter_free(&f);
     }
     tb->used_lo = t0; tb->used_hi = t1;
-    return rc;
-}
-
-static int lanczos_two_pass(rgba_frame_f32 *target, const rgba_frame_f32 *source, float fx, float fy, int ksize, hipStream_t s) {
-    const box2i *sw = &source->current_window, *tf = &target->full_window;
-    rgba_frame_f32 mid;
-    box2i_set(&mid.full_window, tf->min.x, sw->min.y, tf->max.x, sw->max.y);
-    mid.current_window = mid.full_window;
-    mid.data = cvs_malloc(cvs_box_pixels(&mid.full_window) * sizeof(rgba_f32));
-    if (!mid.data) { box2i_set_empty(&target->current_window); return -1; }
-    const int lo_y = sw->min.y, hi_y = sw->max.y;
-    tap_table tb;
-    int rc = plan_lanczos(&tb, tf->min.x, tf->max.x, sw->min.x, sw->max.x, fx, ksize);
-    if (rc == 0) rc = run_table(&tb, cvs_view(mid.data, &mid.full_window), cvs_view(source->data, &source->full_window), 1, lo_y, hi_y, s);
-    table_free(&tb);
-    const int lo_x = tf->min.x, hi_x = tf->max.x;
-    if (rc == 0) rc = plan_lanczos(&tb, tf->min.y, tf->max.y, sw->min.y, sw->max.y, fy, ksize);
-    if (rc == 0) { rc = run_table(&tb, cvs_view(target->data, &target->full_window), cvs_view(mid.data, &mid.full_window), 0, lo_x, hi_x, s); table_free(&tb); }
-    cvs_free(mid.data);
-    if (rc == 0) target->current_window = *tf;
-    else box2i_set_empty(&target->current_window);
     return rc;
 }
 
@@ -729,7 +658,6 @@ CVS_EXPORT int cvs_fir_blur_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32
     target->current_window = win;
     if (box2i_is_empty(&win)) return 0;
     int rc = blur_fused(target->data, &target->full_window, 0, source->data, &source->full_window, &source->current_window, 0, &win, taps, ntaps, s);
-    if (rc == 1) rc = blur_two_pass(target, source, taps, ntaps, s);
     if (rc != 0) box2i_set_empty(&target->current_window);
     return rc;
 }
@@ -746,15 +674,6 @@ CVS_EXPORT int cvs_fir_blur_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16
     target->current_window = win;
     if (box2i_is_empty(&win)) return 0;
     int rc = blur_fused(target->data, &target->full_window, 1, source->data, &source->full_window, &source->current_window, 1, &win, taps, ntaps, s);
-    if (rc == 1) {
-        /* tile too large for LDS: the same nodes one by one on f32 frames */
-        rgba_frame_f32 wide = { cvs_pool_malloc(cvs_box_pixels(&source->full_window) * sizeof(rgba_f32), s), source->full_window, source->full_window };
-        rgba_frame_f32 out = { cvs_pool_malloc(cvs_box_pixels(&target->full_window) * sizeof(rgba_f32), s), target->full_window, target->full_window };
-        rc = (wide.data && out.data) ? cvs_frame_f16_to_f32_dev(&wide, source, s) : -1;
-        if (rc == 0) rc = blur_two_pass(&out, &wide, taps, ntaps, s);
-        if (rc == 0) rc = cvs_frame_f32_to_f16_dev(target, &out, s);
-        cvs_pool_free(wide.data, s); cvs_pool_free(out.data, s);
-    }
     if (rc != 0) box2i_set_empty(&target->current_window);
     return rc;
 }
@@ -794,12 +713,6 @@ CVS_EXPORT int cvs_blur_over_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *
         if (!box2i_is_empty(&win)) {
             acc.current_window = win;
             rc = blur_fused(acc.data, full, 0, source->data, &source->full_window, &source->current_window, 1, &win, taps, ntaps, s);
-            if (rc == 1) {
-                rgba_frame_f32 wide = { cvs_pool_malloc(cvs_box_pixels(&source->full_window) * sizeof(rgba_f32), s), source->full_window, source->full_window };
-                rc = wide.data ? cvs_frame_f16_to_f32_dev(&wide, source, s) : -1;
-                if (rc == 0) rc = blur_two_pass(&acc, &wide, taps, ntaps, s);
-                cvs_pool_free(wide.data, s);
-            }
         }
     }
     for (int l = 0; rc == 0 && l < noverlays; l++) {
@@ -821,7 +734,6 @@ CVS_EXPORT int cvs_resample_lanczos_f32_dev(rgba_frame_f32 *target, const rgba_f
     }
     hipStream_t s = cvs_pick_stream(stream);
     int rc = lanczos_fused(target->data, &target->full_window, 0, source->data, &source->full_window, &source->current_window, 0, fx, fy, ksize, s);
-    if (rc == 1) return lanczos_two_pass(target, source, fx, fy, ksize, s);
     if (rc == 0) target->current_window = target->full_window;
     else box2i_set_empty(&target->current_window);
     return rc;
@@ -843,18 +755,7 @@ CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame
     if (!mid.data) { box2i_set_empty(&target->current_window); return -1; }
     int rc = blur_fused(mid.data, &mid.full_window, 0, source->data, &source->full_window, sw, 1, sw, taps, ntaps, s);
     if (rc == 0) rc = lanczos_fused(target->data, &target->full_window, 1, mid.data, &mid.full_window, sw, 0, fx, fy, ksize, s);
-    if (rc == 1) {
-        /* tiles too large for LDS: same nodes one by one on f32 frames */
-        rgba_frame_f32 wide = { cvs_pool_malloc(cvs_box_pixels(&source->full_window) * sizeof(rgba_f32), s), source->full_window, source->full_window };
-        rgba_frame_f32 small = { cvs_pool_malloc(cvs_box_pixels(&target->full_window) * sizeof(rgba_f32), s), target->full_window, target->full_window };
-        rc = (wide.data && small.data) ? cvs_frame_f16_to_f32_dev(&wide, source, s) : -1;
-        if (rc == 0) rc = blur_two_pass(&mid, &wide, taps, ntaps, s);
-        if (rc == 0) rc = lanczos_two_pass(&small, &mid, fx, fy, ksize, s);
-        if (rc == 0) rc = cvs_frame_f32_to_f16_dev(target, &small, s);
-        cvs_pool_free(wide.data, s); cvs_pool_free(small.data, s);
-    } else if (rc == 0) {
-        target->current_window = target->full_window;
-    }
+    if (rc == 0) target->current_window = target->full_window;
     cvs_pool_free(mid.data, s);
     if (rc != 0) box2i_set_empty(&target->current_window);
     return rc;
