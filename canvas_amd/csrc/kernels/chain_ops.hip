@@ -286,7 +286,8 @@ static int chain_dispatch(const cvk_chain_job *jobs, int njobs, int uniform_laye
     unsigned block = bl ? (unsigned)atoi(bl) : 512u;
     if (block < 64 || block > (unsigned)kWG || (block & 63u)) block = 512u;
     const bool fused_kernel = variant != 0 && uniform_layers >= 1 && uniform_layers <= kFusedLayers;
-    const int per_launch = fused_kernel ? kJobsPerLaunch : kJobsPerLaunchV0;
+    int per_launch = fused_kernel ? kJobsPerLaunch : kJobsPerLaunchV0;
+    if (const char *pl = getenv("CVS_CHAIN_JOBS_PER_LAUNCH")) { const int v = atoi(pl); if (v >= 1 && v < per_launch) per_launch = v; }
     for (int first = 0; first < njobs; first += per_launch) {
         const int n = njobs - first < per_launch ? njobs - first : per_launch;
         int rc;

@@ -4,6 +4,8 @@ Layer k of frame i: f16 RGBA from a counter-based RNG (Philox) seeded 0xC0FFEE +
 r,g,b ~ U[0,1) truncated to half; alpha == 1.0 on layer 0 and ~ U[0,1) on layers >= 1 (so the
 divide of the over operator is always live); full_window = current_window = (0,0)-(W-1,H-1).
 """
+import os
+
 import numpy as np
 
 from .abi import HostFrame
@@ -23,12 +25,25 @@ def truncate_to_half(x):
 
 def layer_pixels(width, height, layer, frame, opaque_base=True):
     """opaque_base=False is NOT the BASELINE input: it gives layer 0 a random alpha too, so that the
-    over operator's divides see denominators other than 1.0 (bench.py --translucent-base)."""
+    over operator's divides see denominators other than 1.0 (bench.py --translucent-base).
+    CANVAS_SYNTH_CACHE=<dir>: keep generated frames as .npy there (measurement scripts that start the same
+    workload in many processes; the cached file holds exactly what the generator returns)."""
+    cache = os.environ.get("CANVAS_SYNTH_CACHE")
+    path = None
+    if cache:
+        path = os.path.join(cache, "synth_%dx%d_l%d_f%d_%d.npy" % (width, height, layer, frame, int(bool(opaque_base))))
+        if os.path.exists(path):
+            return np.load(path)
     rng = np.random.Generator(np.random.Philox(SEED_BASE + 1000 * layer + frame))
     px = rng.random((height, width, 4), dtype=np.float32)
     codes = truncate_to_half(px)
     if layer == 0 and opaque_base:
         codes[..., 3] = 0x3C00
+    if path:
+        os.makedirs(cache, exist_ok=True)
+        tmp = "%s.%d.tmp.npy" % (path, os.getpid())
+        np.save(tmp, codes)
+        os.replace(tmp, path)
     return codes
 
 

@@ -47,7 +47,9 @@ def main():
     for r in range(args.rounds + 1):
         for v in variants:
             os.environ["CVS_CHAIN_VARIANT"] = v.split(":")[0]
-            os.environ["CVS_DIAG_GRIDMUL"] = v.split(":")[1] if ":" in v else "1"
+            parts = v.split(":")                      # variant[:gridmul[:block]]
+            os.environ["CVS_DIAG_GRIDMUL"] = parts[1] if len(parts) > 1 and parts[1] else "1"
+            os.environ["CVS_CHAIN_BLOCK"] = parts[2] if len(parts) > 2 else os.environ.get("AB_DEFAULT_BLOCK", "512")
             lib.cvs_event_record(e0, stream)
             for _ in range(args.steps):
                 chain_color_over(ring, m, _lib.LUT_REC709_TO_LINEAR_SCENE if args.lut == 'rec709' else _lib.LUT_NONE, _lib.LUT_NONE, stream)
