@@ -22,6 +22,12 @@ namespace cvs {
 
 __device__ __forceinline__ bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0; }
 
+// Placed at the top of a rarely taken, wave-uniform branch.  Without it hipcc if-converts a short branch body: the
+// |x| >= 65536 fix-up below became 6 packed multiplies + 6 selects executed on EVERY trip (seen in the ISA of the
+// first pipelined kernel: 18 issue slots per layer pair for a case that ordinary footage never reaches).  An asm
+// statement cannot be speculated, so the body stays behind its s_cbranch.
+__device__ __forceinline__ void rare_path() { asm volatile("; rare path"); }
+
 // truncate a pair of f32 to half and widen back (the rounding point between the colour filter and the
 // stack, color.c:132 / :159 + main.c:128-136); POST applies the post-table to the half codes
 template <bool POST_LDS, bool POST_GLB>
@@ -48,7 +54,7 @@ __device__ __forceinline__ px32x2 grade_pair(u32x4 p, const MatR &mat, const uin
     // rare: a channel at or beyond the half range must become Inf, not 65504
     const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.r.x), __builtin_fabsf(o.g.x)), __builtin_fabsf(o.b.x)),
                                       __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.r.y), __builtin_fabsf(o.g.y)), __builtin_fabsf(o.b.y)));
-    if (wave_any(big >= 65536.0f)) { o.r = saturate_to_inf2(o.r); o.g = saturate_to_inf2(o.g); o.b = saturate_to_inf2(o.b); }
+    if (wave_any(big >= 65536.0f)) { rare_path(); o.r = saturate_to_inf2(o.r); o.g = saturate_to_inf2(o.g); o.b = saturate_to_inf2(o.b); }
     constexpr bool post_lds = POST && !PRE, post_glb = POST && PRE;     // the LDS slot belongs to the pre table when both exist
     o.r = through_half<post_lds, post_glb>(o.r, lds_lut, glb_post);
     o.g = through_half<post_lds, post_glb>(o.g, lds_lut, glb_post);
@@ -178,27 +184,30 @@ __device__ __forceinline__ u32x4 narrow_pair(px32x2 v) {
     const float big = __builtin_fmaxf(
         __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v.r.x), __builtin_fabsf(v.g.x)), __builtin_fabsf(v.b.x)), __builtin_fabsf(v.a.x)),
         __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(v.r.y), __builtin_fabsf(v.g.y)), __builtin_fabsf(v.b.y)), __builtin_fabsf(v.a.y)));
-    if (wave_any(big >= 65536.0f)) { v.r = saturate_to_inf2(v.r); v.g = saturate_to_inf2(v.g); v.b = saturate_to_inf2(v.b); v.a = saturate_to_inf2(v.a); }
+    if (wave_any(big >= 65536.0f)) { rare_path(); v.r = saturate_to_inf2(v.r); v.g = saturate_to_inf2(v.g); v.b = saturate_to_inf2(v.b); v.a = saturate_to_inf2(v.a); }
     return u32x4{ pkrtz(v.r.x, v.g.x), pkrtz(v.b.x, v.a.x), pkrtz(v.r.y, v.g.y), pkrtz(v.b.y, v.a.y) };
 }
 
-// a layer as the stack sees it: through the colour filter, or (mat.plain, wave-uniform) just widened
-template <bool PRE, bool POST>
-__device__ __forceinline__ px32x2 layer_pair(u32x4 p, const MatR &mat, const uint16_t *lut, const uint16_t *post) {
-    if (mat.plain) return widen2(make_uint4(p.x, p.y, p.z, p.w));
-    return grade_pair<PRE, POST>(p, mat, lut, post);
-}
+// What a launch of the chain kernel does with its layers (one instantiation each, so that the trip loop carries no
+// wave-uniform mode branches and no dead code of the other modes):
+//   CHAIN_GRADE  every layer through the colour filter, then the stack      (config 2)
+//   CHAIN_PLAIN  layers widened as they are, then the stack                 (a VideoWorkspace of half-native items, config 4)
+//   CHAIN_CROSS  two layers crossfaded with weights wa, wb                  (VideoMixFilter on half-native inputs)
+enum { CHAIN_GRADE = 0, CHAIN_PLAIN = 1, CHAIN_CROSS = 2 };
 
-template <int NL, bool PRE, bool POST>
+__device__ __forceinline__ px32x2 widen_pair(u32x4 p) { return widen2(make_uint4(p.x, p.y, p.z, p.w)); }
+
+template <int NL, bool PRE, bool POST, int MODE>
 __device__ __forceinline__ u32x4 chain_pair_lean(const u32x4 (&w)[NL], const MatR &mat, const uint16_t *lut, const uint16_t *post) {
-    if constexpr (NL == 2) {
-        if (mat.cross)         // wave-uniform: a crossfade of two half frames (widen, video_mix.c:193-205, truncate)
-            return narrow_pair(cross_pair(widen2(make_uint4(w[0].x, w[0].y, w[0].z, w[0].w)), widen2(make_uint4(w[1].x, w[1].y, w[1].z, w[1].w)), mat.wa, mat.wb));
-    }
-    px32x2 acc = layer_pair<PRE, POST>(w[0], mat, lut, post);
+    if constexpr (MODE == CHAIN_CROSS) {
+        static_assert(NL == 2, "a crossfade has two inputs");
+        return narrow_pair(cross_pair(widen_pair(w[0]), widen_pair(w[1]), mat.wa, mat.wb));     // widen, video_mix.c:193-205, truncate
+    } else {
+        px32x2 acc = MODE == CHAIN_PLAIN ? widen_pair(w[0]) : grade_pair<PRE, POST>(w[0], mat, lut, post);
 #pragma unroll
-    for (int k = 1; k < NL; k++) acc = over_pair(acc, layer_pair<PRE, POST>(w[k], mat, lut, post));
-    return narrow_pair(acc);
+        for (int k = 1; k < NL; k++) acc = over_pair(acc, MODE == CHAIN_PLAIN ? widen_pair(w[k]) : grade_pair<PRE, POST>(w[k], mat, lut, post));
+        return narrow_pair(acc);
+    }
 }
 
 // the colour filter alone, codes in -> codes out (color.c structure on a pair of pixels)
@@ -216,7 +225,7 @@ __device__ __forceinline__ u32x4 color_pair_codes(u32x4 p, const MatR &mat, cons
     px32x2 o = mat3x2(v, mat);
     const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.r.x), __builtin_fabsf(o.g.x)), __builtin_fabsf(o.b.x)),
                                       __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(o.r.y), __builtin_fabsf(o.g.y)), __builtin_fabsf(o.b.y)));
-    if (wave_any(big >= 65536.0f)) { o.r = saturate_to_inf2(o.r); o.g = saturate_to_inf2(o.g); o.b = saturate_to_inf2(o.b); }
+    if (wave_any(big >= 65536.0f)) { rare_path(); o.r = saturate_to_inf2(o.r); o.g = saturate_to_inf2(o.g); o.b = saturate_to_inf2(o.b); }
     uint32_t rr = pkrtz(o.r.x, o.r.y), gg = pkrtz(o.g.x, o.g.y), bb = pkrtz(o.b.x, o.b.y);    // lo: first pixel, hi: second
     uint32_t q[8] = { rr & 0xFFFFu, gg & 0xFFFFu, bb & 0xFFFFu, c[3], rr >> 16, gg >> 16, bb >> 16, c[7] };
     constexpr bool post_lds = POST && !PRE, post_glb = POST && PRE;

@@ -7,17 +7,21 @@
 // each arrow a pass over memory with f32 intermediates.  Here a pixel goes through the whole
 // chain in registers: 8 B read per layer pixel + 8 B written per output pixel.
 //
-// Shape of the kernel (MI355X):
-//   * persistent grid, ONE workgroup per CU: the 128 KiB transfer table lives in LDS (160 KiB per CU),
-//     staged once per launch; a launch carries up to 32 frames so the staging (~3 us) is amortised;
-//   * 512 lanes per workgroup (2 waves per SIMD): with one 16-byte load per layer per lane in flight
-//     that is 16 KiB outstanding per CU, the amount at which this chip's HBM streams fastest for a
-//     2-read + 1-write pattern (tools/membench.hip: 4 MiB in flight chip-wide -> 6.2 TB/s; 16 MiB -> 5.3);
-//   * a lane owns pixel PAIRS: one global_load_dwordx4 per layer, one global_store_dwordx4, all
-//     non-temporal (nothing is re-read); the pair's arithmetic runs as packed f32;
-//   * hand-counted software pipeline (below): the loads of trip t+1 are in flight during the
-//     arithmetic of trip t;
-//   * job records arrive in the kernel-argument segment (scalar loads, nothing to recycle).
+// Shape of the kernel (MI355X), second generation (what changed and why: DESIGN.md 4.1):
+//   * 256 workgroups of 512 lanes, one per CU: the 128 KiB transfer table lives in LDS (160 KiB per CU);
+//   * a lane owns pixel PAIRS: one global_load_dwordx4 per layer, one global_store_dwordx4, all non-temporal;
+//   * the batch of frames is ONE run of 8 KiB chunks (512 pairs): workgroup b takes chunks b, b + 256, b + 512, ...
+//     of the whole batch, walking from frame to frame without a per-frame tail.  The walk is wave-uniform, so it
+//     lives in SGPRs: a load is `global_load_dwordx4 v, v_lane_offset, s[chunk base]` and the trip loop carries no
+//     vector address arithmetic at all (the first generation spent 18 VALU instructions per trip on 64-bit
+//     per-lane indices and frame-boundary selects);
+//   * software pipeline by hand: the loads of trip t+1 are in flight during the arithmetic of trip t (inline asm,
+//     hipcc would sink them; cdna_hip_programming.md 5.7);
+//   * SHORT LAUNCHES: the host cuts a batch into launches of about eight 4K frames (kBytesPerLaunch).  Measured: in a
+//     long launch the persistent workgroups drift apart (some CUs stream a little faster for the whole launch), the
+//     2 MiB window of addresses in flight chip-wide smears out and HBM efficiency falls -- a plain 2-read + 1-write
+//     stream drops from 0.80 of 8 TB/s at 4 frames per launch to 0.715 at 64.  A kernel boundary is the cheapest
+//     rendezvous there is (~3.5 us including the table staging).
 // Bound: HBM.  Algorithmic bytes per output pixel: 8 * (nlayers + 1)  (config 2: 24).
 #include "lut_common.hpp"
 #include "grade.hpp"
@@ -29,15 +33,19 @@ using namespace cvs;
 namespace {
 
 // Job records travel as kernel arguments (<= 4 KiB per launch).  The production kernel takes up to four layers, so
-// its records are compact (48 B) and a launch carries 64 frames: a launch costs ~24 us beyond its per-frame time
-// (table staging, ramp, drain), which is worth amortising.  The first version keeps the full 8-layer record.
+// its records are compact (48 B) and a launch can carry 64 frames; the first version keeps the full 8-layer record.
 constexpr int kJobsPerLaunchV0 = 32, kJobsPerLaunch = 64, kFusedLayers = 4;
+// bytes (read + written) one launch of the production kernel moves before the host starts the next one:
+// eight 4K two-layer frames.  See "SHORT LAUNCHES" above; tools/chainlab.hip and profiles/r02/launch_split.txt.
+constexpr uint64_t kBytesPerLaunch = 8ull * 3840 * 2160 * 24;
+constexpr int kChainBlock = 512, kChainBlockLog2 = 9;
 struct BatchV0 { cvk_chain_job jobs[kJobsPerLaunchV0]; };
 struct JobC { void *out; const void *layer[kFusedLayers]; uint64_t npixels; };
 struct Batch { JobC jobs[kJobsPerLaunch]; };
 static_assert(sizeof(Batch) + 128 <= 4096, "kernel arguments must fit the 4 KiB segment");
 
-// ---------------------------------------------------------------- v0: first correct version (kept for A/B)
+// ---------------------------------------------------------------- v0: first correct version
+// Serves stacks of 5..8 layers, batches with mixed layer counts and frames too large for 32-bit chunk offsets.
 
 template <int MAXL, bool PRE, bool POST>
 __device__ __forceinline__ uint2 chain_pixel(const uint2 (&px)[MAXL], int nl, const MatR &mat, const uint16_t *lut, const uint16_t *post) {
@@ -89,35 +97,28 @@ __global__ __launch_bounds__(kWG) void k_chain_v0(BatchV0 batch, int njobs, Mat 
 // asm (invisible to both passes) and waited for by hand (cdna_hip_programming.md 5.7, form (ii)).
 //
 // One trip of one lane = one pixel pair:
-//     asm loads   nxt <- next trip            NL x global_load_dwordx4 ... nt   (indices clamped, never predicated)
+//     asm loads   nxt <- next chunk           NL x global_load_dwordx4 v, v_off, s[base] nt   (lane offsets clamped, never predicated)
 //     arithmetic  cur -> res                  chain_math.hpp
 //     s_waitcnt vmcnt(0) naming nxt           BEFORE this trip's store is issued
 //     store       res                         global_store_dwordx4 ... nt
 // Why the wait sits before the store: measured on gfx950, vmcnt(N) with N younger STORES outstanding
-// does not guarantee that older LOADS have landed (stores retire early; outputs were wrong until this
-// was changed).  At this point only the next trip's loads (needed now anyway) and the previous trip's
-// store (a whole trip old) are outstanding; the new store then drains under the next trip's arithmetic.
-//
+// does not guarantee that older LOADS have landed (outputs were wrong until this was changed).  At this point only
+// the next trip's loads (needed now anyway) and the previous trip's store (a whole trip old) are outstanding; the
+// new store then drains under the next trip's arithmetic.
 // The trip loop is unrolled by two with the register sets swapping roles, so no cur = nxt copies.
 
-template <bool NT>
-__device__ __forceinline__ void asm_ld4(u32x4 &dst, const void *base, size_t idx) {
-    const u32x4 *p = reinterpret_cast<const u32x4 *>(base) + idx;
-    if (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p));
-    else    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
+// address = 64-bit scalar base + 32-bit unsigned lane offset (the global saddr form): no vector address arithmetic
+__device__ __forceinline__ void asm_ld4s(u32x4 &dst, const void *sbase, uint32_t voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(dst) : "v"(voff), "s"(sbase));
 }
 
-template <int N, int P, int L>
-__device__ __forceinline__ void wait_vm(u32x4 (&r)[P][L]) {
-    static_assert(P * L <= 8 && P <= 2, "operand list below covers 2 x 4");
-    if constexpr (P * L == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r[0][0]) : "i"(N) : "memory");
-    else if constexpr (P == 1 && L == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0][0]), "+v"(r[0][1]) : "i"(N) : "memory");
-    else if constexpr (P == 1 && L == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]) : "i"(N) : "memory");
-    else if constexpr (P == 1 && L == 4) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[0][3]) : "i"(N) : "memory");
-    else if constexpr (P == 2 && L == 1) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0][0]), "+v"(r[1][0]) : "i"(N) : "memory");
-    else if constexpr (P == 2 && L == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[1][0]), "+v"(r[1][1]) : "i"(N) : "memory");
-    else if constexpr (P == 2 && L == 3) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[1][2]) : "i"(N) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[0][3]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[1][2]), "+v"(r[1][3]) : "i"(N) : "memory");
+template <int L>
+__device__ __forceinline__ void wait_vm0(u32x4 (&r)[L]) {
+    static_assert(L >= 1 && L <= 4, "operand lists below cover 1..4 layers");
+    if constexpr (L == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]) : : "memory");
+    else if constexpr (L == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]) : : "memory");
+    else if constexpr (L == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]) : : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : : "memory");
 }
 
 __device__ __forceinline__ void stage_lut_any(uint16_t *lds, const uint16_t *__restrict__ table) {
@@ -138,112 +139,140 @@ __device__ __forceinline__ void stage_lut_any(uint16_t *lds, const uint16_t *__r
     __syncthreads();
 }
 
+enum { DIAG_NONE = 0, DIAG_MEMORY_ONLY = 1, DIAG_COMPUTE_ONLY = 2 };     // != DIAG_NONE only exists in -DCVS_DIAG builds (tools/)
 
+// Position of a workgroup in the batch's run of chunks; every member is wave-uniform (SGPRs).
+struct Walk {
+    unsigned job;           // index into the batch, == njobs when past the end
+    unsigned chunk;         // chunk of that job
+    unsigned npairs;        // pixel pairs of that job
+    unsigned nchunks;       // ceil(npairs / L)
+};
 
-enum { DIAG_NONE = 0, DIAG_MEMORY_ONLY = 1, DIAG_COMPUTE_ONLY = 2 };
-
-// NL in 1..4, the same for every job of the batch; every job has npixels >= 2
-template <int NL, bool PRE, bool POST, int DIAG>
-__global__ __launch_bounds__(kWG) void k_chain(Batch batch, int njobs, Mat kmat,
+// NL in 1..4, the same for every job of the batch; every job has 2 <= npixels and npixels * 8 < 4 GiB;
+// blockDim.x == 1 << lshift
+template <int NL, int MODE, bool PRE, bool POST, int DIAG>
+__global__ __launch_bounds__(kWG) void k_chain(Batch batch, int njobs_, Mat kmat, int lshift,
                                                const uint16_t *__restrict__ pre, const uint16_t *__restrict__ post) {
     const MatR mat = CVS_MAT_REGS(kmat);
     __shared__ uint16_t lut[(PRE || POST) ? kLutHalfs : 1];
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t lane = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned L = 1u << lshift, G = gridDim.x, tid = threadIdx.x, njobs = (unsigned)njobs_;
 
-    u32x4 A[1][NL], B[1][NL];
-    u32x4 diag_acc = { 0, 0, 0, 0 };
-    {
-        // the first trip of the first frame goes out before the table is staged
-        const JobC &job = batch.jobs[0];
-        const size_t last = job.npixels / 2 - 1;
-        const size_t idx = lane < last ? lane : last;
+    auto load_job = [&](Walk &w) {
+        w.npairs = (unsigned)(batch.jobs[w.job].npixels >> 1);
+        w.nchunks = (w.npairs + L - 1) >> lshift;
+    };
+    // move `w` forward by `by` chunks, crossing into later frames as needed
+    auto advance = [&](Walk &w, unsigned by) {
+        w.chunk += by;
+        while (w.chunk >= w.nchunks) {
+            w.chunk -= w.nchunks;
+            if (++w.job >= njobs) { w.job = njobs; w.chunk = 0; return; }
+            load_job(w);
+        }
+    };
+    // lanes past the end of a frame's last chunk read its last pair again (clamped, never predicated) and do not store
+    auto valid_of = [&](const Walk &w) -> unsigned { const unsigned left = w.npairs - (w.chunk << lshift); return left < L ? left : L; };
+    auto issue = [&](u32x4 (&dst)[NL], const Walk &w) {
+        const unsigned valid = valid_of(w);
+        const uint32_t voff = (tid < valid ? tid : valid - 1) << 4;
+        const JobC &job = batch.jobs[w.job];
 #pragma unroll
-        for (int k = 0; k < NL; k++) asm_ld4<true>(A[0][k], job.layer[k], idx);
-    }
+        for (int k = 0; k < NL; k++)
+            asm_ld4s(dst[k], reinterpret_cast<const char *>(job.layer[k]) + ((size_t)w.chunk << (lshift + 4)), voff);
+    };
+
+    Walk cur = { 0, 0, 0, 0 };
+    load_job(cur);
+    advance(cur, blockIdx.x);
+    if (cur.job >= njobs) return;               // fewer chunks in the whole batch than workgroups (uniform: no barrier is left behind)
+
+    u32x4 A[NL], B[NL];
+    u32x4 diag_acc = { 0, 0, 0, 0 };
+    issue(A, cur);                              // the first trip goes out before the table is staged
     if (PRE) stage_lut_any(lut, pre);
     else if (POST) stage_lut_any(lut, post);
-    wait_vm<0>(A);
+    wait_vm0(A);
 
-    for (int j = 0; j < njobs; j++) {
-        const JobC &job = batch.jobs[j];
-        const size_t npairs = job.npixels / 2;
-        const bool more_jobs = j + 1 < njobs;
-        const JobC &njob = batch.jobs[more_jobs ? j + 1 : j];
-        const size_t nnpairs = njob.npixels / 2;
-        // frame base pointers as wave-uniform values (scalar loads): the per-lane choice in the prefetch
-        // is then a register select, not a vector load of the job record
-        const void *lp[NL], *nlp[NL];
+    // one trip: prefetch the next chunk into `nxt`, run the arithmetic on `now`, store; returns false after the last chunk
+    auto trip = [&](u32x4 (&now)[NL], u32x4 (&nxt)[NL]) -> bool {
+        Walk next = cur;
+        advance(next, G);
+        const bool more = next.job < njobs;
+        if (DIAG == DIAG_COMPUTE_ONLY) {
 #pragma unroll
-        for (int k = 0; k < NL; k++) { lp[k] = job.layer[k]; nlp[k] = njob.layer[k]; }
-        void *const outp = job.out;
+            for (int k = 0; k < NL; k++) nxt[k] = now[k];
+        } else {
+            issue(nxt, more ? next : cur);      // after the last chunk: a harmless second read of it
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 res;
+        if (DIAG == DIAG_MEMORY_ONLY) {
+            res = now[0];
+#pragma unroll
+            for (int k = 1; k < NL; k++) res ^= now[k];
+        } else {
+            res = chain_pair_lean<NL, PRE, POST, MODE>(now, mat, lut, post);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vm0(nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        if (DIAG == DIAG_COMPUTE_ONLY) diag_acc ^= res;
+        else if (tid < valid_of(cur)) {
+            g_u4 out = (g_u4)(reinterpret_cast<char *>(batch.jobs[cur.job].out) + ((size_t)cur.chunk << (lshift + 4)));
+            __builtin_nontemporal_store(res, out + tid);
+        }
+        cur = next;
+        return more;
+    };
+    while (trip(A, B) && trip(B, A)) { }
+    if (DIAG == DIAG_COMPUTE_ONLY) ((g_u4)batch.jobs[0].out)[(size_t)blockIdx.x * L + tid] = diag_acc;
 
-        auto trip = [&](u32x4 (&cur)[1][NL], u32x4 (&nxt)[1][NL], size_t base) {
-            const size_t nbase = base + stride;
-            const bool same = nbase < npairs;          // next trip in this frame, else first trip of the next one
-            size_t idx = same ? nbase : lane;
-            const size_t last = (same ? npairs : nnpairs) - 1;
-            idx = idx < last ? idx : last;
-#pragma unroll
-            for (int k = 0; k < NL; k++) {
-                if (DIAG == DIAG_COMPUTE_ONLY) nxt[0][k] = cur[0][k];
-                else asm_ld4<true>(nxt[0][k], same ? lp[k] : nlp[k], idx);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            u32x4 res;
-            if (DIAG == DIAG_MEMORY_ONLY) {
-                res = cur[0][0];
-#pragma unroll
-                for (int k = 1; k < NL; k++) res ^= cur[0][k];
-            } else {
-                res = chain_pair_lean<NL, PRE, POST>(cur[0], mat, lut, post);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            wait_vm<0>(nxt);
-            __builtin_amdgcn_sched_barrier(0);
-            if (DIAG == DIAG_COMPUTE_ONLY) diag_acc ^= res;
-            else __builtin_nontemporal_store(res, (g_u4)outp + base);
-        };
-
-        size_t base = lane;
-        bool in_b = false;                              // which register set holds this lane's next input
-        while (base < npairs) {
-            trip(A, B, base);
-            base += stride;
-            if (!(base < npairs)) { in_b = true; break; }
-            trip(B, A, base);
-            base += stride;
-        }
-        if (in_b) {
-#pragma unroll
-            for (int k = 0; k < NL; k++) A[0][k] = B[0][k];
-        }
-        // a lane that had no trip in this frame starts the next frame cold
-        if (more_jobs && !(lane < npairs)) {
-            const size_t last = nnpairs - 1;
-            const size_t idx = lane < last ? lane : last;
-#pragma unroll
-            for (int k = 0; k < NL; k++) asm_ld4<true>(A[0][k], nlp[k], idx);
-            wait_vm<0>(A);
-        }
-        if (DIAG == DIAG_COMPUTE_ONLY && lane < npairs) ((g_u4)outp)[lane] = diag_acc;
-        // odd pixel count: the last pixel on its own (scalar form of the same arithmetic)
-        if ((job.npixels & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+    // odd pixel counts: the last pixel of such a frame on its own (scalar form of the same arithmetic)
+    if (blockIdx.x == 0 && tid == 0) {
+        MatR m1 = mat;
+        m1.plain = MODE == CHAIN_PLAIN; m1.cross = MODE == CHAIN_CROSS;
+        for (unsigned j = 0; j < njobs; j++) {
+            const JobC &job = batch.jobs[j];
+            if (!(job.npixels & 1)) continue;
             uint2 px[NL];
 #pragma unroll
             for (int k = 0; k < NL; k++) px[k] = ld2(job.layer[k], job.npixels - 1);
-            st2(job.out, job.npixels - 1, chain_pixel<NL, PRE, POST>(px, NL, mat, lut, post));
+            st2(job.out, job.npixels - 1, chain_pixel<NL, PRE, POST>(px, NL, m1, lut, post));
         }
     }
 }
 
-template <int NL, int DIAG>
-int launch(const Batch &jobs, int njobs, const Mat &mat, const uint16_t *pre, const uint16_t *post, unsigned grid, unsigned block, hipStream_t s) {
-    if (pre && post)  hipLaunchKernelGGL((k_chain<NL, true, true, DIAG>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, pre, post);
-    else if (pre)     hipLaunchKernelGGL((k_chain<NL, true, false, DIAG>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, pre, post);
-    else if (post)    hipLaunchKernelGGL((k_chain<NL, false, true, DIAG>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, pre, post);
-    else              hipLaunchKernelGGL((k_chain<NL, false, false, DIAG>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, pre, post);
+template <int NL, int MODE, int DIAG>
+int launch(const Batch &jobs, int njobs, const Mat &mat, const uint16_t *pre, const uint16_t *post, unsigned grid, unsigned block, int lshift, hipStream_t s) {
+    if constexpr (MODE != CHAIN_GRADE) {
+        hipLaunchKernelGGL((k_chain<NL, MODE, false, false, DIAG>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, lshift, pre, post);
+    } else {
+        if (pre && post)  hipLaunchKernelGGL((k_chain<NL, MODE, true, true, DIAG>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, lshift, pre, post);
+        else if (pre)     hipLaunchKernelGGL((k_chain<NL, MODE, true, false, DIAG>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, lshift, pre, post);
+        else if (post)    hipLaunchKernelGGL((k_chain<NL, MODE, false, true, DIAG>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, lshift, pre, post);
+        else              hipLaunchKernelGGL((k_chain<NL, MODE, false, false, DIAG>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, lshift, pre, post);
+    }
     return (int)hipGetLastError();
+}
+
+template <int DIAG>
+int launch_nl(int nl, const Batch &b, int n, const Mat &mat, const uint16_t *pre, const uint16_t *post, unsigned grid, unsigned block, int lshift, hipStream_t s) {
+    if (mat.cross) return launch<2, CHAIN_CROSS, DIAG>(b, n, mat, pre, post, grid, block, lshift, s);
+    if (mat.plain) {
+        switch (nl) {
+        case 1: return launch<1, CHAIN_PLAIN, DIAG>(b, n, mat, pre, post, grid, block, lshift, s);
+        case 2: return launch<2, CHAIN_PLAIN, DIAG>(b, n, mat, pre, post, grid, block, lshift, s);
+        case 3: return launch<3, CHAIN_PLAIN, DIAG>(b, n, mat, pre, post, grid, block, lshift, s);
+        default: return launch<4, CHAIN_PLAIN, DIAG>(b, n, mat, pre, post, grid, block, lshift, s);
+        }
+    }
+    switch (nl) {
+    case 1: return launch<1, CHAIN_GRADE, DIAG>(b, n, mat, pre, post, grid, block, lshift, s);
+    case 2: return launch<2, CHAIN_GRADE, DIAG>(b, n, mat, pre, post, grid, block, lshift, s);
+    case 3: return launch<3, CHAIN_GRADE, DIAG>(b, n, mat, pre, post, grid, block, lshift, s);
+    default: return launch<4, CHAIN_GRADE, DIAG>(b, n, mat, pre, post, grid, block, lshift, s);
+    }
 }
 
 template <int NL>
@@ -255,65 +284,61 @@ int launch_v0(const BatchV0 &jobs, int njobs, const Mat &mat, const uint16_t *pr
     return (int)hipGetLastError();
 }
 
-}  // namespace
+// What tools/ may turn (only a -DCVS_DIAG build reads them, once per call; the shipped library has no knobs on this path):
+//   CVS_CHAIN_VARIANT  1 = production kernel (default); 0 = the first version; 10 = memory traffic only, 12 = arithmetic
+//                      only (both produce WRONG pixels: timing only)
+//   CVS_CHAIN_BLOCK    lanes per workgroup: 256, 512 (default) or 1024
+//   CVS_CHAIN_LAUNCH_MB  bytes moved per launch before the batch is cut, in MiB (default kBytesPerLaunch)
+struct Tuning { int variant; unsigned block; int lshift; uint64_t bytes_per_launch; };
 
-// Development knobs, read per call (none of them changes results):
-//   CVS_CHAIN_VARIANT  unset/1 = production kernel; 0 = the simple first version (A/B reference);
-//                      10 = memory traffic only, 12 = arithmetic only (diagnostic builds, wrong output)
-//   CVS_CHAIN_BLOCK    lanes per workgroup (default 512 = 2 waves per SIMD; one workgroup per CU)
-static int chain_dispatch(const cvk_chain_job *jobs, int njobs, int uniform_layers, const Mat &mat,
-                          const uint16_t *pre, const uint16_t *post, int cus, void *stream);
-
-extern "C" int cvk_chain_color_over(const cvk_chain_job *jobs, int njobs, int uniform_layers, const float *m,
-                                    const uint16_t *pre, const uint16_t *post, int cus, void *stream) {
-    return chain_dispatch(jobs, njobs, uniform_layers, make_mat(m), pre, post, cus, stream);
+Tuning tuning() {
+    Tuning t = { 1, (unsigned)kChainBlock, kChainBlockLog2, kBytesPerLaunch };
+#ifdef CVS_DIAG
+    if (const char *e = getenv("CVS_CHAIN_VARIANT")) t.variant = atoi(e);
+    if (const char *e = getenv("CVS_CHAIN_BLOCK")) {
+        const int b = atoi(e);
+        if (b == 256) { t.block = 256; t.lshift = 8; } else if (b == 1024) { t.block = 1024; t.lshift = 10; }
+    }
+    if (const char *e = getenv("CVS_CHAIN_LAUNCH_MB")) { const long long mb = atoll(e); if (mb > 0) t.bytes_per_launch = (uint64_t)mb << 20; }
+#endif
+    return t;
 }
 
-// two-layer jobs, crossfaded: out = cross(layer[0], layer[1]) with weights wa, wb
-extern "C" int cvk_chain_cross(const cvk_chain_job *jobs, int njobs, float wa, float wb, int cus, void *stream) {
-    Mat mat = make_mat(NULL);
-    mat.cross = 1; mat.wa = wa; mat.wb = wb;
-    return chain_dispatch(jobs, njobs, 2, mat, NULL, NULL, cus, stream);
-}
-
-static int chain_dispatch(const cvk_chain_job *jobs, int njobs, int uniform_layers, const Mat &mat,
-                          const uint16_t *pre, const uint16_t *post, int cus, void *stream) {
+int chain_dispatch(const cvk_chain_job *jobs, int njobs, int uniform_layers, const Mat &mat,
+                   const uint16_t *pre, const uint16_t *post, int cus, void *stream) {
     const unsigned grid = (unsigned)(cus > 0 ? cus : 256);
     hipStream_t s = (hipStream_t)stream;
-    const char *env = getenv("CVS_CHAIN_VARIANT");
-    const int variant = env ? atoi(env) : 1;
-    const char *bl = getenv("CVS_CHAIN_BLOCK");
-    unsigned block = bl ? (unsigned)atoi(bl) : 512u;
-    if (block < 64 || block > (unsigned)kWG || (block & 63u)) block = 512u;
-    const bool fused_kernel = variant != 0 && uniform_layers >= 1 && uniform_layers <= kFusedLayers;
-    int per_launch = fused_kernel ? kJobsPerLaunch : kJobsPerLaunchV0;
-    if (const char *pl = getenv("CVS_CHAIN_JOBS_PER_LAUNCH")) { const int v = atoi(pl); if (v >= 1 && v < per_launch) per_launch = v; }
-    for (int first = 0; first < njobs; first += per_launch) {
-        const int n = njobs - first < per_launch ? njobs - first : per_launch;
-        int rc;
+    const Tuning t = tuning();
+    bool fused_kernel = t.variant != 0 && uniform_layers >= 1 && uniform_layers <= kFusedLayers;
+    for (int i = 0; fused_kernel && i < njobs; i++)             // chunk offsets are 32-bit
+        if (jobs[i].npixels < 2 || jobs[i].npixels * 8 >= (1ull << 32)) fused_kernel = false;
+    int first = 0;
+    while (first < njobs) {
+        int n = 0, rc;
         if (fused_kernel) {
             Batch b;
             memset(&b, 0, sizeof b);
-            for (int i = 0; i < n; i++) {
-                const cvk_chain_job &src = jobs[first + i];
-                b.jobs[i].out = src.out;
-                for (int k = 0; k < uniform_layers; k++) b.jobs[i].layer[k] = src.layer[k];
-                b.jobs[i].npixels = src.npixels;
+            uint64_t bytes = 0;
+            while (first + n < njobs && n < kJobsPerLaunch) {
+                const cvk_chain_job &src = jobs[first + n];
+                const uint64_t job_bytes = src.npixels * 8 * (uint64_t)(uniform_layers + 1);
+                if (n > 0 && bytes + job_bytes > t.bytes_per_launch) break;        // the next launch takes it
+                b.jobs[n].out = src.out;
+                for (int k = 0; k < uniform_layers; k++) b.jobs[n].layer[k] = src.layer[k];
+                b.jobs[n].npixels = src.npixels;
+                bytes += job_bytes;
+                n++;
             }
-#define CVK_DISPATCH(NLV)                                                                              \
-            (variant == 10 ? launch<NLV, DIAG_MEMORY_ONLY>(b, n, mat, pre, post, grid, block, s)          \
-             : variant == 12 ? launch<NLV, DIAG_COMPUTE_ONLY>(b, n, mat, pre, post, grid, block, s)       \
-                             : launch<NLV, DIAG_NONE>(b, n, mat, pre, post, grid, block, s))
-            switch (uniform_layers) {
-            case 1: rc = CVK_DISPATCH(1); break;
-            case 2: rc = CVK_DISPATCH(2); break;
-            case 3: rc = CVK_DISPATCH(3); break;
-            default: rc = CVK_DISPATCH(4); break;
-            }
-#undef CVK_DISPATCH
+#ifdef CVS_DIAG
+            if (t.variant == 10) rc = launch_nl<DIAG_MEMORY_ONLY>(uniform_layers, b, n, mat, pre, post, grid, t.block, t.lshift, s);
+            else if (t.variant == 12) rc = launch_nl<DIAG_COMPUTE_ONLY>(uniform_layers, b, n, mat, pre, post, grid, t.block, t.lshift, s);
+            else
+#endif
+            rc = launch_nl<DIAG_NONE>(uniform_layers, b, n, mat, pre, post, grid, t.block, t.lshift, s);
         } else {
             BatchV0 b;
             memset(&b, 0, sizeof b);
+            n = njobs - first < kJobsPerLaunchV0 ? njobs - first : kJobsPerLaunchV0;
             memcpy(b.jobs, jobs + first, sizeof(cvk_chain_job) * (size_t)n);
             switch (uniform_layers) {
             case 1: rc = launch_v0<1>(b, n, mat, pre, post, grid, s); break;
@@ -324,6 +349,21 @@ static int chain_dispatch(const cvk_chain_job *jobs, int njobs, int uniform_laye
             }
         }
         if (rc != 0) return rc;
+        first += n;
     }
     return 0;
+}
+
+}  // namespace
+
+extern "C" int cvk_chain_color_over(const cvk_chain_job *jobs, int njobs, int uniform_layers, const float *m,
+                                    const uint16_t *pre, const uint16_t *post, int cus, void *stream) {
+    return chain_dispatch(jobs, njobs, uniform_layers, make_mat(m), pre, post, cus, stream);
+}
+
+// two-layer jobs, crossfaded: out = cross(layer[0], layer[1]) with weights wa, wb
+extern "C" int cvk_chain_cross(const cvk_chain_job *jobs, int njobs, float wa, float wb, int cus, void *stream) {
+    Mat mat = make_mat(NULL);
+    mat.plain = 0; mat.cross = 1; mat.wa = wa; mat.wb = wb;
+    return chain_dispatch(jobs, njobs, 2, mat, NULL, NULL, cus, stream);
 }
