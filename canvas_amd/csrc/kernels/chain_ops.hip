@@ -141,12 +141,16 @@ __device__ __forceinline__ void stage_lut_any(uint16_t *lds, const uint16_t *__r
 
 enum { DIAG_NONE = 0, DIAG_MEMORY_ONLY = 1, DIAG_COMPUTE_ONLY = 2 };     // != DIAG_NONE only exists in -DCVS_DIAG builds (tools/)
 
-// Position of a workgroup in the batch's run of chunks; every member is wave-uniform (SGPRs).
+// Position of a workgroup in the batch's run of chunks; every member is wave-uniform (SGPRs).  The frame's pointers
+// ride along so that the argument segment is read once per frame crossed, not once per trip.
+template <int NL>
 struct Walk {
     unsigned job;           // index into the batch, == njobs when past the end
     unsigned chunk;         // chunk of that job
     unsigned npairs;        // pixel pairs of that job
     unsigned nchunks;       // ceil(npairs / L)
+    const char *layer[NL];
+    char *out;
 };
 
 // NL in 1..4, the same for every job of the batch; every job has 2 <= npixels and npixels * 8 < 4 GiB;
@@ -158,12 +162,16 @@ __global__ __launch_bounds__(kWG) void k_chain(Batch batch, int njobs_, Mat kmat
     __shared__ uint16_t lut[(PRE || POST) ? kLutHalfs : 1];
     const unsigned L = 1u << lshift, G = gridDim.x, tid = threadIdx.x, njobs = (unsigned)njobs_;
 
-    auto load_job = [&](Walk &w) {
-        w.npairs = (unsigned)(batch.jobs[w.job].npixels >> 1);
+    auto load_job = [&](Walk<NL> &w) {
+        const JobC &job = batch.jobs[w.job];
+        w.npairs = (unsigned)(job.npixels >> 1);
         w.nchunks = (w.npairs + L - 1) >> lshift;
+#pragma unroll
+        for (int k = 0; k < NL; k++) w.layer[k] = reinterpret_cast<const char *>(job.layer[k]);
+        w.out = reinterpret_cast<char *>(job.out);
     };
     // move `w` forward by `by` chunks, crossing into later frames as needed
-    auto advance = [&](Walk &w, unsigned by) {
+    auto advance = [&](Walk<NL> &w, unsigned by) {
         w.chunk += by;
         while (w.chunk >= w.nchunks) {
             w.chunk -= w.nchunks;
@@ -172,17 +180,16 @@ __global__ __launch_bounds__(kWG) void k_chain(Batch batch, int njobs_, Mat kmat
         }
     };
     // lanes past the end of a frame's last chunk read its last pair again (clamped, never predicated) and do not store
-    auto valid_of = [&](const Walk &w) -> unsigned { const unsigned left = w.npairs - (w.chunk << lshift); return left < L ? left : L; };
-    auto issue = [&](u32x4 (&dst)[NL], const Walk &w) {
+    auto valid_of = [&](const Walk<NL> &w) -> unsigned { const unsigned left = w.npairs - (w.chunk << lshift); return left < L ? left : L; };
+    auto issue = [&](u32x4 (&dst)[NL], const Walk<NL> &w) {
         const unsigned valid = valid_of(w);
         const uint32_t voff = (tid < valid ? tid : valid - 1) << 4;
-        const JobC &job = batch.jobs[w.job];
 #pragma unroll
-        for (int k = 0; k < NL; k++)
-            asm_ld4s(dst[k], reinterpret_cast<const char *>(job.layer[k]) + ((size_t)w.chunk << (lshift + 4)), voff);
+        for (int k = 0; k < NL; k++) asm_ld4s(dst[k], w.layer[k] + ((size_t)w.chunk << (lshift + 4)), voff);
     };
 
-    Walk cur = { 0, 0, 0, 0 };
+    Walk<NL> cur;
+    cur.job = 0; cur.chunk = 0;
     load_job(cur);
     advance(cur, blockIdx.x);
     if (cur.job >= njobs) return;               // fewer chunks in the whole batch than workgroups (uniform: no barrier is left behind)
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(kWG) void k_chain(Batch batch, int njobs_, Mat kmat
 
     // one trip: prefetch the next chunk into `nxt`, run the arithmetic on `now`, store; returns false after the last chunk
     auto trip = [&](u32x4 (&now)[NL], u32x4 (&nxt)[NL]) -> bool {
-        Walk next = cur;
+        Walk<NL> next = cur;
         advance(next, G);
         const bool more = next.job < njobs;
         if (DIAG == DIAG_COMPUTE_ONLY) {
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(kWG) void k_chain(Batch batch, int njobs_, Mat kmat
         __builtin_amdgcn_sched_barrier(0);
         if (DIAG == DIAG_COMPUTE_ONLY) diag_acc ^= res;
         else if (tid < valid_of(cur)) {
-            g_u4 out = (g_u4)(reinterpret_cast<char *>(batch.jobs[cur.job].out) + ((size_t)cur.chunk << (lshift + 4)));
+            g_u4 out = (g_u4)(cur.out + ((size_t)cur.chunk << (lshift + 4)));
             __builtin_nontemporal_store(res, out + tid);
         }
         cur = next;

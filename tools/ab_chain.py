@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 
 from canvas_amd import REC709_RGB_TO_YPBPR, _lib, synth  # noqa: E402
 from canvas_amd.device import DeviceFrame, chain_color_over  # noqa: E402
+from tools._diag import use_diag_library  # noqa: E402
 
 
 def main():
@@ -26,6 +27,7 @@ def main():
     ap.add_argument("--lut", default="rec709", help="rec709 | none")
     args = ap.parse_args()
     variants = [v for v in args.variants.split(",")]
+    use_diag_library()
     lib = _lib.load()
     _lib.check(lib.cvs_init(0))
     lib.init_half()
