@@ -193,6 +193,8 @@ __global__ __launch_bounds__(kWG) void k_chain(Batch batch, int njobs_, Mat kmat
     load_job(cur);
     advance(cur, blockIdx.x);
     if (cur.job >= njobs) return;               // fewer chunks in the whole batch than workgroups (uniform: no barrier is left behind)
+    Walk<NL> next = cur;                        // the chunk after `cur` (job == njobs: there is none)
+    advance(next, G);
 
     u32x4 A[NL], B[NL];
     u32x4 diag_acc = { 0, 0, 0, 0 };
@@ -200,19 +202,14 @@ __global__ __launch_bounds__(kWG) void k_chain(Batch batch, int njobs_, Mat kmat
     if (PRE) stage_lut_any(lut, pre);
     else if (POST) stage_lut_any(lut, post);
     wait_vm0(A);
+    if (next.job < njobs) issue(B, next);
 
-    // one trip: prefetch the next chunk into `nxt`, run the arithmetic on `now`, store; returns false after the last chunk
+    // One trip.  On entry `now` holds chunk `cur` and the loads of chunk `next` are in flight into `nxt`.
+    // The order inside matters: everything that does not need the loaded data -- the arithmetic on `now` and the walk
+    // to the chunk after next -- runs BEFORE the wait, so that between "the loads have landed" and "the following
+    // loads are issued" there is nothing but this trip's store.  (The first form of this kernel walked after the
+    // wait: some forty scalar instructions on the load -> issue -> load critical loop.)
     auto trip = [&](u32x4 (&now)[NL], u32x4 (&nxt)[NL]) -> bool {
-        Walk<NL> next = cur;
-        advance(next, G);
-        const bool more = next.job < njobs;
-        if (DIAG == DIAG_COMPUTE_ONLY) {
-#pragma unroll
-            for (int k = 0; k < NL; k++) nxt[k] = now[k];
-        } else {
-            issue(nxt, more ? next : cur);      // after the last chunk: a harmless second read of it
-        }
-        __builtin_amdgcn_sched_barrier(0);
         u32x4 res;
         if (DIAG == DIAG_MEMORY_ONLY) {
             res = now[0];
@@ -221,16 +218,27 @@ __global__ __launch_bounds__(kWG) void k_chain(Batch batch, int njobs_, Mat kmat
         } else {
             res = chain_pair_lean<NL, PRE, POST, MODE>(now, mat, lut, post);
         }
+        Walk<NL> after = next;
+        if (after.job < njobs) advance(after, G);
+        const bool store_it = tid < valid_of(cur);
+        g_u4 out = (g_u4)(cur.out + ((size_t)cur.chunk << (lshift + 4)));
         __builtin_amdgcn_sched_barrier(0);
         wait_vm0(nxt);
         __builtin_amdgcn_sched_barrier(0);
         if (DIAG == DIAG_COMPUTE_ONLY) diag_acc ^= res;
-        else if (tid < valid_of(cur)) {
-            g_u4 out = (g_u4)(cur.out + ((size_t)cur.chunk << (lshift + 4)));
-            __builtin_nontemporal_store(res, out + tid);
+        else if (store_it) __builtin_nontemporal_store(res, out + tid);
+        if (after.job < njobs) {
+            if (DIAG == DIAG_COMPUTE_ONLY) {
+#pragma unroll
+                for (int k = 0; k < NL; k++) now[k] = nxt[k];
+            } else {
+                issue(now, after);              // into the registers this trip has just consumed
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
         cur = next;
-        return more;
+        next = after;
+        return cur.job < njobs;
     };
     while (trip(A, B) && trip(B, A)) { }
     if (DIAG == DIAG_COMPUTE_ONLY) ((g_u4)batch.jobs[0].out)[(size_t)blockIdx.x * L + tid] = diag_acc;

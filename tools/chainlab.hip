@@ -19,7 +19,7 @@ constexpr int kJobs = 64;
 struct Job { void *out; const void *in[2]; uint64_t npairs; };
 struct Batch { Job j[kJobs]; };
 
-enum { F_ASM = 1, F_PIPE = 2, F_LUT = 4, F_IDX64 = 8, F_CLAMP = 16, F_CHUNK = 32, F_GATHER = 64, F_RESYNC = 128 };
+enum { F_ASM = 1, F_PIPE = 2, F_LUT = 4, F_IDX64 = 8, F_CLAMP = 16, F_CHUNK = 32, F_GATHER = 64, F_RESYNC = 128, F_TICKET = 256, F_TICKET8 = 512, F_ROT = 1024 };
 
 // timing-only rendezvous of the (co-resident) workgroups: no data is handed over, so no fences; bounded spin
 __device__ __forceinline__ void resync(unsigned *ctr, unsigned target) {
@@ -65,12 +65,53 @@ template <int F>
 __global__ __launch_bounds__(1024) void k_lab(Batch batch, int njobs, const uint16_t *table, unsigned *ctr, int every) {
     __shared__ uint16_t lds[(F & (F_LUT | F_GATHER)) ? 65536 : 1];
     if (F & (F_LUT | F_GATHER)) stage(lds, table);
+    if (F & (F_TICKET | F_TICKET8)) {
+        // dynamic chunk assignment: chunk ids come from a device-wide counter (F_TICKET) or from one of eight counters
+        // chosen by blockIdx % 8, the chunk being ticket * 8 + blockIdx % 8 (F_TICKET8); wave 0 draws the ticket two
+        // trips ahead, hands it to the other waves through LDS, one barrier per trip.  All frames equal here.
+        __shared__ unsigned slot[4];
+        const unsigned L = blockDim.x, per_frame = (unsigned)(batch.j[0].npairs / L), total = per_frame * (unsigned)njobs;
+        unsigned *my = (F & F_TICKET8) ? ctr + 32 * (blockIdx.x & 7) : ctr;
+        auto draw = [&]() -> unsigned {
+            unsigned t = 0;
+            if (threadIdx.x == 0) t = __hip_atomic_fetch_add(my, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return t;
+        };
+        auto chunk_of = [&](unsigned t) -> unsigned { return (F & F_TICKET8) ? t * 8 + (blockIdx.x & 7) : t; };
+        unsigned t0 = draw(), t1 = draw();
+        if (threadIdx.x == 0) { slot[0] = chunk_of(t0); slot[1] = chunk_of(t1); }
+        __syncthreads();
+        unsigned c = slot[0], n = 0;
+        u32x4 a0, a1;
+        if (c < total) { const unsigned j = c / per_frame, i = c - j * per_frame; asm_ld(a0, batch.j[j].in[0], (size_t)i * L + threadIdx.x); asm_ld(a1, batch.j[j].in[1], (size_t)i * L + threadIdx.x); }
+        while (c < total) {
+            const unsigned nc = slot[(n + 1) & 3];
+            const unsigned t2 = draw();                                  // for trip n + 2
+            const unsigned pc = nc < total ? nc : c;
+            const unsigned pj = pc / per_frame, pi = pc - pj * per_frame;
+            u32x4 b0, b1;
+            asm_ld(b0, batch.j[pj].in[0], (size_t)pi * L + threadIdx.x);
+            asm_ld(b1, batch.j[pj].in[1], (size_t)pi * L + threadIdx.x);
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 r = combine<F>(a0, a1, lds);
+            __builtin_amdgcn_sched_barrier(0);
+            wait2(b0, b1);
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned j = c / per_frame, i = c - j * per_frame;
+            __builtin_nontemporal_store(r, (g_u4)batch.j[j].out + (size_t)i * L + threadIdx.x);
+            if (threadIdx.x == 0) slot[(n + 2) & 3] = chunk_of(t2);
+            __syncthreads();
+            a0 = b0; a1 = b1; c = nc; n++;
+        }
+        return;
+    }
     if (F & F_CHUNK) {
         // workgroup-uniform chunk walk over the whole batch: chunk c = blockDim.x pairs; frames hold whole chunks
         const unsigned L = blockDim.x, G = gridDim.x, nj_all = (unsigned)njobs;
         unsigned j = 0, c = blockIdx.x, nch = (unsigned)(batch.j[0].npairs / L);
         while (j < nj_all && c >= nch) { c -= nch; j++; nch = j < nj_all ? (unsigned)(batch.j[j].npairs / L) : 1; }
         if (j >= nj_all) return;
+        unsigned off = blockIdx.x;                 // F_ROT: position inside the stripe of G chunks, rotated by `every` per trip
         // frame pointers live in registers (wave-uniform) and are re-read from the argument segment only when the
         // walk crosses into another frame
         const void *ci0 = batch.j[j].in[0], *ci1 = batch.j[j].in[1];
@@ -78,7 +119,10 @@ __global__ __launch_bounds__(1024) void k_lab(Batch batch, int njobs, const uint
         u32x4 a0, a1;
         asm_ld(a0, ci0, (size_t)c * L + threadIdx.x); asm_ld(a1, ci1, (size_t)c * L + threadIdx.x);
         for (;;) {
-            unsigned nj = j, nc = c + G, nnch = nch;
+            unsigned noff = off;
+            if (F & F_ROT) { noff = off + (unsigned)every; if (noff >= G) noff -= G; }
+            unsigned nj = j, nc = c + G + noff - off, nnch = nch;
+            off = noff;
             const void *ni0 = ci0, *ni1 = ci1;
             void *no = co;
             if (nc >= nnch) {
@@ -148,14 +192,14 @@ struct Variant { const char *name; int flags; int lanes; int split; };   // spli
 static unsigned *g_ctr; static int g_every = 8;
 template <int F>
 static void go(const Batch &b, int njobs, const uint16_t *table, int lanes, hipStream_t s) {
-    if (F & F_RESYNC) CK(hipMemsetAsync(g_ctr, 0, 4, s));
+    if (F & (F_RESYNC | F_TICKET | F_TICKET8)) CK(hipMemsetAsync(g_ctr, 0, 1024, s));
     hipLaunchKernelGGL(k_lab<F>, dim3(256), dim3(lanes), 0, s, b, njobs, table, g_ctr, g_every);
 }
 
 static void launch(int f, const Batch &b, int njobs, const uint16_t *table, int lanes, hipStream_t s) {
     switch (f) {
 #define C(X) case X: go<X>(b, njobs, table, lanes, s); break;
-    C(F_RESYNC) C(F_RESYNC | F_LUT) C(0) C(F_ASM) C(F_IDX64) C(F_IDX64 | F_ASM) C(F_IDX64 | F_ASM | F_PIPE) C(F_LUT) C(F_LUT | F_IDX64 | F_ASM | F_PIPE)
+    C(F_CHUNK | F_ROT) C(F_TICKET) C(F_TICKET8) C(F_TICKET | F_LUT | F_GATHER) C(F_TICKET8 | F_LUT | F_GATHER) C(F_RESYNC) C(F_RESYNC | F_LUT) C(0) C(F_ASM) C(F_IDX64) C(F_IDX64 | F_ASM) C(F_IDX64 | F_ASM | F_PIPE) C(F_LUT) C(F_LUT | F_IDX64 | F_ASM | F_PIPE)
     C(F_CHUNK) C(F_CHUNK | F_LUT) C(F_CHUNK | F_LUT | F_GATHER) C(F_LUT | F_GATHER | F_IDX64 | F_ASM | F_PIPE) C(F_LUT | F_GATHER)
 #undef C
     default: printf("no instance for flags %d\n", f); exit(1);
@@ -179,7 +223,7 @@ int main(int argc, char **argv) {
         b.j[j].out = arena + slot * (3 * g + 2);
         b.j[j].npairs = pairs;
     }
-    CK(hipMalloc((void **)&g_ctr, 4));
+    CK(hipMalloc((void **)&g_ctr, 1024));
     hipStream_t s;
     CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     hipEvent_t e0, e1;
@@ -198,6 +242,14 @@ int main(int argc, char **argv) {
         { "pipelined + table (prod. mem-only), 1 launch 512", F_LUT | F_IDX64 | F_ASM | F_PIPE, 512, 0 },
         { "pipelined + table, launches of 8 frames      512", F_LUT | F_IDX64 | F_ASM | F_PIPE, 512, 8 },
         { "chunk walk, one launch                       512", F_CHUNK, 512, 0 },
+        { "chunk walk, launches of 8 frames             512", F_CHUNK, 512, 8 },
+        { "chunk walk rotated by 1 per trip, one launch 512", F_CHUNK | F_ROT, 512, -1 },
+        { "chunk walk rotated by 8 per trip, one launch 512", F_CHUNK | F_ROT, 512, -8 },
+        { "chunk walk rotated by 37 per trip, 1 launch  512", F_CHUNK | F_ROT, 512, -37 },
+        { "chunk walk rotated by 101 per trip, 1 launch 512", F_CHUNK | F_ROT, 512, -101 },
+        { "chunk walk rotated by 128 per trip, 1 launch 512", F_CHUNK | F_ROT, 512, -128 },
+        { "tickets (8 counters), one launch             512", F_TICKET8, 512, 0 },
+        { "chunk walk + table + gathers, launches of 8  512", F_CHUNK | F_LUT | F_GATHER, 512, 8 },
     };
     const int nv = (int)(sizeof vs / sizeof vs[0]);
     std::vector<std::vector<float>> t(nv);
