@@ -4,18 +4,27 @@ each of 2 layers, 2-layer alpha-over, f16 out; frames resident in HBM; Mpixels/s
 
   python bench.py --gpus N --steps K --warmup W
 
-One process per GPU (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE).  Frames shard
-round-robin: global frame g belongs to rank g % N; no collective on the frame path.  RCCL carries
-only the parameter block (matrix + 128 KiB LUT) once at start and the timings at the end.
+One process per GPU.  Under `torch.distributed.run` the ranks are the launcher's (RANK / LOCAL_RANK / WORLD_SIZE);
+started plainly with --gpus N > 1, this script starts its N ranks itself (canvas_amd/launch.py) before anything touches
+the GPU.  Frames shard round-robin: global frame g belongs to rank g % N; no collective on the frame path.  RCCL
+carries the parameter block (matrix + 128 KiB LUT) once at start and one all-gather of per-rank
+{frames, checksum, seconds, verified, launch ms} at the end.
 
-A "step" = one batch of --batch frames per GPU through the fused chain kernel (one launch).
-The input ring (--ring frame sets, default 8 x 199 MB = 1.6 GB) is several times the 256 MiB Infinity
-Cache, so every launch streams from HBM (a 64-frame step walks the ring eight times).
+A "step" = one batch of --batch frames per GPU through the fused chain kernel (ONE call of the C-ABI entry
+cvs_chain_color_over_f16_dev; the library cuts it into launches of about eight frames).
+The input ring (--ring frame sets, default 8 x 199 MB = 1.6 GB) is several times the 256 MiB Infinity Cache, so every
+launch streams from HBM (a 64-frame step walks the ring eight times).
+
+Every rank proves its pixels: the output of its first frame (global frame = rank) is downloaded whole and its SHA-256
+compared with the committed fixture tests/golden/stream_frames_sha256.json (made by the oracle in the build container);
+the JSON line carries `ranks_verified`.  After the timed config-2 region the other BASELINE configs (3, 4, 5) run briefly
+on every rank, each over more than 1.5 GB of rotating frames, and appear as `extra` sub-records.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,20 +43,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU (one kernel launch; 64 = the most job records one launch carries)")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU (one C-ABI call)")
     ap.add_argument("--ring", type=int, default=8, help="distinct frame sets resident per GPU")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--layers", type=int, default=2)
     ap.add_argument("--translucent-base", action="store_true",
                     help="NOT the BASELINE input: random alpha on layer 0 as well, so every divide of the over operator is live")
-    ap.add_argument("--no-arena", action="store_true", help="one hipMalloc per frame instead of one arena for the ring")
-    ap.add_argument("--slot-pad", type=int, default=0, help="extra bytes between consecutive frames of the arena (placement experiment; multiple of 256)")
-    ap.add_argument("--pre-alloc-mb", type=int, default=0, help="allocate (and keep) this much device memory before the ring (placement experiment)")
-    ap.add_argument("--arena-align-mb", type=int, default=0, help="round the ring's base address up to this many MiB (placement experiment)")
-    ap.add_argument("--report-base", action="store_true", help="print the ring's base address on stderr (placement experiment)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-extra", action="store_true", help="skip the config 3 / 4 / 5 sub-records")
+    ap.add_argument("--extra-seconds", type=float, default=0.25, help="timed region of each extra config, per rank")
     return ap.parse_args()
 
 
@@ -114,13 +120,44 @@ def cpu_baseline(args, seconds):
         "value": round(single, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
         "sample": "%d x (%dx%d, %d layers) in %.1f s, 1 thread, %s" % (n, w, h, nl, dt1, flags),
         "all_cores": {"value": round(total * w * h / dtn / 1e6, 2), "cores": cores,
-                      "sample": "%d frames in %.1f s, %d threads on independent frames" % (total, dtn, cores)},
+                      "sample": "%d frames in %.1f s, %d threads on independent frames" % (total, dtn, cores),
+                      "note": "scales poorly by construction: like the reference (main.c:43-71, color.c:122) the port allocates and "
+                              "frees full-frame f32 temporaries on every pull, so the threads contend in the allocator and on page faults"},
         "cpu": cpu,
     }
 
 
+class Timed:
+    """HIP events around every step of a region, on the stream the work is launched on."""
+
+    def __init__(self, lib, stream):
+        self.lib, self.stream, self.ev = lib, stream, []
+
+    def step(self, fn):
+        a, b = self.lib.cvs_event_create(), self.lib.cvs_event_create()
+        self.lib.cvs_event_record(a, self.stream)
+        fn()
+        self.lib.cvs_event_record(b, self.stream)
+        self.ev.append((a, b))
+
+    def ms(self):
+        out = [self.lib.cvs_event_elapsed_ms(a, b) for a, b in self.ev]
+        for a, b in self.ev:
+            self.lib.cvs_event_destroy(a), self.lib.cvs_event_destroy(b)
+        self.ev = []
+        return out
+
+
+def spread(ms):
+    return {"mean": round(float(np.mean(ms)), 4), "median": round(float(statistics.median(ms)), 4),
+            "min": round(float(min(ms)), 4), "max": round(float(max(ms)), 4), "n": len(ms)}
+
+
 def main():
     args = parse()
+    from canvas_amd import launch
+    launch.ensure_ranks(args.gpus)          # --gpus N without a launcher: become N ranks (never returns in the parent)
+
     # stdout carries exactly ONE line, the JSON result: libraries that write banners there (RCCL prints its version,
     # host name and library path on communicator creation) are sent to stderr until the result is ready
     sys.stdout.flush()
@@ -143,9 +180,9 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from canvas_amd import REC709_RGB_TO_YPBPR, _lib, synth
+    from canvas_amd import REC709_RGB_TO_YPBPR, _lib, synth, verify
     from canvas_amd.device import DeviceFrame, chain_color_over
-    from canvas_amd.shard import broadcast_parameters, frames_of_rank
+    from canvas_amd.shard import broadcast_parameters, checksum52, frames_of_rank, gather_stats
 
     lib = _lib.load()
     _lib.check(lib.cvs_init(local_rank), "cvs_init(%d)" % local_rank)
@@ -162,20 +199,15 @@ def main():
     # weak scaling: every rank owns --ring frame sets whatever the world size (frames_of_rank counts per rank);
     # global frame g lives on rank g % world
     my_frames = frames_of_rank(rank, world, args.ring)
-    # one arena for the whole ring: a single large allocation maps with far fewer page-table entries than
-    # dozens of 66 MB ones, and the TLB reach of the chip is what a multi-GB streaming working set leans on
+    # one arena for the whole ring: consecutive 64 MiB-aligned slots
     frame_bytes = w * h * 8
-    slot = (frame_bytes + (2 << 20) - 1) // (2 << 20) * (2 << 20) + args.slot_pad
-    dummy = lib.cvs_malloc(args.pre_alloc_mb << 20) if args.pre_alloc_mb else None      # noqa: F841 -- kept alive on purpose
-    align = args.arena_align_mb << 20
-    arena = None if args.no_arena else lib.cvs_malloc(slot * (nl + 1) * len(my_frames) + align)
-    at = [arena if not align or arena is None else (arena + align - 1) // align * align]
-    if rank == 0 and (args.pre_alloc_mb or align or args.report_base):
-        print("ring base %#x (arena %#x)" % (at[0], arena), file=sys.stderr)
+    slot = (frame_bytes + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+    arena = lib.cvs_malloc(slot * (nl + 1) * len(my_frames))
+    if not arena:
+        raise MemoryError("ring arena: " + _lib.last_error())
+    at = [arena]
 
     def place():
-        if arena is None:
-            return DeviceFrame(full, np.uint16)
         d = DeviceFrame(full, np.uint16, ptr=at[0])
         at[0] += slot
         return d
@@ -204,71 +236,59 @@ def main():
     barrier()
     assert lib.cvs_chain_last_was_fused() == 1, "the fused kernel did not run"
 
-    ev = [(lib.cvs_event_create(), lib.cvs_event_create()) for _ in range(args.steps)]
+    timed = Timed(lib, stream)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        lib.cvs_event_record(ev[i][0], stream)
-        step(args.warmup + i)
-        lib.cvs_event_record(ev[i][1], stream)
+        timed.step(lambda: step(args.warmup + i))
     barrier()
     elapsed = time.perf_counter() - t0
+    step_ms = timed.ms()
 
-    launch_ms = [lib.cvs_event_elapsed_ms(a, b) for a, b in ev]
-    for a, b in ev:
-        lib.cvs_event_destroy(a), lib.cvs_event_destroy(b)
+    # ---- every rank proves its pixels: whole first frame, SHA-256 against the committed fixture
+    standard = (w, h, nl) == (3840, 2160, 2) and not args.translucent_base
+    digest = verify.canon_sha256(ring[0][0].download(stream).array)
+    want = verify.stream_fixture("config2_3840x2160", my_frames[0]) if standard else None
+    verified = -1 if want is None else int(digest == want)            # -1: no fixture for this shape / frame
 
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    px_per_step = args.batch * w * h
+    algo_bytes = px_per_step * BYTES_PER_PIXEL_PER_LAYER * (nl + 1)
+    my_frac = algo_bytes / (float(np.mean(step_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS
+    stats = gather_stats(dist, args.steps * args.batch, checksum52(digest), elapsed, extra=(verified, float(np.mean(step_ms)), my_frac))
+    elapsed = max(s[2] for s in stats)                                  # the slowest rank's clock
 
-    # guard: the head of one output frame against the oracle
-    verified = None
-    if rank == 0:
-        try:
-            import oracle
-            rows = 4
-            from canvas_amd.abi import HostFrame
-            heads = [HostFrame((0, 0, w - 1, rows - 1), np.uint16, synth.layer_pixels(w, h, k, my_frames[0], opaque_base=not args.translucent_base)[:rows]) for k in range(nl)]
-            want = oracle.chain_color_over(heads, m, oracle.transfer_table(0), None)
-            got = ring[0][0].download(stream).array[:rows]
-            verified = bool(np.array_equal(got, want.array))
-        except Exception as e:                                  # the oracle is only a checker here
-            verified = "unchecked: %s" % e
-
-    # same-run yardstick for this box: plain device-to-device copies of the same frames (SURVEY 8d asks for one beside
-    # the roofline figure; boxes of the pool differ by several per cent)
+    # same-run yardstick for this box: plain device-to-device copies of the same frames
     copy_gbs = None
     if rank == 0:
         try:
             e0, e1 = lib.cvs_event_create(), lib.cvs_event_create()
-            nbytes = w * h * 8
             pairs = [(ring[i % len(ring)][0], ring[(i + 1) % len(ring)][1][0]) for i in range(32)]
             for rep in range(2):
                 lib.cvs_event_record(e0, stream)
                 for dst, src in pairs:
-                    lib.cvs_memcpy_d2d(dst.ptr, src.ptr, nbytes, stream)
+                    lib.cvs_memcpy_d2d(dst.ptr, src.ptr, frame_bytes, stream)
                 lib.cvs_event_record(e1, stream)
                 _lib.check(lib.cvs_stream_sync(stream), "sync")
-            copy_gbs = round(2 * nbytes * len(pairs) / (lib.cvs_event_elapsed_ms(e0, e1) * 1e-3) / 1e9, 1)
+            copy_gbs = round(2 * frame_bytes * len(pairs) / (lib.cvs_event_elapsed_ms(e0, e1) * 1e-3) / 1e9, 1)
             lib.cvs_event_destroy(e0), lib.cvs_event_destroy(e1)
         except Exception:                                       # a yardstick, not a result
             copy_gbs = None
 
+    extra = []
+    if not args.no_extra and standard:
+        from bench_extra import run_extras
+        extra = run_extras(lib, dist, rank, world, stream, ring, my_frames, m, args.extra_seconds)
+
     if rank == 0:
-        px_per_step = args.batch * w * h
         total_px = px_per_step * args.steps * world
-        avg_ms = float(np.mean(launch_ms))
-        algo_bytes = px_per_step * BYTES_PER_PIXEL_PER_LAYER * (nl + 1)
+        avg_ms = float(np.mean(step_ms))
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
-                # PMC-measured HBM bytes per output pixel of k_chain (FETCH_SIZE x2-corrected + WRITE_SIZE, separate
-                # rocprofv3 --pmc passes, tools/profile_bench.sh), scaled to this run's pixels per launch
-                traffic = round(json.load(open(tpath))["k_chain_bytes_per_output_pixel"] * px_per_step)
+                tj = json.load(open(tpath))
+                traffic = round(tj["k_chain_bytes_per_output_pixel"] * px_per_step)
+                traffic_src = "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on a builder-side run, scaled to this run's pixels per step); NOT measured in this run" % tj.get("source", "profiles/hbm_traffic.json")
             except Exception:
                 traffic = None
         res = {
@@ -290,14 +310,24 @@ def main():
                        "frames_per_step_per_gpu": args.batch, "ring_frames_per_gpu": len(ring),
                        "sharding": "frame g -> gpu g %% %d, no data-path collective" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_chain<%d,pre-LUT>" % nl, "avg_launch_ms": round(avg_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_chain<%d layers, grade, pre-LUT>" % nl, "avg_launch_ms": round(avg_ms, 4),
+                         "step_ms": spread(step_ms),
                          "same_run_dtod_copy_GBps": copy_gbs,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "achieved = %d B/px x %d px per launch / HIP-event launch time" % (BYTES_PER_PIXEL_PER_LAYER * (nl + 1), px_per_step)},
-            "verified_against_oracle": verified,
+                         "note": "one step = one C-ABI call over %d frames, which the library issues as back-to-back launches of ~8 frames; "
+                                 "achieved = %d B/px x %d px per step / HIP-event step time on the launch stream (rank 0)" % (
+                                     args.batch, BYTES_PER_PIXEL_PER_LAYER * (nl + 1), px_per_step)},
+            "frames_per_rank": [s[0] for s in stats],
+            "ranks_verified": sum(1 for s in stats if int(s[3]) == 1),
+            "per_rank": [{"rank": r, "first_frame": r, "sha256_52bit": "%013x" % s[1],
+                          "verified": {1: True, 0: False}.get(int(s[3]), "no fixture"),
+                          "seconds": round(s[2], 4), "step_ms_mean": round(s[4], 4), "frac": round(s[5], 4)} for r, s in enumerate(stats)],
+            "verified_against_fixture": all(int(s[3]) == 1 for s in stats) if standard else "no fixture for this shape",
             "device": lib.cvs_device_name().decode(),
         }
+        if extra:
+            res["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
@@ -313,6 +343,10 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    bad = [r for r, s in enumerate(stats) if int(s[3]) == 0]
+    if bad:
+        sys.stderr.write("ranks %s rendered pixels that do not match the fixture\n" % bad)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

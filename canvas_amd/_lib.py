@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libcanvas_hip.so")
 
 CHAIN_MAX_LAYERS = 8
 DISPLAY_RGBA8, DISPLAY_ARGB32_PREMUL = 0, 1
+FIR_PATH_AUTO, FIR_PATH_SWEEP, FIR_PATH_TILED, FIR_PATH_TABLES = 0, 1, 2, 4
 LUT_NONE, LUT_REC709_TO_LINEAR_SCENE, LUT_REC709_TO_LINEAR_DISPLAY, LUT_LINEAR_TO_REC709, LUT_LINEAR_TO_SRGB = -1, 0, 1, 2, 3
 
 
@@ -155,6 +156,7 @@ SIGNATURES = {
     "cvs_blur_over_f16_dev": (C.c_int, [_F16, _F16, _f32p, C.c_int, P(_F16), C.c_int, _vp]),
     "cvs_resample_lanczos_f32_dev": (C.c_int, [_F32, _F32, C.c_float, C.c_float, C.c_int, _vp]),
     "cvs_blur_lanczos_f16_dev": (C.c_int, [_F16, _F16, _f32p, C.c_int, C.c_float, C.c_float, C.c_int, _vp]),
+    "cvs_fir_path_override": (None, [C.c_int]),
     # (3) fused chain
     "cvs_chain_color_over_f16_dev": (C.c_int, [P(chain_job), C.c_int, _f32p, C.c_int, C.c_int, _vp]),
     "cvs_chain_last_was_fused": (C.c_int, []),

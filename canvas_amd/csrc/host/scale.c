@@ -19,6 +19,10 @@
 #include "internal.h"
 #include <limits.h>
 #include <math.h>
+#include <stdatomic.h>
+
+static _Atomic int g_fir_path = CVS_FIR_PATH_AUTO;
+CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES)); }
 
 typedef struct {
     int t0, t1;            /* target lines covered by the table */
@@ -546,11 +550,11 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
      * 32 x 16 target pixels); such table pairs are swept down the frame instead (resample_ops.hip; 4K -> 1536x864: 0.22 ->
      * 0.08 ms) when the vertical table allows it (consecutive, non-decreasing tap lists) and the lists fit its registers.
      * Small footprints (enlargements, blurs) stay with the tiles, which are as fast or faster there.
-     * CVS_FIR_TILED=1 / CVS_FIR_STREAM=1 force one or the other (A/B runs and tests). */
-    const char *force_stream = getenv("CVS_FIR_STREAM");
+     * cvs_fir_path_override() pins one or the other (parity tests of each kernel, A/B runs). */
+    const int force = atomic_load(&g_fir_path);
     const bool can_stream = v->streamable && h->max_taps >= 1 && v->max_active >= 1 && cvk_fir_stream_supported(h->max_taps, v->max_active);
-    const bool want_stream = force_stream ? atoi(force_stream) != 0 : cvk_fir2d_lds_bytes(&fp) > 64 * 1024;
-    if (can_stream && want_stream && !getenv("CVS_FIR_TILED")) {
+    const bool want_stream = (force & CVS_FIR_PATH_SWEEP) ? true : cvk_fir2d_lds_bytes(&fp) > 64 * 1024;
+    if (can_stream && want_stream && !(force & CVS_FIR_PATH_TILED)) {
         cvk_fir2d_params sp = fp;
         sp.max_sw = h->wide_foot > 0 ? h->wide_foot : 1;
         sp.max_sh = 0;
@@ -567,7 +571,7 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
 static bool blur_has_fast_kernel(const float *taps, int ntaps) {
     bool finite = true;
     for (int k = 0; k < ntaps; k++) finite = finite && isfinite(taps[k]);
-    return finite && cvk_blur_supported(ntaps, 1) && !getenv("CVS_BLUR_GENERIC");
+    return finite && cvk_blur_supported(ntaps, 1) && !(atomic_load(&g_fir_path) & CVS_FIR_PATH_TABLES);
 }
 
 /* `over`: nover f16 buffers with the target's layout, blended over the blur result before the store (f16 in/out only) */
@@ -612,7 +616,7 @@ static int lanczos_fused(void *tdata, const box2i *tfull, int out_half, const vo
                          float fx, float fy, int ksize, hipStream_t s) {
     /* Halving on both axes: every line centre t / 0.5 is an integer, so every line gets the taps of offset 0 and
      * reads source lines 2t - centre + k (plan_lanczos with frac == 0): the decimating register-window kernel. */
-    if (fx == 0.5f && fy == 0.5f && !getenv("CVS_BLUR_GENERIC")) {
+    if (fx == 0.5f && fy == 0.5f && !(atomic_load(&g_fir_path) & CVS_FIR_PATH_TABLES)) {
         fir_filter f = { NULL, 0, 0 };
         filter_createLanczos(0.5f, ksize, 0.0f, &f);
         bool usable = f.coeff && cvk_blur_supported(f.width, 2) && f.center == f.width / 2 &&

@@ -232,7 +232,7 @@ int resident_per_cu(K kernel, int block) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, 0) != hipSuccess || n < 1) n = 1;
     static int cap = -1;
-    if (cap < 0) { const char *e = getenv("CVS_BLUR_WGS_PER_CU"); cap = e ? atoi(e) : 0; }
+    if (cap < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_WGS_PER_CU"); cap = e ? atoi(e) : 0; }
     return cap > 0 ? cap : n;
 }
 

@@ -53,8 +53,8 @@ extern "C" int cvk_blur(const cvk_blur_params *bp_in, int cus, void *stream) {
     const int cols = bp.tx1 - bp.tx0 + 1;
     // strip width: 256 lanes unless the frame is so narrow that 128 wastes fewer lanes
     static int env_w = -1, env_rows = -1;
-    if (env_w < 0) { const char *e = getenv("CVS_BLUR_WIDTH"); env_w = e ? atoi(e) : 0; }
-    if (env_rows < 0) { const char *e = getenv("CVS_BLUR_ROWS"); env_rows = e ? atoi(e) : 0; }
+    if (env_w < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_WIDTH"); env_w = e ? atoi(e) : 0; }
+    if (env_rows < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_ROWS"); env_rows = e ? atoi(e) : 0; }
     const int width = (bp.ntaps > 15 || !(bp.ntaps & 1)) ? 256 : env_w ? env_w : (cols <= 128 ? 128 : 256);      // long and even lists: 256-lane instances only
     if (bp.rows_per_wg <= 0 && env_rows > 0) bp.rows_per_wg = env_rows;
     return width == 128 ? pick<128>(&bp, cus, (hipStream_t)stream) : pick<256>(&bp, cus, (hipStream_t)stream);

@@ -123,7 +123,7 @@ extern "C" int cvk_color_matrix(cvk_view dst, cvk_view src, cvk_rect r, const fl
         if (((((uintptr_t)d) | ((uintptr_t)q)) & 15u) == 0) {
             static int env_block = -1;
             if (env_block < 0) {
-                const char *e = getenv("CVS_COLOR_BLOCK");
+                const char *e = CVS_DIAG_ENV("CVS_COLOR_BLOCK");
                 env_block = e ? atoi(e) : 0;
                 if (env_block < 64 || env_block > kWG || (env_block & 63)) env_block = 0;
             }

@@ -10,6 +10,16 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* Measurement knobs of tools/ exist only in the diagnostic build (make diag, -DCVS_DIAG); in the shipped library the
+ * macro is a null pointer constant and the branches that read it fold away -- no environment variable changes what the
+ * product computes or launches. */
+#ifdef CVS_DIAG
+#include <stdlib.h>
+#define CVS_DIAG_ENV(name) getenv(name)
+#else
+#define CVS_DIAG_ENV(name) ((const char *)0)
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif

@@ -73,14 +73,22 @@ def broadcast_parameters(lib, dist, rank, matrix, lut_ids, device=None):
     return unpack_parameters(lib, block, lut_ids, install=(rank != 0))
 
 
-def gather_stats(dist, frames_done, checksum, seconds, device=None):
-    """All ranks' (frames_done, checksum, seconds) on every rank: list of tuples, index = rank."""
+def checksum52(hex_digest):
+    """The first 52 bits of a SHA-256 hex digest: what fits a float64 exactly, so that it can ride in gather_stats."""
+    return int(hex_digest[:13], 16)
+
+
+def gather_stats(dist, frames_done, checksum, seconds, extra=(), device=None):
+    """All ranks' (frames_done, checksum, seconds, *extra) on every rank: list of tuples, index = rank.
+    `checksum` < 2**52 (checksum52 of the digest of one rendered frame); `extra`: further floats per rank (verified
+    flag, launch time, ...).  This is the one collective at the end of a run."""
+    extra = [float(x) for x in extra]
     if dist is None:
-        return [(int(frames_done), int(checksum), float(seconds))]
+        return [(int(frames_done), int(checksum), float(seconds), *extra)]
     import torch
     if device is None:
         device = "cuda" if dist.get_backend() == "nccl" else "cpu"
-    mine = torch.tensor([float(frames_done), float(checksum % (1 << 52)), float(seconds)], dtype=torch.float64, device=device)
+    mine = torch.tensor([float(frames_done), float(checksum % (1 << 52)), float(seconds)] + extra, dtype=torch.float64, device=device)
     out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
     dist.all_gather(out, mine)
-    return [(int(o[0].item()), int(o[1].item()), float(o[2].item())) for o in out]
+    return [(int(o[0].item()), int(o[1].item()), float(o[2].item()), *[float(x) for x in o[3:].tolist()]) for o in out]

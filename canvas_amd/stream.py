@@ -35,7 +35,11 @@ class GraphStream:
     """Device-resident ring of input sets plus the intermediates of one in-flight frame per slot."""
 
     def __init__(self, width, height, ring=4, matrix=None, pre_lut=_lib.LUT_REC709_TO_LINEAR_SCENE,
-                 post_lut=_lib.LUT_NONE, taps=None, overlays=OVERLAYS, first_frame=0):
+                 post_lut=_lib.LUT_NONE, taps=None, overlays=OVERLAYS, first_frame=0, frame_step=1, exact_slots=None, donors=None):
+        """Slot s holds the inputs of stream frame first_frame + s * frame_step.  exact_slots / donors: only the first
+        `exact_slots` slots get the generator's frames; the others are filled on the device with copies of `donors`
+        (resident f16 frames of the same size) -- same value distribution, no host generation, for throughput runs that
+        check slot 0 only."""
         from . import REC709_RGB_TO_YPBPR
         self.lib = _lib.load()
         self.w, self.h, self.ring, self.overlays = width, height, ring, overlays
@@ -44,14 +48,21 @@ class GraphStream:
         self.pre_lut, self.post_lut = pre_lut, post_lut
         self.taps = np.ascontiguousarray(synth.gaussian_taps(9, 1.5) if taps is None else taps, np.float32)
         self.slots = []
+        nd = 0
         for slot in range(ring):
-            src = DeviceFrame(self.full, np.uint16)
-            src.upload(synth.layer_pixels(width, height, 0, first_frame + slot))
-            over = []
-            for k in range(1, overlays + 1):
-                o = DeviceFrame(self.full, np.uint16)
-                o.upload(synth.layer_pixels(width, height, k, first_frame + slot))
-                over.append(o)
+            exact = exact_slots is None or slot < exact_slots or not donors
+            frames = []
+            for k in range(overlays + 1):
+                d = DeviceFrame(self.full, np.uint16)
+                if exact:
+                    d.upload(synth.layer_pixels(width, height, k, first_frame + slot * frame_step))
+                else:
+                    # the bottom layer must stay opaque (BASELINE input): donors[0::2] are layer-0 frames by convention
+                    src_frame = donors[(2 * nd) % len(donors)] if k == 0 else donors[(2 * nd + 1) % len(donors)]
+                    nd += 1
+                    _lib.check(self.lib.cvs_memcpy_d2d(d.ptr, src_frame.ptr, d.nbytes, None), "d2d")
+                frames.append(d)
+            src, over = frames[0], frames[1:]
             refs = (C.POINTER(_lib.rgba_frame_f16_t) * overlays)(*[C.pointer(o.c) for o in over])
             self.slots.append({"src": src, "over": over, "over_refs": refs, "graded": DeviceFrame(self.full, np.uint16),
                                "out": DeviceFrame(self.full, np.uint16)})
@@ -71,9 +82,10 @@ class GraphStream:
                                              self.overlays, stream), "blur+over")
         return s["out"]
 
-    def run(self, frames, rank=0, world=1, stream=None):
-        """Render this rank's share of stream frames [0, frames); returns how many it rendered."""
-        mine = frames_of_rank(rank, world, frames)
+    def run(self, frames_per_rank, rank=0, world=1, stream=None):
+        """Render `frames_per_rank` frames on this rank (weak scaling: the stream has frames_per_rank * world frames,
+        global frame g belongs to rank g % world); returns how many it rendered."""
+        mine = frames_of_rank(rank, world, frames_per_rank)
         for i, _g in enumerate(mine):
             self.render(i, stream)
         return len(mine)

@@ -82,6 +82,8 @@ def _bind(lib):
 
 
 _lib = None
+_SO_FMA = os.path.join(_HERE, "liboracle_fma.so")
+_lib_fma = None
 
 
 def lib(path=None):
@@ -92,6 +94,43 @@ def lib(path=None):
         build()
         _lib = _bind(C.CDLL(_SO))
     return _lib
+
+
+def build_fma(force=False):
+    """The clang / contraction-on flavour (oracle/Makefile, target fma): what the reference's preferred build rounds like."""
+    srcs = [os.path.join(_HERE, f) for f in ("tables.c", "mix.c", "scale.c", "color.c", "dv.c", "oracle.h")]
+    if not force and os.path.exists(_SO_FMA) and all(os.path.getmtime(_SO_FMA) >= os.path.getmtime(s) for s in srcs):
+        return _SO_FMA
+    subprocess.run(["make", "-C", _HERE, "-B", "fma"], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return _SO_FMA
+
+
+class flavour:
+    """`with oracle.flavour("fma"): ...` -- every convenience of this module runs on the contraction-on build inside the
+    block (the gcc / no-contraction build is the default everywhere else)."""
+
+    def __init__(self, name):
+        assert name in ("gcc", "fma")
+        self.name = name
+
+    def __enter__(self):
+        global _lib, _lib_fma
+        self.saved = _lib
+        if self.name == "fma":
+            if _lib_fma is None:
+                if not os.path.exists(_SO_FMA):
+                    build_fma()
+                _lib_fma = _bind(C.CDLL(_SO_FMA))
+            _lib = _lib_fma
+        else:
+            _lib = None
+            lib()
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
+        return False
 
 
 # ---- numpy conveniences -------------------------------------------------------------------

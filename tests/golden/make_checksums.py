@@ -6,6 +6,7 @@ pinned by the reference build).  Run here, with this container's libm; the GPU b
 with the committed hashes, so a libm or generator drift shows up as a mismatch rather than silently moving both sides.
 
     python tests/golden/make_checksums.py            # takes about a minute
+    python tests/golden/make_checksums.py --stream 8 # frames 0..7 of every config -> stream_frames_sha256.json (minutes)
 """
 import ctypes as C
 import hashlib
@@ -27,19 +28,19 @@ def canon_sha256(codes):
     return hashlib.sha256(canon_f16(codes).tobytes()).hexdigest()
 
 
-def config2(oracle):
+def config2(oracle, g=0):
     from canvas_amd import REC709_RGB_TO_YPBPR, synth
-    layers = [synth.layer_frame(3840, 2160, k, 0) for k in range(2)]
+    layers = [synth.layer_frame(3840, 2160, k, g) for k in range(2)]
     out = oracle.chain_color_over(layers, np.array(REC709_RGB_TO_YPBPR, np.float32), oracle.transfer_table(0), None)
     return out.array
 
 
-def config3(oracle):
+def config3(oracle, g=0):
     from canvas_amd import synth
     from canvas_amd.abi import HostFrame
     f32p = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
     taps = synth.gaussian_taps(9, 1.5)
-    src16 = synth.layer_frame(3840, 2160, 1, 0)
+    src16 = synth.layer_frame(3840, 2160, 1, g)
     src32 = HostFrame(src16.full_window, np.float32, oracle.half_to_float(src16.array))
     blurred = HostFrame(src16.full_window, np.float32)
     oracle.lib().orc_fir_blur_f32(blurred.ref(), src32.ref(), f32p(taps), 9)
@@ -48,16 +49,16 @@ def config3(oracle):
     return oracle.float_to_half(small.array)
 
 
-def config4(oracle):
+def config4(oracle, g=0):
     from canvas_amd import synth
-    layers = [synth.layer_frame(7680, 4320, k, 0) for k in range(3)]
+    layers = [synth.layer_frame(7680, 4320, k, g) for k in range(3)]
     return oracle.chain_color_over(layers, None).array
 
 
-def config5(oracle):
+def config5(oracle, g=0):
     from canvas_amd import REC709_RGB_TO_YPBPR, synth
     from tests.util import oracle_graph
-    layers = [synth.layer_frame(3840, 2160, k, 0) for k in range(4)]
+    layers = [synth.layer_frame(3840, 2160, k, g) for k in range(4)]
     return oracle_graph(oracle, layers, np.array(REC709_RGB_TO_YPBPR, np.float32), oracle.transfer_table(0), None, synth.gaussian_taps(9, 1.5)).array
 
 
@@ -78,7 +79,31 @@ def checksums(only=None):
     return out
 
 
+def stream_checksums(nframes=8, only=None):
+    """Digests of stream frames 0..nframes-1 of every config: what rank r of an N-GPU bench run proves its first frame
+    (global frame r) against -> tests/golden/stream_frames_sha256.json."""
+    import oracle
+    oracle.lib()
+    out = {}
+    for name, fn in CASES.items():
+        if only and name not in only:
+            continue
+        out[name] = {}
+        for g in range(nframes):
+            t0 = time.perf_counter()
+            out[name][str(g)] = canon_sha256(fn(oracle, g))
+            print("%-34s frame %d %s  (%.1f s)" % (name, g, out[name][str(g)][:16], time.perf_counter() - t0), file=sys.stderr)
+    return out
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--stream":
+        path = os.path.join(HERE, "stream_frames_sha256.json")
+        with open(path, "w") as f:
+            json.dump(stream_checksums(int(sys.argv[2]) if len(sys.argv) > 2 else 8), f, indent=1, sort_keys=True)
+            f.write("\n")
+        print("wrote", path)
+        sys.exit(0)
     path = os.path.join(HERE, "full_size_sha256.json")
     with open(path, "w") as f:
         json.dump(checksums(), f, indent=1, sort_keys=True)

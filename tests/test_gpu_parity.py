@@ -670,19 +670,19 @@ def test_lanczos_resample(cvs, orc, fx, fy, tsize):
 
 @pytest.fixture
 def force_fir(request):
-    """CVS_FIR_STREAM / CVS_FIR_TILED are read on every call: pin the general FIR path to one of its two kernels."""
-    libc = C.CDLL(None)
+    """cvs_fir_path_override pins the general FIR path to one of its kernels (speed only: the point of these tests is that
+    the pixels do not change)."""
+    lib = _lib.load()
 
     def pin(which):
-        libc.unsetenv(b"CVS_FIR_STREAM")
-        libc.unsetenv(b"CVS_FIR_TILED")
-        libc.unsetenv(b"CVS_BLUR_GENERIC")
+        mode = _lib.FIR_PATH_AUTO
         if which:
-            libc.setenv(b"CVS_BLUR_GENERIC", b"1", 1)          # blurs too: past the register-window kernel, to the table kernels
+            mode |= _lib.FIR_PATH_TABLES                    # blurs too: past the register-window kernel, to the table kernels
         if which == "stream":
-            libc.setenv(b"CVS_FIR_STREAM", b"1", 1)
+            mode |= _lib.FIR_PATH_SWEEP
         elif which == "tiled":
-            libc.setenv(b"CVS_FIR_TILED", b"1", 1)
+            mode |= _lib.FIR_PATH_TILED
+        lib.cvs_fir_path_override(mode)
     yield pin
     pin(None)
 

@@ -74,44 +74,58 @@ WORKER = textwrap.dedent("""
     ok_m = bool(np.array_equal(got, np.arange(9, dtype=np.float32) * 0.5))
     ok_t = rank == 0 or bool(np.array_equal(store.installed[0], table))
     mine = shard.frames_of_rank(rank, world, 6)
-    stats = shard.gather_stats(dist, len(mine), sum(mine), 0.25 * (rank + 1))
+    stats = shard.gather_stats(dist, len(mine), sum(mine), 0.25 * (rank + 1), extra=(1 - rank, 2.5 + rank))
     print(json.dumps({"rank": rank, "ok_m": ok_m, "ok_t": ok_t, "frames": mine, "stats": stats}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 """)
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
 def test_two_rank_broadcast_and_gather_over_gloo(tmp_path):
+    """Two ranks started by the SAME launcher code bench.py uses for `--gpus N` (canvas_amd.launch.spawn_ranks),
+    gloo instead of RCCL: the parameter broadcast and the end-of-run all-gather with the per-rank proof fields."""
     import json
+    from canvas_amd import launch
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    port = _free_port()
-    procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = []
-    for p in procs:
-        try:
-            out, err = p.communicate(timeout=240)
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
-        assert p.returncode == 0, err[-2000:]
-        outs.append(json.loads(out.strip().splitlines()[-1]))
-    outs.sort(key=lambda o: o["rank"])
+    rc, outs = launch.spawn_ranks(2, [sys.executable, str(script)], timeout=240, relay=False)
+    assert rc == 0, outs
+    outs = sorted((json.loads(o.strip().splitlines()[-1]) for o in outs), key=lambda o: o["rank"])
     assert all(o["ok_m"] and o["ok_t"] for o in outs)
     assert outs[0]["frames"] == [0, 2, 4, 6, 8, 10] and outs[1]["frames"] == [1, 3, 5, 7, 9, 11]
     for o in outs:
         assert [s[0] for s in o["stats"]] == [6, 6]
         assert [s[1] for s in o["stats"]] == [30, 36]
         assert [round(s[2], 2) for s in o["stats"]] == [0.25, 0.5]
+        assert [s[3:] for s in o["stats"]] == [[1.0, 2.5], [0.0, 3.5]]          # the extra fields ride along, rank by rank
+
+
+def test_a_failing_rank_takes_the_others_down(tmp_path):
+    from canvas_amd import launch
+    script = tmp_path / "w.py"
+    script.write_text("import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(7)\ntime.sleep(60)\n")
+    import time
+    t0 = time.monotonic()
+    rc, _ = launch.spawn_ranks(2, [sys.executable, str(script)], timeout=30, relay=False)
+    assert rc == 7 and time.monotonic() - t0 < 20
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """`python bench.py --gpus 2` with no launcher starts its own ranks -- or, with fewer than 2 devices visible, says so
+    and exits before touching anything."""
+    from canvas_amd import launch
+    if launch.visible_gpu_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs are visible here")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert p.returncode == 2
+    assert "2 ranks wanted, %d devices visible" % launch.visible_gpu_count() in p.stderr
+    assert p.stdout == ""
+
+
+def test_checksum52_fits_a_float64():
+    d = "f" * 64
+    v = shard.checksum52(d)
+    assert v == (1 << 52) - 1 and float(v) == v

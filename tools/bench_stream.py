@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """BASELINE config 5: 3840x2160 10-node graph (4 sources, colour -> blur -> 4-step composite) over a 600-frame synthetic stream.
 
-    python tools/bench_stream.py [--frames 600] [--ring 4] [--width 3840 --height 2160]
-    python -m torch.distributed.run --nproc-per-node N ... tools/bench_stream.py --gpus N
+    python tools/bench_stream.py [--frames 600] [--ring 4] [--width 3840 --height 2160] [--gpus N]
+
+--gpus N > 1 without a launcher: the script starts its N ranks itself (canvas_amd/launch.py), one per GPU; under
+torch.distributed.run it takes the launcher's ranks.  The stream has --frames frames IN TOTAL; global frame g is rendered
+by rank g % N (rank r: frames r, r + N, ...).  Every rank proves one whole output frame (its first: stream frame r)
+against tests/golden/stream_frames_sha256.json.
 
 Prints one JSON line: whole-job Mpixels/s (output pixels), per-rank frame counts, ms per frame and the
 split of a frame's time over its two launches (HIP events on the launch stream).
@@ -26,6 +30,8 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the frames alternate over (tails of one frame overlap the next)")
     a = ap.parse_args()
+    from canvas_amd import launch
+    launch.ensure_ranks(a.gpus)
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
@@ -40,7 +46,8 @@ def main():
     lib = _lib.load()
     if lib.cvs_init(local) != 0:
         raise SystemExit("no HIP device: " + _lib.last_error())
-    g = GraphStream(a.width, a.height, ring=a.ring)
+    assert a.ring % a.streams == 0, "slot i always runs on stream i % streams: the ring must be a multiple of the stream count"
+    g = GraphStream(a.width, a.height, ring=a.ring, first_frame=rank, frame_step=world)      # slot s: stream frame rank + s * world
     if dist is not None:
         g.matrix[:] = shard.broadcast_parameters(lib, dist, rank, g.matrix, [_lib.LUT_REC709_TO_LINEAR_SCENE])
     stream = lib.cvs_stream_create()
@@ -64,30 +71,29 @@ def main():
     _lib.check(lib.cvs_stream_sync(stream))
     streams = [stream] + [lib.cvs_stream_create() for _ in range(a.streams - 1)]
     t0 = time.perf_counter()
-    if a.streams == 1:
-        mine = g.run(a.frames, rank, world, stream)
-    else:
-        frames = shard.frames_of_rank(rank, world, a.frames)
-        for i, _g in enumerate(frames):                 # slot i % ring: consecutive frames use different slots
-            g.render(i, streams[i % a.streams])
-        mine = len(frames)
+    frames = list(range(rank, a.frames, world))         # this rank's share of the stream's frames [0, frames)
+    for i, _g in enumerate(frames):                     # slot i % ring on stream i % streams (ring % streams == 0: a slot never changes stream)
+        g.render(i, streams[i % a.streams])
+    mine = len(frames)
     t_enqueued = time.perf_counter() - t0          # host time to enqueue everything (launch-bound if close to the total)
     for st in streams:
         _lib.check(lib.cvs_stream_sync(st))
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    counts, seconds = [mine], dt
-    if dist is not None:
-        stats = shard.gather_stats(dist, mine, 0, dt)
-        counts = [int(x[0]) for x in stats]
-        seconds = max(float(x[2]) for x in stats)
+    from canvas_amd import verify
+    g.render(0, stream)                                  # slot 0 = stream frame `rank`, rendered once more for the proof
+    digest = verify.canon_sha256(g.slots[0]["out"].download(stream).array)
+    want = verify.stream_fixture("config5_3840x2160", rank) if (a.width, a.height) == (3840, 2160) else None
+    stats = shard.gather_stats(dist, mine, shard.checksum52(digest), dt, extra=(-1 if want is None else int(digest == want),))
+    counts = [int(x[0]) for x in stats]
+    seconds = max(float(x[2]) for x in stats)
     if rank == 0:
         px = a.width * a.height
         print(json.dumps({
             "metric": "Mpixels/s", "value": round(sum(counts) * px / seconds / 1e6, 1), "n_gpus": world,
             "config": {"workload": "config5: %dx%d 10-node graph (4 sources, colour->blur->4-step composite), %d-frame stream" % (a.width, a.height, a.frames)},
-            "frames_per_rank": counts, "streams": a.streams, "host_enqueue_ms_per_frame": round(t_enqueued / max(mine, 1) * 1e3, 4), "ms_per_frame": round(seconds / max(counts) * 1e3, 4),
+            "frames_per_rank": counts, "ranks_verified": sum(1 for x in stats if int(x[3]) == 1), "streams": a.streams, "host_enqueue_ms_per_frame": round(t_enqueued / max(mine, 1) * 1e3, 4), "ms_per_frame": round(seconds / max(counts) * 1e3, 4),
             "launch_ms": {"colour": round(split[0], 4), "blur+over": round(split[1], 4)},
             "node_bytes_per_pixel": NODE_BYTES_PER_PIXEL, "moved_bytes_per_pixel": BYTES_PER_PIXEL,
             "moved_GBps_per_gpu": round(max(counts) * px * BYTES_PER_PIXEL / seconds / 1e9, 1),
