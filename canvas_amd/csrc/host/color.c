@@ -71,17 +71,44 @@ static bool same_box(const box2i *a, const box2i *b) {
     return a->min.x == b->min.x && a->min.y == b->min.y && a->max.x == b->max.x && a->max.y == b->max.y;
 }
 
+static bool ranges_overlap(const void *a, const void *b, size_t bytes) {
+    const uintptr_t x = (uintptr_t)a, y = (uintptr_t)b;
+    return x < y + bytes && y < x + bytes;
+}
+
 static bool job_is_fusable(const cvs_chain_job *j) {
     if (j->nlayers < 1 || j->nlayers > CVS_CHAIN_MAX_LAYERS) return false;
     const box2i *fw = &j->out->full_window;
     if (box2i_is_empty(fw) || cvs_box_pixels(fw) < 2) return false;       /* the kernel works on pixel pairs */
     if (((uintptr_t)j->out->data & 15u) != 0) return false;
+    const size_t bytes = cvs_box_pixels(fw) * sizeof(rgba_f16);
     for (int k = 0; k < j->nlayers; k++) {
         const rgba_frame_f16 *l = j->layers[k];
         if (!same_box(&l->full_window, fw) || !same_box(&l->current_window, fw)) return false;
         if (((uintptr_t)l->data & 15u) != 0) return false;
+        /* in place (out IS a layer) is fine: a lane reads a pixel pair of every layer before it writes that pair;
+         * a shifted overlap is not: another lane may still have to read what this one writes */
+        if (l->data != j->out->data && ranges_overlap(l->data, j->out->data, bytes)) return false;
     }
     return true;
+}
+
+/* Jobs of one call may feed each other (job 5 stacking job 2's output) or reuse an output buffer.  One launch of the
+ * fused kernel gives no order between its jobs -- workgroups walk the whole batch, each at its own pace -- so a job
+ * that touches what an earlier job of the same launch writes (or writes what an earlier one reads) starts a new launch:
+ * launches on one stream run in order.  Returns true when job `j` conflicts with any of jobs [first, j). */
+static bool job_depends_on_earlier(const cvs_chain_job *jobs, int first, int j) {
+    const size_t bj = cvs_box_pixels(&jobs[j].out->full_window) * sizeof(rgba_f16);
+    for (int i = first; i < j; i++) {
+        const size_t bi = cvs_box_pixels(&jobs[i].out->full_window) * sizeof(rgba_f16);
+        const size_t span = bi > bj ? bi : bj;                                   /* conservative for frames of different sizes */
+        if (ranges_overlap(jobs[j].out->data, jobs[i].out->data, span)) return true;                  /* write after write */
+        for (int k = 0; k < jobs[j].nlayers; k++)
+            if (ranges_overlap(jobs[j].layers[k]->data, jobs[i].out->data, span)) return true;          /* read after write */
+        for (int k = 0; k < jobs[i].nlayers; k++)
+            if (ranges_overlap(jobs[j].out->data, jobs[i].layers[k]->data, span)) return true;          /* write after read */
+    }
+    return false;
 }
 
 /* the same graph, one device kernel per reference node; scratch frames are f32 like the reference's temps */
@@ -149,7 +176,13 @@ CVS_EXPORT int cvs_chain_color_over_f16_dev(const cvs_chain_job *jobs, int njobs
         jobs[i].out->current_window = jobs[i].out->full_window;
     }
     if (uniform > 4) uniform = 0;
-    int rc = cvk_chain_color_over(recs, njobs, uniform, m, pre, post, cvs_cus(), s);
+    int rc = 0;
+    for (int first = 0; rc == 0 && first < njobs; ) {       /* runs of mutually independent jobs, one (set of) launch(es) each */
+        int end = first + 1;
+        while (end < njobs && !job_depends_on_earlier(jobs, first, end)) end++;
+        rc = cvk_chain_color_over(recs + first, end - first, uniform, m, pre, post, cvs_cus(), s);
+        first = end;
+    }
     free(recs);
     if (rc != 0) { cvs_set_error("chain kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
     t_last_fused = 1;

@@ -114,8 +114,9 @@ CVS_EXPORT void *cvs_malloc(size_t bytes) {
     return p;
 }
 
-/* Work enqueued on any of the library's (non-blocking) streams may still be reading or writing the block: wait for
- * the device first.  hipFree alone was observed to return memory that a queued kernel then faulted on. */
+/* A block from cvs_malloc: the library does not know which streams its user ran on it, so wait for the whole device
+ * (hipFree alone does not wait for kernels on non-blocking streams: a queued kernel faulted on a just-freed block).
+ * Pool blocks know their stream and wait for that alone (release_to_driver below). */
 static void free_when_idle(void *dev) {
     (void)hipDeviceSynchronize();
     (void)hipFree(dev);
@@ -168,46 +169,87 @@ CVS_EXPORT int cvs_stream_sync(cvs_stream_t s) {
     return 0;
 }
 
-/* ---- scratch pool: intermediates of a filter graph (f32 temps, pulled layers) come and go once per
- * frame; hipFree synchronises the device and hipMalloc costs tens of microseconds, so freed blocks
- * are parked and handed back to the next request of the same size.  A block remembers the stream it
- * was last used on; handing it to a different stream first waits for that stream. */
-#define POOL_SLOTS 64
-static struct { void *ptr; size_t bytes; hipStream_t stream; int live; } g_pool[POOL_SLOTS];
+/* ---- scratch pool: intermediates of a filter graph (f32 temps, pulled layers) come and go once per frame; hipMalloc
+ * costs tens of microseconds and hipFree stalls, so freed blocks are parked and handed back to later requests.
+ *
+ * Lifetime rule (what the first version got wrong, and then hid behind a device-wide wait before every hipFree): a block
+ * is "freed" while the kernels that use it are still queued on the freeing stream.  Every parked block therefore carries
+ * a hipEvent recorded on that stream at the moment of the free:
+ *   - handing the block to the SAME stream needs nothing (stream order);
+ *   - handing it to ANOTHER stream makes that stream wait for the event on the device (hipStreamWaitEvent: no host stall,
+ *     and no stale stream handle -- the first version called hipStreamSynchronize on a remembered handle that its owner
+ *     may have destroyed meanwhile, the error was ignored and the block went out while still in use);
+ *   - returning it to the driver (eviction, trim) waits for the event on the host first: hipFree of memory that a kernel
+ *     on a non-blocking stream still reads is what faulted.
+ * A request is served by the smallest parked block of at least its size and at most 1/8 more (animated windows ask for a
+ * slightly different size every frame); when the table is full the least recently parked block is evicted. */
+#define POOL_SLOTS 256
+#define GRAPH_BLOCKS 64
+typedef struct { void (*release)(void *); void *arg; } cvs_hold;
+static __thread struct { int active, overflow; hipStream_t stream; void *blocks[GRAPH_BLOCKS]; int n; cvs_hold holds[GRAPH_BLOCKS]; int nholds; } t_capture;
+typedef struct { void *ptr; size_t bytes; hipStream_t stream; hipEvent_t ev; int live; uint64_t stamp; } pool_slot;
+static pool_slot g_pool[POOL_SLOTS];
+static uint64_t g_pool_clock;
 static size_t g_pool_parked;                         /* bytes sitting idle in the pool */
 static const size_t kPoolParkedMax = (size_t)8 << 30;
+
+static void release_to_driver(void *ptr, hipEvent_t ev) {      /* g_lock NOT held */
+    if (ev) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); }
+    (void)hipFree(ptr);
+}
 
 CVS_EXPORT void *cvs_pool_malloc(size_t bytes, cvs_stream_t s) {
     if (cvs_enter() != 0) return NULL;
     if (!bytes) bytes = 1;
     hipStream_t st = cvs_pick_stream(s);
     pthread_mutex_lock(&g_lock);
+    int best = -1;
     for (int i = 0; i < POOL_SLOTS; i++)
-        if (g_pool[i].ptr && !g_pool[i].live && g_pool[i].bytes == bytes) {
-            g_pool[i].live = 1;
-            g_pool_parked -= bytes;
-            hipStream_t prev = g_pool[i].stream;
-            void *p = g_pool[i].ptr;
-            g_pool[i].stream = st;
-            pthread_mutex_unlock(&g_lock);
-            if (prev != st) hipStreamSynchronize(prev);
-            return p;
+        if (g_pool[i].ptr && !g_pool[i].live && g_pool[i].bytes >= bytes && g_pool[i].bytes - bytes <= bytes / 8 &&
+            (best < 0 || g_pool[i].bytes < g_pool[best].bytes)) best = i;
+    if (best >= 0) {
+        pool_slot *b = &g_pool[best];
+        b->live = 1;
+        g_pool_parked -= b->bytes;
+        const hipStream_t prev = b->stream;
+        const hipEvent_t ev = b->ev;
+        void *p = b->ptr;
+        b->stream = st;
+        pthread_mutex_unlock(&g_lock);
+        if (prev != st && ev) {                      /* the old user's kernels finish before ours start */
+            if (t_capture.active && st == t_capture.stream) (void)hipEventSynchronize(ev);      /* no outside events inside a capture */
+            else (void)hipStreamWaitEvent(st, ev, 0);
         }
+        return p;
+    }
     pthread_mutex_unlock(&g_lock);
     void *p = NULL;
     hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        cvs_pool_trim();                                                  /* parked blocks may be what is in the way */
+        e = hipMalloc(&p, bytes);
+    }
     if (e != hipSuccess) { cvs_set_error("hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); return NULL; }
+    void *evict_ptr = NULL; hipEvent_t evict_ev = NULL;
     pthread_mutex_lock(&g_lock);
-    for (int i = 0; i < POOL_SLOTS; i++)
-        if (!g_pool[i].ptr) { g_pool[i].ptr = p; g_pool[i].bytes = bytes; g_pool[i].stream = st; g_pool[i].live = 1; break; }
-    pthread_mutex_unlock(&g_lock);      /* table full: the block is simply untracked and freed directly later */
+    int slot = -1, oldest = -1;
+    for (int i = 0; i < POOL_SLOTS; i++) {
+        if (!g_pool[i].ptr) { slot = i; break; }
+        if (!g_pool[i].live && (oldest < 0 || g_pool[i].stamp < g_pool[oldest].stamp)) oldest = i;
+    }
+    if (slot < 0 && oldest >= 0) {                  /* table full: the least recently parked block goes back to the driver */
+        slot = oldest;
+        evict_ptr = g_pool[slot].ptr; evict_ev = g_pool[slot].ev;
+        g_pool_parked -= g_pool[slot].bytes;
+    }
+    if (slot >= 0) { pool_slot fresh = { p, bytes, st, NULL, 1, 0 }; g_pool[slot] = fresh; }
+    pthread_mutex_unlock(&g_lock);                  /* every slot live: the block is untracked, cvs_pool_free handles that */
+    if (evict_ptr) release_to_driver(evict_ptr, evict_ev);
     return p;
 }
 
 /* ---- graph capture state of the calling thread (see cvs_graph_begin below) */
-#define GRAPH_BLOCKS 64
-typedef struct { void (*release)(void *); void *arg; } cvs_hold;
-static __thread struct { int active, overflow; hipStream_t stream; void *blocks[GRAPH_BLOCKS]; int n; cvs_hold holds[GRAPH_BLOCKS]; int nholds; } t_capture;
+/* (t_capture itself is declared above the pool, which needs to know whether its stream is capturing) */
 
 /* A cached device table (FIR taps, display bytes) that a launch has just been handed: outside a capture the caller
  * lets go of it as soon as the launch is enqueued; inside one, the recorded kernels will read it at every replay, so
@@ -228,21 +270,33 @@ CVS_EXPORT void cvs_pool_free(void *dev, cvs_stream_t s) {
         else t_capture.overflow = 1;
         return;
     }
+    hipEvent_t ev = NULL;
     pthread_mutex_lock(&g_lock);
+    int slot = -1;
     for (int i = 0; i < POOL_SLOTS; i++)
-        if (g_pool[i].ptr == dev) {
-            if (g_pool_parked + g_pool[i].bytes <= kPoolParkedMax) {
-                g_pool[i].live = 0;
-                g_pool[i].stream = st;
-                g_pool_parked += g_pool[i].bytes;
-                pthread_mutex_unlock(&g_lock);
-                return;
-            }
-            g_pool[i].ptr = NULL;
-            break;
-        }
+        if (g_pool[i].ptr == dev) { slot = i; break; }
+    if (slot >= 0) { ev = g_pool[slot].ev; g_pool[slot].ev = NULL; }
     pthread_mutex_unlock(&g_lock);
-    free_when_idle(dev);
+    /* the kernels that use the block are queued on `st`: mark the point after them */
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = NULL;
+    if (ev && hipEventRecord(ev, st) != hipSuccess) { (void)hipEventDestroy(ev); ev = NULL; }
+    if (!ev) (void)hipStreamSynchronize(st);                            /* no event to be had: wait here instead */
+    bool parked = false;
+    pthread_mutex_lock(&g_lock);
+    if (slot >= 0 && g_pool[slot].ptr == dev && g_pool[slot].live) {
+        if (g_pool_parked + g_pool[slot].bytes <= kPoolParkedMax) {
+            g_pool[slot].live = 0;
+            g_pool[slot].stream = st;
+            g_pool[slot].ev = ev;
+            g_pool[slot].stamp = ++g_pool_clock;
+            g_pool_parked += g_pool[slot].bytes;
+            parked = true;
+        } else {
+            g_pool[slot].ptr = NULL;
+        }
+    }
+    pthread_mutex_unlock(&g_lock);
+    if (!parked) release_to_driver(dev, ev);        /* over the parking limit, or a block the full table never tracked */
 }
 
 CVS_EXPORT int cvs_mem_info(size_t *free_bytes, size_t *total_bytes) {
@@ -256,10 +310,20 @@ CVS_EXPORT int cvs_mem_info(size_t *free_bytes, size_t *total_bytes) {
 
 CVS_EXPORT void cvs_pool_trim(void) {
     if (cvs_enter() != 0) return;
-    pthread_mutex_lock(&g_lock);
-    for (int i = 0; i < POOL_SLOTS; i++)
-        if (g_pool[i].ptr && !g_pool[i].live) { free_when_idle(g_pool[i].ptr); g_pool_parked -= g_pool[i].bytes; g_pool[i].ptr = NULL; }
-    pthread_mutex_unlock(&g_lock);
+    for (;;) {                                      /* one block at a time: the wait and the hipFree happen outside the lock */
+        void *ptr = NULL; hipEvent_t ev = NULL;
+        pthread_mutex_lock(&g_lock);
+        for (int i = 0; i < POOL_SLOTS; i++)
+            if (g_pool[i].ptr && !g_pool[i].live) {
+                ptr = g_pool[i].ptr; ev = g_pool[i].ev;
+                g_pool_parked -= g_pool[i].bytes;
+                g_pool[i].ptr = NULL; g_pool[i].ev = NULL;
+                break;
+            }
+        pthread_mutex_unlock(&g_lock);
+        if (!ptr) break;
+        release_to_driver(ptr, ev);
+    }
 }
 
 /* ---- HIP graphs: a launch-bound sequence (a node graph on small frames is a dozen 10-20 us kernels) recorded once

@@ -327,7 +327,7 @@ typedef struct {
 
 typedef struct { const float *taps; float factor, tmin, smin; } axis_plan;    /* what the planner of the key's kind needs */
 
-#define AXIS_CACHE 32
+#define AXIS_CACHE 128
 static axis_entry g_axis[AXIS_CACHE];
 static uint64_t g_axis_clock;
 static pthread_mutex_t g_axis_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -432,48 +432,95 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     return 0;
 }
 
-/* cached table for one axis.  The entry comes back PINNED (*pin = its slot): it cannot be evicted -- its device block
- * freed -- until axis_done() says the launch that reads it is on its stream.  An eviction then waits for the device. */
+/* Device blocks of evicted (or lost-the-race) tables.  A kernel on ANY stream may still be reading an evicted table, so
+ * its block is parked here instead of freed; when the list is full ONE device-wide wait -- outside every lock -- makes all
+ * of them free at once.  (The first version waited for the whole device under the cache lock on every eviction: an
+ * animated zoom, which misses on every frame, stalled all streams and all pull-queue workers once per frame.) */
+#define AXIS_RETIRED 64
+static char *g_retired[AXIS_RETIRED];
+static int g_nretired;
+
+static void retire_block(char *dev) {           /* g_axis_lock NOT held */
+    if (!dev) return;
+    char *drain[AXIS_RETIRED];
+    int n = 0;
+    pthread_mutex_lock(&g_axis_lock);
+    if (g_nretired == AXIS_RETIRED) { memcpy(drain, g_retired, sizeof drain); n = g_nretired; g_nretired = 0; }
+    g_retired[g_nretired++] = dev;
+    pthread_mutex_unlock(&g_axis_lock);
+    if (n) {
+        (void)hipDeviceSynchronize();           /* every launch enqueued before this point has finished */
+        for (int i = 0; i < n; i++) (void)hipFree(drain[i]);
+    }
+}
+
+static void fill_from_entry(const axis_entry *e, cvk_fir_axis *out, int *max_foot, int *used_lo, int *used_hi) {
+    *out = e->axis; *max_foot = e->max_foot;
+    if (used_lo) { *used_lo = e->used_lo; *used_hi = e->used_hi; }
+}
+
+/* cached table for one axis.  The entry comes back PINNED (*pin = its slot): it cannot be evicted until axis_done() says
+ * the launch that reads it is on its stream.  The lock covers table look-ups and slot bookkeeping only: planning, the
+ * allocation and the upload of a missing table run outside it, and nothing under it calls back into the error log. */
 static int axis_get_ex(const axis_key *key, const axis_plan *pl, cvk_fir_axis *out, int *max_foot, int *used_lo, int *used_hi, int *pin) {
     pthread_mutex_lock(&g_axis_lock);
-    int victim = -1;
     for (int i = 0; i < AXIS_CACHE; i++) {
         if (g_axis[i].valid && memcmp(&g_axis[i].key, key, sizeof *key) == 0) {
             g_axis[i].stamp = ++g_axis_clock;
             g_axis[i].pins++;
             *pin = i;
-            *out = g_axis[i].axis; *max_foot = g_axis[i].max_foot;
-            if (used_lo) { *used_lo = g_axis[i].used_lo; *used_hi = g_axis[i].used_hi; }
+            fill_from_entry(&g_axis[i], out, max_foot, used_lo, used_hi);
             pthread_mutex_unlock(&g_axis_lock);
             return 0;
         }
-        if (g_axis[i].valid && g_axis[i].pins > 0) continue;
-        if (victim < 0 || (g_axis[victim].valid && (!g_axis[i].valid || g_axis[i].stamp < g_axis[victim].stamp))) victim = i;
     }
-    if (victim < 0) {
-        pthread_mutex_unlock(&g_axis_lock);
-        cvs_set_error("FIR tables: every cache slot is held by a launch in preparation or a captured graph");
-        return -1;
-    }
+    pthread_mutex_unlock(&g_axis_lock);
+
+    /* miss: build the table without holding anything */
     tap_table tb;
     int rc = key->kind == 1 ? plan_blur(&tb, key->t0, key->t1, key->s0, key->s1, pl->taps, key->ksize)
            : key->kind == 2 ? plan_lanczos(&tb, key->t0, key->t1, key->s0, key->s1, pl->factor, key->ksize)
                             : plan_triangle(&tb, pl->tmin, pl->smin, pl->factor, key->s0, key->s1, key->t0, key->t1, key->ksize != 0);
+    if (rc != 0) { cvs_set_error("FIR planning: out of memory"); return -1; }
     axis_entry fresh;
     memset(&fresh, 0, sizeof fresh);
-    if (rc == 0) { fresh.used_lo = tb.used_lo; fresh.used_hi = tb.used_hi; rc = axis_upload(&tb, key->tile, &fresh); table_free(&tb); }
-    else cvs_set_error("FIR planning: out of memory");
-    if (rc == 0) {
+    fresh.used_lo = tb.used_lo; fresh.used_hi = tb.used_hi;
+    rc = axis_upload(&tb, key->tile, &fresh);
+    table_free(&tb);
+    if (rc != 0) return -1;                                 /* axis_upload has logged why */
+    fresh.key = *key; fresh.valid = 1; fresh.pins = 1;
+
+    char *lost = NULL, *evicted = NULL;
+    pthread_mutex_lock(&g_axis_lock);
+    int slot = -1, victim = -1;
+    for (int i = 0; i < AXIS_CACHE; i++) {
+        if (g_axis[i].valid && memcmp(&g_axis[i].key, key, sizeof *key) == 0) { slot = i; break; }     /* another thread was faster */
+        if (g_axis[i].valid && g_axis[i].pins > 0) continue;
+        if (victim < 0 || (g_axis[victim].valid && (!g_axis[i].valid || g_axis[i].stamp < g_axis[victim].stamp))) victim = i;
+    }
+    if (slot >= 0) {
+        g_axis[slot].stamp = ++g_axis_clock;
+        g_axis[slot].pins++;
+        lost = fresh.dev;                                   /* never read by any kernel, still parked like the others */
+        *pin = slot;
+        fill_from_entry(&g_axis[slot], out, max_foot, used_lo, used_hi);
+    } else if (victim >= 0) {
         axis_entry *e = &g_axis[victim];
-        if (e->valid && e->dev) { hipDeviceSynchronize(); hipFree(e->dev); }     /* unpinned: every launch that read it is on a stream; wait for them */
-        fresh.key = *key; fresh.valid = 1; fresh.pins = 1; fresh.stamp = ++g_axis_clock;
+        if (e->valid) evicted = e->dev;
+        fresh.stamp = ++g_axis_clock;
         *e = fresh;
         *pin = victim;
-        *out = e->axis; *max_foot = e->max_foot;
-        if (used_lo) { *used_lo = e->used_lo; *used_hi = e->used_hi; }
+        fill_from_entry(e, out, max_foot, used_lo, used_hi);
     }
     pthread_mutex_unlock(&g_axis_lock);
-    return rc;
+    retire_block(lost);
+    retire_block(evicted);
+    if (slot < 0 && victim < 0) {
+        retire_block(fresh.dev);
+        cvs_set_error("FIR tables: every cache slot is held by a launch in preparation or a captured graph");
+        return -1;
+    }
+    return 0;
 }
 
 static void axis_unpin(void *slot) {

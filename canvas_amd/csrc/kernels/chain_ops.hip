@@ -243,30 +243,43 @@ __global__ __launch_bounds__(kWG) void k_chain(Batch batch, int njobs_, Mat kmat
     while (trip(A, B) && trip(B, A)) { }
     if (DIAG == DIAG_COMPUTE_ONLY) ((g_u4)batch.jobs[0].out)[(size_t)blockIdx.x * L + tid] = diag_acc;
 
-    // odd pixel counts: the last pixel of such a frame on its own (scalar form of the same arithmetic)
-    if (blockIdx.x == 0 && tid == 0) {
-        MatR m1 = mat;
-        m1.plain = MODE == CHAIN_PLAIN; m1.cross = MODE == CHAIN_CROSS;
-        for (unsigned j = 0; j < njobs; j++) {
-            const JobC &job = batch.jobs[j];
-            if (!(job.npixels & 1)) continue;
-            uint2 px[NL];
+}
+
+// Odd pixel counts: the last pixel of such a frame has no partner.  One lane per frame of the batch, the scalar form of
+// the same arithmetic, tables read from global memory -- a launch of its own (only when a batch has such a frame) so
+// that the trip loop's kernel carries none of this code.
+template <int NL, int MODE, bool PRE, bool POST>
+__global__ __launch_bounds__(64) void k_chain_tail(Batch batch, int njobs, Mat kmat, const uint16_t *__restrict__ pre, const uint16_t *__restrict__ post) {
+    MatR mat = CVS_MAT_REGS(kmat);
+    mat.plain = MODE == CHAIN_PLAIN; mat.cross = MODE == CHAIN_CROSS;
+    const int j = (int)threadIdx.x;
+    if (j >= njobs) return;
+    const JobC &job = batch.jobs[j];
+    if (!(job.npixels & 1)) return;
+    uint2 px[NL];
 #pragma unroll
-            for (int k = 0; k < NL; k++) px[k] = ld2(job.layer[k], job.npixels - 1);
-            st2(job.out, job.npixels - 1, chain_pixel<NL, PRE, POST>(px, NL, m1, lut, post));
-        }
-    }
+    for (int k = 0; k < NL; k++) px[k] = ld2(job.layer[k], job.npixels - 1);
+    st2(job.out, job.npixels - 1, chain_pixel<NL, PRE, POST>(px, NL, mat, PRE ? pre : post, post));
 }
 
 template <int NL, int MODE, int DIAG>
 int launch(const Batch &jobs, int njobs, const Mat &mat, const uint16_t *pre, const uint16_t *post, unsigned grid, unsigned block, int lshift, hipStream_t s) {
+    bool odd = false;
+    for (int i = 0; i < njobs; i++) odd = odd || (jobs.jobs[i].npixels & 1);
     if constexpr (MODE != CHAIN_GRADE) {
         hipLaunchKernelGGL((k_chain<NL, MODE, false, false, DIAG>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, lshift, pre, post);
+        if (odd) hipLaunchKernelGGL((k_chain_tail<NL, MODE, false, false>), dim3(1), dim3(64), 0, s, jobs, njobs, mat, pre, post);
     } else {
         if (pre && post)  hipLaunchKernelGGL((k_chain<NL, MODE, true, true, DIAG>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, lshift, pre, post);
         else if (pre)     hipLaunchKernelGGL((k_chain<NL, MODE, true, false, DIAG>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, lshift, pre, post);
         else if (post)    hipLaunchKernelGGL((k_chain<NL, MODE, false, true, DIAG>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, lshift, pre, post);
         else              hipLaunchKernelGGL((k_chain<NL, MODE, false, false, DIAG>), dim3(grid), dim3(block), 0, s, jobs, njobs, mat, lshift, pre, post);
+        if (odd) {
+            if (pre && post)  hipLaunchKernelGGL((k_chain_tail<NL, MODE, true, true>), dim3(1), dim3(64), 0, s, jobs, njobs, mat, pre, post);
+            else if (pre)     hipLaunchKernelGGL((k_chain_tail<NL, MODE, true, false>), dim3(1), dim3(64), 0, s, jobs, njobs, mat, pre, post);
+            else if (post)    hipLaunchKernelGGL((k_chain_tail<NL, MODE, false, true>), dim3(1), dim3(64), 0, s, jobs, njobs, mat, pre, post);
+            else              hipLaunchKernelGGL((k_chain_tail<NL, MODE, false, false>), dim3(1), dim3(64), 0, s, jobs, njobs, mat, pre, post);
+        }
     }
     return (int)hipGetLastError();
 }

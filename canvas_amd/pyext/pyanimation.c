@@ -88,7 +88,7 @@ static int point_set_frame(py_anim_point *self, PyObject *value, void *c) {
     if (frame == -1.0 && PyErr_Occurred()) return -1;
     py_anim *a = self->owner;
     if (!a) { self->frame = frame; return 0; }
-    pthread_rwlock_wrlock(&a->lock);
+    py_wrlock_nogil(&a->lock);
     Py_ssize_t at = index_of(a, self);
     if (at >= 0) {          /* take it out, find its new place, put it back */
         memmove(a->points + at, a->points + at + 1, sizeof(*a->points) * (size_t)(a->count - at - 1));
@@ -174,7 +174,7 @@ static PyObject *anim_add(py_anim *self, PyObject *args, PyObject *kw) {
         p = (py_anim_point *)PyObject_Call((PyObject *)&py_type_AnimationPoint, args, kw);
         if (!p) return NULL;
     }
-    pthread_rwlock_wrlock(&self->lock);
+    py_wrlock_nogil(&self->lock);
     if (self->count == self->cap) {
         Py_ssize_t cap = self->cap ? self->cap * 2 : 8;
         py_anim_point **grown = PyMem_Realloc(self->points, sizeof(*grown) * (size_t)cap);
@@ -196,7 +196,7 @@ static PyObject *anim_remove(py_anim *self, PyObject *args) {
     py_anim_point *p;
     if (!PyArg_ParseTuple(args, "O!", &py_type_AnimationPoint, &p)) return NULL;
     if (p->owner != self) Py_RETURN_NONE;
-    pthread_rwlock_wrlock(&self->lock);
+    py_wrlock_nogil(&self->lock);
     Py_ssize_t at = index_of(self, p);
     if (at >= 0) {
         memmove(self->points + at, self->points + at + 1, sizeof(*self->points) * (size_t)(self->count - at - 1));

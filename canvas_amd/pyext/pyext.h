@@ -13,6 +13,16 @@
 #include "pyframework.h"
 #include <pthread.h>
 
+/* Writer side of a node's rwlock, taken from a Python-called method (GIL held).  Worker threads hold the reader side
+ * across pulls, and a pull may need the GIL (a source written in Python): a writer that blocks WITH the GIL would then
+ * wait for a reader that waits for the GIL.  So: try first, and if the lock is busy, wait for it without the GIL. */
+static inline void py_wrlock_nogil(pthread_rwlock_t *lock) {
+    if (pthread_rwlock_trywrlock(lock) == 0) return;
+    Py_BEGIN_ALLOW_THREADS
+    pthread_rwlock_wrlock(lock);
+    Py_END_ALLOW_THREADS
+}
+
 /* a node's native render: fill `frame` (device, of the node's native format) for frame_index */
 typedef void (*node_render_func)(PyObject *self, int frame_index, rgba_frame_dev *frame);
 

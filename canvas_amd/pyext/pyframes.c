@@ -387,7 +387,7 @@ static PyObject *ffpass_get_source(py_ffpass *self, PyObject *noargs) {
 static PyObject *ffpass_set_source(py_ffpass *self, PyObject *args) {
     PyObject *src;
     if (!PyArg_ParseTuple(args, "O", &src)) return NULL;
-    pthread_rwlock_wrlock(&self->lock);
+    py_wrlock_nogil(&self->lock);
     const bool ok = py_framefunc_take_source(src, &self->source);
     pthread_rwlock_unlock(&self->lock);
     if (!ok) return NULL;

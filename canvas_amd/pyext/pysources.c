@@ -103,14 +103,14 @@ static PyObject *node1_get_source(node1 *self, void *c) {
 static PyObject *node1_set_source(node1 *self, PyObject *args) {
     PyObject *src;
     if (!PyArg_ParseTuple(args, "O", &src)) return NULL;
-    pthread_rwlock_wrlock(&self->lock);
+    py_wrlock_nogil(&self->lock);
     bool ok = py_video_take_source(src, &self->source);
     pthread_rwlock_unlock(&self->lock);
     if (!ok) return NULL;
     Py_RETURN_NONE;
 }
 static int node1_set_source_attr(node1 *self, PyObject *value, void *c) {
-    pthread_rwlock_wrlock(&self->lock);
+    py_wrlock_nogil(&self->lock);
     bool ok = py_video_take_source(value, &self->source);
     pthread_rwlock_unlock(&self->lock);
     return ok ? 0 : -1;
@@ -380,7 +380,7 @@ static PyObject *pass_get_offset(py_pass *self, void *c) { return PyLong_FromLon
 static int pass_set_offset(py_pass *self, PyObject *v, void *c) {
     long x = PyLong_AsLong(v);
     if (PyErr_Occurred()) return -1;
-    pthread_rwlock_wrlock(&self->n.lock); self->offset = (int)x; pthread_rwlock_unlock(&self->n.lock);
+    py_wrlock_nogil(&self->n.lock); self->offset = (int)x; pthread_rwlock_unlock(&self->n.lock);
     return 0;
 }
 static PyObject *opt_int(bool has, int v) { if (!has) Py_RETURN_NONE; return PyLong_FromLong(v); }
@@ -389,7 +389,7 @@ static PyObject *pass_get_end(py_pass *self, void *c) { return opt_int(self->has
 static int pass_set_bound(py_pass *self, PyObject *v, bool *has, int *slot) {
     long x = 0;
     if (v && v != Py_None) { x = PyLong_AsLong(v); if (PyErr_Occurred()) return -1; }
-    pthread_rwlock_wrlock(&self->n.lock);
+    py_wrlock_nogil(&self->n.lock);
     *has = v && v != Py_None; *slot = (int)x;
     pthread_rwlock_unlock(&self->n.lock);
     return 0;
@@ -474,7 +474,7 @@ static int seq_ass_item(py_seq *self, Py_ssize_t i, PyObject *v) {
     if (i < 0 || i >= self->count) { PyErr_SetString(PyExc_IndexError, "Index was out of range."); return -1; }
     seq_elem fresh;
     if (v && !seq_parse(v, &fresh)) return -1;
-    pthread_rwlock_wrlock(&self->lock);
+    py_wrlock_nogil(&self->lock);
     Py_CLEAR(self->e[i].tuple);
     py_video_take_source(NULL, &self->e[i].source);
     if (v) self->e[i] = fresh;
@@ -489,7 +489,7 @@ static PyObject *seq_insert_at(py_seq *self, Py_ssize_t i, PyObject *v) {
     if (i > self->count) { PyErr_SetString(PyExc_IndexError, "Index was out of range."); return NULL; }
     seq_elem fresh;
     if (!seq_parse(v, &fresh)) return NULL;
-    pthread_rwlock_wrlock(&self->lock);
+    py_wrlock_nogil(&self->lock);
     if (self->count == self->cap) {
         Py_ssize_t cap = self->cap ? self->cap * 2 : 8;
         seq_elem *e = PyMem_Realloc(self->e, sizeof(seq_elem) * (size_t)cap);

@@ -73,7 +73,7 @@ static PyObject *ws_add(py_workspace *self, PyObject *args, PyObject *kw) {
     if (!it) return NULL;
     if (!py_video_take_source(src, &it->source)) { Py_DECREF(it); return NULL; }
     Py_INCREF(tag);
-    pthread_rwlock_wrlock(&self->lock);
+    py_wrlock_nogil(&self->lock);
     it->item = workspace_add_item(self->ws, it->source, x, length, offset, z, tag);
     pthread_rwlock_unlock(&self->lock);
     it->owner = self;
@@ -86,7 +86,7 @@ static PyObject *ws_remove(py_workspace *self, PyObject *args) {
     if (!PyArg_ParseTuple(args, "O!", &py_type_WorkspaceItem, &it)) return NULL;
     if (it->owner != self) { PyErr_SetString(PyExc_ValueError, "The item does not belong to this workspace."); return NULL; }
     PyObject *tag = workspace_get_item_tag(it->item);
-    pthread_rwlock_wrlock(&self->lock);
+    py_wrlock_nogil(&self->lock);
     item_detach(it);
     pthread_rwlock_unlock(&self->lock);
     Py_XDECREF(tag);
@@ -158,7 +158,7 @@ static PyObject *item_update(py_ws_item *self, PyObject *args, PyObject *kw) {
     PyObject *old_tag = tag ? workspace_get_item_tag(self->item) : NULL;
     if (tag) Py_INCREF(tag);
     py_workspace *owner = self->owner;
-    pthread_rwlock_wrlock(&owner->lock);
+    py_wrlock_nogil(&owner->lock);
     workspace_update_item(self->item, x ? &vx : NULL, length ? &vl : NULL, z ? &vz : NULL, offset ? &vo : NULL,
                           source ? &src_ptr : NULL, tag ? &tag_ptr : NULL);
     if (source) { video_source *old = self->source; self->source = fresh; py_video_take_source(NULL, &old); }
@@ -189,28 +189,45 @@ typedef struct pq_item {
     struct pq_item *next;
     video_source *source;
     PyObject *callback, *user_data, *pyframe;
+    PyObject *queue;                /* strong: a queue with requests pending stays alive (its last Python reference may be dropped
+                                     * inside one of its own callbacks) */
     rgba_frame_f16 *frame;
     int frame_index;
     volatile int active;
 } py_pq_item;
 
+/* What the worker threads share.  It is NOT the Python object: the object can be deallocated on a worker thread (the last
+ * reference dropped in a callback), and a worker must be able to go round its loop once more and leave.  The core is
+ * reference-counted by the object and by every worker; the last one out frees it. */
 typedef struct {
-    PyObject_HEAD
     pthread_mutex_t mutex;
     pthread_cond_t wake;
     py_pq_item *head, *tail;
+    int quit, refs;
+} pq_core;
+
+typedef struct {
+    PyObject_HEAD
+    pq_core *core;
     pthread_t workers[16];
-    int nworkers, quit;
+    int nworkers;
 } py_pullqueue;
 
 static PyTypeObject py_type_PullQueueItem;
 
+static void pq_core_unref(pq_core *c) {
+    pthread_mutex_lock(&c->mutex);
+    const int left = --c->refs;
+    pthread_mutex_unlock(&c->mutex);
+    if (left == 0) { pthread_cond_destroy(&c->wake); pthread_mutex_destroy(&c->mutex); free(c); }
+}
+
 static void *pq_worker(void *arg) {
-    py_pullqueue *q = arg;
+    pq_core *q = arg;
     for (;;) {
         pthread_mutex_lock(&q->mutex);
         while (!q->head && !q->quit) pthread_cond_wait(&q->wake, &q->mutex);
-        if (!q->head && q->quit) { pthread_mutex_unlock(&q->mutex); return NULL; }
+        if (!q->head && q->quit) { pthread_mutex_unlock(&q->mutex); pq_core_unref(q); return NULL; }
         py_pq_item *it = q->head;
         q->head = it->next;
         if (!q->head) q->tail = NULL;
@@ -227,6 +244,7 @@ static void *pq_worker(void *arg) {
         }
         Py_CLEAR(it->callback); Py_CLEAR(it->user_data); Py_CLEAR(it->pyframe);
         py_video_take_source(NULL, &it->source);
+        Py_CLEAR(it->queue);                                /* may run pq_dealloc right here, on this thread: only `q` is touched below */
         Py_DECREF(it);                                      /* the queue's reference */
         PyGILState_Release(st);
     }
@@ -240,23 +258,37 @@ static int pq_init(py_pullqueue *self, PyObject *args, PyObject *kw) {
     int workers = 2;
     if (!PyArg_ParseTupleAndKeywords(args, kw, "|i", kwlist, &workers)) return -1;
     if (workers < 1 || workers > 16) { PyErr_SetString(PyExc_ValueError, "workers must be between 1 and 16"); return -1; }
-    pthread_mutex_init(&self->mutex, NULL);
-    pthread_cond_init(&self->wake, NULL);
-    for (int i = 0; i < workers; i++)
-        if (pthread_create(&self->workers[i], NULL, pq_worker, self) == 0) self->nworkers++;
+    if (self->core) { PyErr_SetString(PyExc_RuntimeError, "VideoPullQueue is already initialised"); return -1; }
+    pq_core *c = calloc(1, sizeof *c);
+    if (!c) { PyErr_NoMemory(); return -1; }
+    pthread_mutex_init(&c->mutex, NULL);
+    pthread_cond_init(&c->wake, NULL);
+    c->refs = 1;                                            /* the object's */
+    self->core = c;
+    for (int i = 0; i < workers; i++) {
+        pthread_mutex_lock(&c->mutex); c->refs++; pthread_mutex_unlock(&c->mutex);
+        if (pthread_create(&self->workers[self->nworkers], NULL, pq_worker, c) == 0) self->nworkers++;
+        else { pthread_mutex_lock(&c->mutex); c->refs--; pthread_mutex_unlock(&c->mutex); }
+    }
     if (!self->nworkers) { PyErr_SetString(PyExc_RuntimeError, "could not start worker threads"); return -1; }
     return 0;
 }
 static void pq_dealloc(py_pullqueue *self) {
-    pthread_mutex_lock(&self->mutex);
-    self->quit = 1;
-    pthread_cond_broadcast(&self->wake);
-    pthread_mutex_unlock(&self->mutex);
-    Py_BEGIN_ALLOW_THREADS
-    for (int i = 0; i < self->nworkers; i++) pthread_join(self->workers[i], NULL);
-    Py_END_ALLOW_THREADS
-    pthread_cond_destroy(&self->wake);
-    pthread_mutex_destroy(&self->mutex);
+    pq_core *c = self->core;
+    if (c) {
+        pthread_mutex_lock(&c->mutex);
+        c->quit = 1;
+        pthread_cond_broadcast(&c->wake);
+        pthread_mutex_unlock(&c->mutex);
+        const pthread_t me = pthread_self();
+        Py_BEGIN_ALLOW_THREADS
+        for (int i = 0; i < self->nworkers; i++) {
+            if (pthread_equal(self->workers[i], me)) pthread_detach(self->workers[i]);     /* deallocated from inside a callback: that worker leaves by itself */
+            else pthread_join(self->workers[i], NULL);
+        }
+        Py_END_ALLOW_THREADS
+        pq_core_unref(c);
+    }
     Py_TYPE(self)->tp_free((PyObject *)self);
 }
 static PyObject *pq_enqueue(py_pullqueue *self, PyObject *args, PyObject *kw) {
@@ -265,23 +297,25 @@ static PyObject *pq_enqueue(py_pullqueue *self, PyObject *args, PyObject *kw) {
     int frame_index; box2i window;
     if (!PyArg_ParseTupleAndKeywords(args, kw, "OiOOO", kwlist, &src, &frame_index, &window_obj, &callback, &user_data)) return NULL;
     if (!py_parse_box2i(window_obj, &window)) return NULL;
+    if (!self->core) { PyErr_SetString(PyExc_RuntimeError, "VideoPullQueue is not initialised"); return NULL; }
     py_pq_item *it = (py_pq_item *)py_type_PullQueueItem.tp_alloc(&py_type_PullQueueItem, 0);
     if (!it) return NULL;
     it->pyframe = py_RgbaFrameF16_new(&window, &it->frame);
     if (!it->pyframe || !py_video_take_source(src, &it->source)) { Py_DECREF(it); return NULL; }
-    Py_INCREF(callback); Py_INCREF(user_data);
-    it->callback = callback; it->user_data = user_data; it->frame_index = frame_index; it->active = 1;
+    Py_INCREF(callback); Py_INCREF(user_data); Py_INCREF(self);
+    it->callback = callback; it->user_data = user_data; it->queue = (PyObject *)self; it->frame_index = frame_index; it->active = 1;
     Py_INCREF(it);                                          /* one reference for the queue, one for the caller */
-    pthread_mutex_lock(&self->mutex);
-    if (self->tail) self->tail->next = it; else self->head = it;
-    self->tail = it;
-    pthread_cond_signal(&self->wake);
-    pthread_mutex_unlock(&self->mutex);
+    pq_core *c = self->core;
+    pthread_mutex_lock(&c->mutex);
+    if (c->tail) c->tail->next = it; else c->head = it;
+    c->tail = it;
+    pthread_cond_signal(&c->wake);
+    pthread_mutex_unlock(&c->mutex);
     return (PyObject *)it;
 }
 static PyObject *pq_item_cancel(py_pq_item *self, PyObject *dummy) { self->active = 0; Py_RETURN_NONE; }
 static void pq_item_dealloc(py_pq_item *self) {
-    Py_CLEAR(self->callback); Py_CLEAR(self->user_data); Py_CLEAR(self->pyframe);
+    Py_CLEAR(self->callback); Py_CLEAR(self->user_data); Py_CLEAR(self->pyframe); Py_CLEAR(self->queue);
     py_video_take_source(NULL, &self->source);
     Py_TYPE(self)->tp_free((PyObject *)self);
 }

@@ -1,9 +1,9 @@
 """Checking a rendered frame against a committed fixture, for callers outside tests/ (bench.py's per-rank proof).
 
-The fixtures (tests/golden/*.json) hold SHA-256 digests of the oracle's outputs for the synthetic stream's frames at the
-BASELINE configs' full sizes, made in the build container by tests/golden/make_checksums.py.  Hashing happens after
+The fixtures (tests/golden/*.json) hold SHA-256 digests of the expected outputs for the synthetic stream's frames at the
+BASELINE configs' full sizes, made in the build container by tests/golden/make_checksums.py (the CPU checker of tests/).  Hashing happens after
 canonicalisation of the two things the reference build does not pin: the sign of zero (-fno-signed-zeros, SConstruct:82-83)
-and NaN payload / sign (x86 and gfx950 default NaNs differ).  Nothing here runs the oracle."""
+and NaN payload / sign (x86 and gfx950 default NaNs differ).  Nothing here computes pixels: it hashes what the library rendered and compares."""
 import hashlib
 import json
 import os

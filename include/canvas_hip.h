@@ -376,7 +376,10 @@ typedef struct {
     const rgba_frame_f16 *layers[CVS_CHAIN_MAX_LAYERS];/* device frames, bottom first */
     int nlayers;
 } cvs_chain_job;
-/* m == NULL: no colour stage -- the plain workspace stack of f16 layers (both tables must then be CVS_LUT_NONE) */
+/* m == NULL: no colour stage -- the plain workspace stack of f16 layers (both tables must then be CVS_LUT_NONE).
+ * Jobs are carried out as if one after the other: a job may read or overwrite what an earlier job of the same call
+ * wrote (the library starts a new launch there); `out` may be one of the job's own layers (in place), but must not
+ * overlap a layer at a shifted address (such a job takes the node-by-node path). */
 CVS_EXPORT int cvs_chain_color_over_f16_dev(const cvs_chain_job *jobs, int njobs, const float m[9],
                                             int pre_lut, int post_lut, cvs_stream_t s);
 /* how the last chain call ran: 1 = single fused kernel, 0 = node-by-node device kernels

@@ -423,6 +423,55 @@ def test_chain_fused_matches_oracle(cvs, orc, nlayers, size):
     assert_same_f16(got.array, want.array, "fused chain, %d layers" % nlayers)
 
 
+def test_chain_jobs_that_feed_each_other_run_in_order(cvs, orc):
+    """One call, jobs that depend on each other: job 1 stacks job 0's output, job 2 overwrites a buffer job 1 reads,
+    job 3 overwrites job 0's output, job 4 works in place.  The library must carry them out as if one after the other
+    (it starts a new launch at every dependent job): a batch in ONE launch gives no order between jobs."""
+    w, h = 640, 360                                  # 115 200 pairs: 225 chunks, nearly every workgroup has one
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    lut = orc.transfer_table(0)
+    L = _synth_layers(w, h, 4)
+    full = (0, 0, w - 1, h - 1)
+    d = [DeviceFrame.from_host(l) for l in L]
+    a, b = DeviceFrame(full, np.uint16), DeviceFrame(full, np.uint16)
+    jobs = [(a, [d[0], d[1]]),          # a = chain(L0, L1)
+            (b, [a, d[2]]),             # b = chain(a, L2)           reads job 0's output
+            (d[2], [d[0], d[3]]),       # L2 := chain(L0, L3)        overwrites what job 1 reads
+            (a, [b, d[1]]),             # a = chain(b, L1)           overwrites job 0's output, reads job 1's
+            (b, [b, d[3]])]             # b = chain(b, L3)           in place
+    chain_color_over(jobs, m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE)
+    _lib.check(cvs.cvs_stream_sync(None))
+    assert cvs.cvs_chain_last_was_fused() == 1
+    wa = orc.chain_color_over([L[0], L[1]], m, lut, None)
+    wb = orc.chain_color_over([wa, L[2]], m, lut, None)
+    w2 = orc.chain_color_over([L[0], L[3]], m, lut, None)
+    wa2 = orc.chain_color_over([wb, L[1]], m, lut, None)
+    wb2 = orc.chain_color_over([wb, L[3]], m, lut, None)
+    assert_same_f16(a.download().array, wa2.array, "a after job 3")
+    assert_same_f16(b.download().array, wb2.array, "b after job 4")
+    assert_same_f16(d[2].download().array, w2.array, "L2 after job 2")
+
+
+def test_chain_shifted_overlap_of_output_and_layer_is_not_fused(cvs, orc):
+    """out overlapping one of its own layers at a shifted address cannot go through the fused kernel (a lane would
+    overwrite pixels another lane still has to read); it takes the node-by-node path, which copies the layer first."""
+    w, h = 64, 36
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    L = _synth_layers(w, h, 2)
+    arena = cvs.cvs_malloc(w * h * 8 + w * 8 * 4)
+    full = (0, 0, w - 1, h - 1)
+    lay0 = DeviceFrame(full, np.uint16, ptr=arena + w * 8 * 4)          # four rows into the arena
+    out = DeviceFrame(full, np.uint16, ptr=arena)                        # overlaps lay0, shifted by four rows
+    lay0.upload(L[0].array)
+    lay1 = DeviceFrame.from_host(L[1])
+    want = orc.chain_color_over(L, m, orc.transfer_table(0), None)
+    chain_color_over([(out, [lay0, lay1])], m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE)
+    _lib.check(cvs.cvs_stream_sync(None))
+    assert cvs.cvs_chain_last_was_fused() == 0
+    assert_same_f16(out.download().array, want.array, "shifted overlap")
+    cvs.cvs_free(arena)
+
+
 @pytest.mark.parametrize("nlayers", [2, 3, 4])
 def test_chain_fused_with_live_divides(cvs, orc, nlayers):
     """Every layer translucent (alpha 0, 1 and in between, per pixel): the x/1.0 shortcut of the kernel

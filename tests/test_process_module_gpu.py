@@ -286,6 +286,33 @@ def test_pull_queue_delivers_frames(process, bt, workers):
     del items
 
 
+def test_pull_queue_may_lose_its_last_reference_on_its_own_worker(process, bt):
+    """The last Python reference to a queue can go away while a request is pending: the pending item keeps the queue
+    alive, the worker drops that reference after the callback, and the queue is then deallocated ON the worker thread --
+    which must neither join itself nor touch the freed object on its way out."""
+    import gc
+    import threading
+    solid = process.SolidColorVideoSource((0.25, 0.5, 0.75, 1.0), bt.box2i(0, 0, 31, 17))
+    for workers in (1, 3):
+        done, seen = threading.Event(), []
+
+        def cb(i, frame, user):
+            seen.append((i, frame.pixel(3, 3)))
+            done.set()
+        q = process.VideoPullQueue(workers=workers)
+        item = q.enqueue(solid, 4, bt.box2i(0, 0, 31, 17), cb, None)
+        del q                                               # the item holds the only reference now
+        assert done.wait(30)
+        assert seen[0][0] == 4 and abs(seen[0][1].g - 0.5) < 1e-3
+        del item
+        gc.collect()
+    # the process is still healthy: another queue works
+    done = threading.Event()
+    q = process.VideoPullQueue()
+    q.enqueue(solid, 0, bt.box2i(0, 0, 3, 3), lambda i, f, u: done.set(), None)
+    assert done.wait(30)
+
+
 def test_preview_pulls_convert_on_the_device(process, bt, orc):
     """get_frame_argb32 equals get_frame_f16(...).to_argb32_bytes() (RgbaFrameF16.c:114-149 against the oracle);
     get_frame_rgba8 is the software widget's sRGB bytes (widget_gl.c:291-307)."""
