@@ -66,6 +66,7 @@ CVS_EXPORT void video_color_xyz_to_srgb(rgba_frame_f16 *frame) {
 
 static __thread int t_last_fused = -1;
 CVS_EXPORT int cvs_chain_last_was_fused(void) { return t_last_fused; }
+CVS_EXPORT int cvs_chain_last_launch_count(void) { return cvk_chain_count(); }
 
 static bool same_box(const box2i *a, const box2i *b) {
     return a->min.x == b->min.x && a->min.y == b->min.y && a->max.x == b->max.x && a->max.y == b->max.y;
@@ -177,6 +178,7 @@ CVS_EXPORT int cvs_chain_color_over_f16_dev(const cvs_chain_job *jobs, int njobs
     }
     if (uniform > 4) uniform = 0;
     int rc = 0;
+    cvk_chain_count_reset();
     for (int first = 0; rc == 0 && first < njobs; ) {       /* runs of mutually independent jobs, one (set of) launch(es) each */
         int end = first + 1;
         while (end < njobs && !job_depends_on_earlier(jobs, first, end)) end++;

@@ -332,6 +332,8 @@ Tuning tuning() {
     return t;
 }
 
+thread_local int t_launches = 0;      // launches of the trip-loop kernel the calling thread's last chain call made
+
 int chain_dispatch(const cvk_chain_job *jobs, int njobs, int uniform_layers, const Mat &mat,
                    const uint16_t *pre, const uint16_t *post, int cus, void *stream) {
     const unsigned grid = (unsigned)(cus > 0 ? cus : 256);
@@ -378,11 +380,15 @@ int chain_dispatch(const cvk_chain_job *jobs, int njobs, int uniform_layers, con
         }
         if (rc != 0) return rc;
         first += n;
+        t_launches++;
     }
     return 0;
 }
 
 }  // namespace
+
+extern "C" void cvk_chain_count_reset(void) { t_launches = 0; }
+extern "C" int cvk_chain_count(void) { return t_launches; }
 
 extern "C" int cvk_chain_color_over(const cvk_chain_job *jobs, int njobs, int uniform_layers, const float *m,
                                     const uint16_t *pre, const uint16_t *post, int cus, void *stream) {

@@ -82,6 +82,10 @@ typedef struct {
 int cvk_chain_color_over(const cvk_chain_job *jobs, int njobs, int uniform_layers, const float *m,
                          const uint16_t *pre_lut, const uint16_t *post_lut, int cus, void *stream);
 
+/* launches of the trip-loop kernel since the calling thread's last reset (a batch is cut into launches of ~8 4K frames) */
+void cvk_chain_count_reset(void);
+int cvk_chain_count(void);
+
 /* the same machinery crossfading two-layer jobs: out = cross(layer[0], layer[1]), weights wa = 1 - mix_b, wb = mix_b */
 int cvk_chain_cross(const cvk_chain_job *jobs, int njobs, float wa, float wb, int cus, void *stream);
 

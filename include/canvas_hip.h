@@ -385,6 +385,8 @@ CVS_EXPORT int cvs_chain_color_over_f16_dev(const cvs_chain_job *jobs, int njobs
 /* how the last chain call ran: 1 = single fused kernel, 0 = node-by-node device kernels
  * (windows did not all cover the output's full window) */
 CVS_EXPORT int cvs_chain_last_was_fused(void);
+/* kernel launches the calling thread's last fused chain call was cut into (about eight 4K frames' worth of bytes each) */
+CVS_EXPORT int cvs_chain_last_launch_count(void);
 /* crossfade of two f16 frames, f16 result: widen, video_mix_cross_f32 (video_mix.c:107-235), truncate -- one launch when
  * every window is the whole output frame */
 CVS_EXPORT int cvs_mix_cross_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *a, const rgba_frame_f16 *b, float mix_b, cvs_stream_t stream);

@@ -18,7 +18,8 @@ def pytest_sessionstart(session):
     import glob
     have = (os.path.exists(os.path.join(ROOT, "canvas_amd", "libcanvas_hip.so"))
             and glob.glob(os.path.join(ROOT, "fluggo", "media", "process*.so"))
-            and os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")))
+            and os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so"))
+            and os.path.exists(os.path.join(ROOT, "oracle", "liboracle_fma.so")))
     if not have:
         import __graft_entry__
         __graft_entry__.build()
@@ -30,3 +31,13 @@ def orc():
     import oracle
     oracle.lib()
     return oracle
+
+
+@pytest.fixture(scope="module")
+def cvs():
+    """The library, initialised on device 0 (GPU tests; modules with their own `cvs` fixture shadow this one)."""
+    from canvas_amd import _lib
+    lib = _lib.load()
+    assert lib.cvs_init(0) == 0, _lib.last_error()
+    lib.init_half()
+    return lib

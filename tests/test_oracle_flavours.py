@@ -6,10 +6,14 @@ restatement compiled both ways gives the two flavours of the oracle (oracle/Make
 
   * CPU: on the colour + over chain (configs 2 and 4) the two flavours differ in a few values per hundred thousand, by
     one half code -- "1 ulp in half" is the width of the reference's own build-to-build spread.  One exception class,
-    measured: where the Y'PbPr matrix cancels (Pb, Pr near zero) and a small blended alpha then divides the result, the
-    f32 rounding difference is amplified and the two BUILDS OF THE REFERENCE land tens of half codes apart (1 value in
-    147 456 on random-alpha input, 31 codes, |difference| 7e-6 at a value of 4e-4).  The bound below is therefore:
-    at most one code apart, except for at most 1 value in 10 000, each of those within 2^-16 of the frame's value range;
+    measured: where the Y'PbPr matrix cancels (Pb, Pr near zero: the result is orders of magnitude smaller than the
+    terms it is the sum of) one f32 rounding difference is many half codes of the tiny result, and the two BUILDS OF THE
+    REFERENCE land tens of codes apart -- on the BASELINE input too (3840 x 256 px: 48 codes at worst), more so where a
+    small blended alpha then divides (1 value in 147 456 on random-alpha input, 31 codes, |difference| 7e-6 at 4e-4).
+    A second, milder class: the colour filter's result is truncated to half BEFORE the stack (color.c:132), so a
+    one-code difference there can come out of the blend and the final truncation as two codes.
+    The bound below is therefore: at most one code apart, except for at most 1 value in 10 000, each of those within
+    one half-ulp of the frame's value range in absolute terms (2^-10 of the largest magnitude);
   * GPU: the library's output is bit-equal to the gcc flavour and inside the same bound from the clang flavour.
 """
 import numpy as np
@@ -33,16 +37,13 @@ def half_code_distance(a, b):
     return d
 
 
-def assert_within_build_spread(orc, a, b, what, strict=False):
+def assert_within_build_spread(orc, a, b, what):
     d = half_code_distance(a, b)
-    if strict:
-        assert d.max() <= 1, (what, int(d.max()))
-        return d
     far = d > 1
     assert far.sum() <= max(1, d.size // 10000), (what, int(far.sum()), int(d.max()))
     if far.any():
         va, vb = orc.half_to_float(a).astype(np.float64), orc.half_to_float(b).astype(np.float64)
-        assert np.abs(va - vb)[far].max() <= 2.0 ** -16 * max(1.0, np.abs(va[np.isfinite(va)]).max()), what
+        assert np.abs(va - vb)[far].max() <= 2.0 ** -10 * max(1.0, np.abs(va[np.isfinite(va)]).max()), what
     return d
 
 
@@ -74,7 +75,7 @@ def test_the_two_reference_builds_differ_by_at_most_one_half_code(orc, case, con
     w, h = 256, 144
     layers = layers_for(case, w, h)[:2 if config == 2 else 3]
     gcc, fma = both_flavours(orc, layers, M if config == 2 else None, orc.transfer_table(0) if config == 2 else None)
-    d = assert_within_build_spread(orc, gcc, fma, (case, config), strict=(case == "baseline"))
+    d = assert_within_build_spread(orc, gcc, fma, (case, config))
     assert d.max() >= 1, "contraction changed nothing here: the case does not exercise the tolerance"
 
 
@@ -114,4 +115,4 @@ def test_library_is_bit_equal_to_gcc_build_and_within_one_code_of_clang_build(cv
     assert cvs.cvs_chain_last_was_fused() == 1
     got = out.download().array
     assert np.array_equal(canon_f16(got), canon_f16(gcc)), "not bit-equal to the gcc / no-contraction build of the reference"
-    assert_within_build_spread(orc, got, fma, "library vs the clang / contraction build", strict=(case == "baseline"))
+    assert_within_build_spread(orc, got, fma, "library vs the clang / contraction build")

@@ -9,7 +9,7 @@ export CANVAS_SYNTH_CACHE=/tmp/canvas_synth
 PASSES=${1:-4}
 OUT=gpurun_out/level
 rm -rf $OUT && mkdir -p $OUT
-B="python3 bench.py --no-cpu-baseline --steps 8 --warmup 3 --report-base"
+B="python3 bench.py --no-cpu-baseline --no-extra --steps 8 --warmup 3"
 PMCG=(
  "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_TAG_STALL_sum GRBM_GUI_ACTIVE GRBM_EA_BUSY"
  "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum GRBM_UTCL2_BUSY GRBM_TC_BUSY"

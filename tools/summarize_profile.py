@@ -14,15 +14,15 @@ for d in ["prof_pmc1", "prof_pmc2", "prof_fetch", "prof_write"]:
     f = newest("gpurun_out/%s/*/*_counter_collection.csv" % d)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "k_chain" in r["Kernel_Name"]:
+        if "k_chain" in r["Kernel_Name"] and "k_chain_tail" not in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in agg.items():
         out[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
-FRAMES = 64            # bench.py default: frames per launch
+FRAMES = 8             # frames per LAUNCH: bench.py's 64-frame step is cut into launches of 8 (chain_ops.hip kBytesPerLaunch)
 px = FRAMES * 3840 * 2160
 fetch = out["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
 write = out["WRITE_SIZE"]["mean_per_launch"] * 1024
-json.dump({"kernel": desc, "command": "tools/profile_bench.sh (rocprofv3 --kernel-trace --pmc <one group per run> -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline; 64 frames per launch)",
+json.dump({"kernel": desc, "command": "tools/profile_bench.sh (rocprofv3 --kernel-trace --pmc <one group per run> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra; 64 frames per step = 8 launches of 8 frames)",
            "pixels_per_launch": px, "counters": out,
            "derived": {"fetch_bytes_per_launch_x2_corrected": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
                        "algorithmic_bytes_per_launch": px * 24,
