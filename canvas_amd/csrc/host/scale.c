@@ -801,6 +801,34 @@ CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame
     hipStream_t s = cvs_pick_stream(stream);
     /* the blurred frame covers the source's current window (blur: output window = source window) */
     const box2i *sw = &source->current_window;
+    /* halving on both axes after an odd blur: one sweep, no intermediate frame (blur_halve_ops.hip) */
+    if (fx == 0.5f && fy == 0.5f && (ntaps & 1) && !(atomic_load(&g_fir_path) & CVS_FIR_PATH_TABLES)) {
+        fir_filter f = { NULL, 0, 0 };
+        filter_createLanczos(0.5f, ksize, 0.0f, &f);
+        const box2i *tf = &target->full_window;
+        bool usable = f.coeff && f.center == f.width / 2 && cvk_blur_halve_supported(ntaps, f.width) &&
+                      tf->min.x > -(1 << 22) && tf->max.x < (1 << 22) && tf->min.y > -(1 << 22) && tf->max.y < (1 << 22);
+        for (int k = 0; usable && k < f.width; k++) usable = isfinite(f.coeff[k]);
+        for (int k = 0; usable && k < ntaps; k++) usable = isfinite(taps[k]);
+        if (usable) {
+            cvk_blur_halve_params bp;
+            memset(&bp, 0, sizeof bp);
+            bp.target = cvs_view(target->data, tf);
+            bp.source = cvs_view((void *)source->data, &source->full_window);
+            bp.in_half = 1; bp.out_half = 1;
+            bp.tx0 = tf->min.x; bp.ty0 = tf->min.y; bp.tx1 = tf->max.x; bp.ty1 = tf->max.y;
+            bp.sx0 = sw->min.x; bp.sy0 = sw->min.y; bp.sx1 = sw->max.x; bp.sy1 = sw->max.y;
+            bp.ntaps1 = ntaps; bp.ntaps2 = f.width;
+            memcpy(bp.taps1, taps, sizeof(float) * (size_t)ntaps);
+            memcpy(bp.taps2, f.coeff, sizeof(float) * (size_t)f.width);
+            filter_free(&f);
+            int rc = cvk_blur_halve(&bp, cvs_cus(), s);
+            if (rc != 0) { cvs_set_error("blur + halving launch failed: %s", hipGetErrorString((hipError_t)rc)); box2i_set_empty(&target->current_window); return -1; }
+            target->current_window = target->full_window;
+            return 0;
+        }
+        filter_free(&f);
+    }
     rgba_frame_f32 mid = { NULL, *sw, *sw };
     mid.data = cvs_pool_malloc(cvs_box_pixels(sw) * sizeof(rgba_f32), s);
     if (!mid.data) { box2i_set_empty(&target->current_window); return -1; }

@@ -1,0 +1,265 @@
+// blur_halve_ops.hip -- BASELINE config 3 in ONE sweep: separable blur (one odd tap list, 1:1) followed by the Lanczos
+// resampler at factor 1/2 on both axes, f16 (or f32) in, f16 (or f32) out, nothing in between ever in HBM.
+//
+// What it replaces: k_blur<NT1,...,1> writing a full-size f32 frame and k_blur<NT2,...,2> reading it back -- for a 4K
+// frame 133 MB written + 185 MB read (1.39x: the decimating pass re-reads its halo rows) beside 66 MB of source and 17 MB
+// of result.  Both sums are the video_scale.c gather structure: every sum starts at 0.0f and takes its
+// taps in ascending order with separately rounded multiply and add; the order of the four passes is the reference order
+// of the two nodes: blur x, blur y (the blur node, horizontal then vertical), resample x, resample y (x pass then y pass).
+//
+//   B(x, y)  = sum_j w1[j] * ( sum_i w1[i] * S(x - c1 + i, y - c1 + j) )            S = source, 0 outside its window
+//   T(t, u)  = sum_j w2[j] * ( sum_i w2[i] * B(2t - c2 + i, 2u - c2 + j) )          B = 0 outside the SOURCE's window:
+// the blur node's output window is its source's window, and the resampler skips taps outside ITS source's window
+// (video_scale.c:106-107,211-212), so a blurred pixel outside the window must contribute nothing -- it is NOT the
+// blur formula evaluated there.
+//
+// Sweep (one workgroup = a strip of W source columns x a segment of target rows), per source row:
+//   load (one pixel per lane, two rows ahead) -> LDS row S -> barrier -> H1 from NT1 neighbours -> ring1 (registers) ->
+//   V1 = blurred row, zeroed outside the window -> LDS row B (de-interleaved by column parity) -> [next step, after its
+//   barrier] H2 on the target-column lanes from NT2 neighbours -> ring2 (registers) -> every second blurred row V2 =
+//   one target row, stored.  ONE barrier per source row: row B of step i is read in step i + 1 behind that step's
+//   barrier, both LDS rows are double-buffered.
+// Second stage on ALL lanes: a strip has fewer than W / 2 target columns, so the lower half of the workgroup takes the
+// (r, g) pair of each target pixel and the upper half the (b, a) pair -- every wave carries the same work (with whole
+// pixels on the first OUTW lanes two of four waves did all of the resampler's arithmetic and the others waited at the barrier).
+// Both rings have RL = 12 slots (NT1 <= 12, NT2 == 11) so that one unrolled body of 12 steps sees every slot as a
+// compile-time register index and the emit parity (every second blurred row) is a compile-time fact as well.
+//
+// Cost model (4K -> 1080p, 9 + 11 taps): the arithmetic is the sum of the two kernels' (~105 packed multiply/add per
+// source pixel at one pixel per lane) times the halo factor of a strip x segment decomposition, which is larger here
+// because every segment re-blurs the resampler's 10 halo rows; the traffic falls from ~400 MB to ~100 MB.
+#include <type_traits>
+#include <utility>
+#include "kernels.h"
+#include "chain_math.hpp"
+
+namespace {
+
+using cvs::f32x2;
+struct Px { f32x2 rg, ba; };
+
+constexpr int RL = 12;                     // ring length of both rings; the step loop is unrolled RL times
+
+template <class F, int... Js>
+__device__ __forceinline__ void each_slot(F &f, std::integer_sequence<int, Js...>) {
+    (void)(f(std::integral_constant<int, Js>{}) && ...);
+}
+
+template <bool INH>
+__device__ __forceinline__ float4 fetch_px(const char *p, bool live) {
+    if (!live) return make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if constexpr (INH) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(p);
+        return make_float4(cvs::h2f(v.x & 0xFFFFu), cvs::h2f(v.x >> 16), cvs::h2f(v.y & 0xFFFFu), cvs::h2f(v.y >> 16));
+    } else {
+        return *reinterpret_cast<const float4 *>(p);
+    }
+}
+
+// sum of NT taps over values fetched by `at(k)`, ascending k, all products first (a packed add right behind the packed
+// multiply it depends on costs a hazard slot), same rounding and order as mul/add in sequence
+template <int NT, class At>
+__device__ __forceinline__ Px fir(const float (&w)[NT], At at) {
+    f32x2 prg[NT], pba[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        const Px v = at(k);
+        prg[k] = v.rg * w[k];
+        pba[k] = v.ba * w[k];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    Px o = { f32x2{ 0.0f, 0.0f }, f32x2{ 0.0f, 0.0f } };
+#pragma unroll
+    for (int k = 0; k < NT; k++) {
+        o.rg = o.rg + prg[k];
+        o.ba = o.ba + pba[k];
+    }
+    return o;
+}
+
+// the same for one channel pair
+template <int NT, class At>
+__device__ __forceinline__ f32x2 fir1(const float (&w)[NT], At at) {
+    f32x2 p[NT];
+#pragma unroll
+    for (int k = 0; k < NT; k++) p[k] = at(k) * w[k];
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 o = { 0.0f, 0.0f };
+#pragma unroll
+    for (int k = 0; k < NT; k++) o = o + p[k];
+    return o;
+}
+
+template <int NT1, int NT2, int W, bool INH>
+__global__ __launch_bounds__(W) void k_blur_halve(cvk_blur_halve_params bp) {
+    static_assert(NT1 % 2 == 1 && NT2 % 2 == 1 && NT1 <= RL && NT2 < RL && RL % 2 == 0, "ring layout");
+    constexpr int C1 = NT1 / 2, C2 = NT2 / 2;
+    constexpr int OUTW = (W - NT1 - NT2 + 1) / 2 + 1;          // target columns per strip
+    constexpr int PITCH = W + 16, HALF = W / 2 + 16;
+    __shared__ float4 rowS[2][PITCH];                          // source row, widened
+    __shared__ float4 rowB[2][2][HALF];                        // blurred row, [buffer][column parity][column / 2]
+    const int lane = threadIdx.x;
+    const int xo = bp.tx0 + (int)blockIdx.x * OUTW;            // first target column of the strip
+    const int sfirst = 2 * xo - C2 - C1;                       // source column of lane 0
+    const int bcol = sfirst + C1 + lane;                       // the blurred column this lane produces (valid for lane <= W - NT1)
+    static_assert(OUTW <= W / 2, "the two halves of the workgroup share the strip's target columns");
+    const int tl = lane & (W / 2 - 1);                         // target column index within the strip
+    const int pair = lane / (W / 2);                           // 0: this lane carries (r, g) of its target pixel, 1: (b, a); wave-uniform
+    const int tcol = xo + tl;                                  // the target column this lane produces (tl < OUTW)
+    const bool out_live = tl < OUTW && tcol <= bp.tx1;
+    const bool bcol_live = bcol >= bp.sx0 && bcol <= bp.sx1;
+    const int ta = bp.ty0 + (int)blockIdx.y * bp.rows_per_wg;
+    const int tb = min(ta + bp.rows_per_wg - 1, bp.ty1);
+    const int ys0 = 2 * ta - C2 - C1;                          // first source row the segment needs
+    const int steps = 2 * (tb - ta) + NT2 + NT1 - 1;
+
+    float w1[NT1], w2[NT2];
+#pragma unroll
+    for (int k = 0; k < NT1; k++) w1[k] = bp.taps1[k];
+#pragma unroll
+    for (int k = 0; k < NT2; k++) w2[k] = bp.taps2[k];
+
+    constexpr size_t SPX = INH ? 8 : 16;
+    const size_t srow = (size_t)bp.source.pitch * SPX;
+    const int scol = sfirst + lane;
+    const bool scol_live = scol >= bp.sx0 && scol <= bp.sx1;
+    const char *sbase = reinterpret_cast<const char *>(bp.source.data) + (ptrdiff_t)(scol - bp.source.fx0) * (ptrdiff_t)SPX;
+    const size_t tpx = bp.out_half ? 8 : 16;
+    char *tbase = reinterpret_cast<char *>(bp.target.data) + (ptrdiff_t)(tcol - bp.target.fx0) * (ptrdiff_t)tpx + (size_t)pair * (tpx / 2);
+    const size_t trow = (size_t)bp.target.pitch * tpx;
+
+    if (lane < PITCH - W) { rowS[0][W + lane] = make_float4(0.f, 0.f, 0.f, 0.f); rowS[1][W + lane] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    if (lane < 2 * (HALF - W / 2)) {
+        const int par = lane & 1, slot = W / 2 + (lane >> 1);
+        rowB[0][par][slot] = make_float4(0.f, 0.f, 0.f, 0.f); rowB[1][par][slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    Px ring1[RL];
+    f32x2 ring2[RL];
+#pragma unroll
+    for (int k = 0; k < RL; k++) { ring1[k].rg = ring1[k].ba = ring2[k] = f32x2{ 0.0f, 0.0f }; }
+
+    auto fetch_row = [&](int ys, bool wanted) -> float4 {
+        const bool live = wanted && scol_live && ys >= bp.sy0 && ys <= bp.sy1;
+        return fetch_px<INH>(sbase + (ptrdiff_t)(ys - bp.source.fy0) * (ptrdiff_t)srow, live);
+    };
+    // three rows in flight, slot = row % 3 (RL is a multiple of 3, so the slot is a compile-time fact of the unrolled body)
+    static_assert(RL % 3 == 0, "prefetch slots rotate with the unrolled step index");
+    float4 pre[3];
+    pre[0] = fetch_row(ys0, true);
+    pre[1] = fetch_row(ys0 + 1, steps > 1);
+    // column part of "is this blurred pixel inside the blurred frame's window", as an all-ones / all-zeros word
+    const uint32_t col_mask = bcol_live ? 0xFFFFFFFFu : 0u;
+
+    // step i: source row ys0 + i enters; blurred row rb = i - (NT1 - 1) leaves the first ring (rb >= 0) and is handed over
+    // through LDS; in step i + 1 it enters the second ring; blurred row rb completes target row ta + (rb - (NT2 - 1)) / 2
+    // when that is a whole number >= 0.  The loop runs one step past the last source row to drain the hand-over.
+    for (int i0 = 0; i0 <= steps; i0 += RL) {
+        auto step = [&](auto jc) -> bool {
+            constexpr int j = decltype(jc)::value;             // == i % RL
+            const int i = i0 + j;
+            if (i > steps) return false;                       // uniform over the workgroup
+            pre[(j + 2) % 3] = fetch_row(ys0 + i + 2, i + 2 < steps);
+            if (i < steps) rowS[i & 1][lane] = pre[j % 3];
+            __syncthreads();                                   // row S of this step and row B of the previous one are visible
+
+            // ---- second stage first (it consumes what the previous step produced): blurred row rb2 = i - NT1
+            constexpr int s2 = (j + RL - (NT1 % RL)) % RL;     // ring2 slot of rb2 = i - NT1 (== rb2 % RL when i0 % RL == 0)
+            const int rb2 = i - NT1;
+            if (rb2 >= 0) {
+                // this lane's channel pair of the blurred row: 8 of the 16 bytes of each float4
+                const float2 *bb0 = reinterpret_cast<const float2 *>(&rowB[(i + 1) & 1][0][0]) + pair;       // written in step i - 1
+                const float2 *bb1 = reinterpret_cast<const float2 *>(&rowB[(i + 1) & 1][1][0]) + pair;
+                const int jl = tl < OUTW ? tl : 0;             // lanes past the strip's last target column stay inside the row
+                ring2[s2] = fir1<NT2>(w2, [&](int k) { const float2 v = ((k & 1) ? bb1 : bb0)[2 * (jl + (k >> 1))]; return f32x2{ v.x, v.y }; });
+                // rb2 - (NT2 - 1) even <=> rb2 even (NT2 odd) <=> i - NT1 even <=> j odd (NT1 odd, RL even)
+                if constexpr (((j - NT1) & 1) == 0) {
+                    if (rb2 >= NT2 - 1) {
+                        const int t = ta + (rb2 - (NT2 - 1)) / 2;
+                        const f32x2 o = fir1<NT2>(w2, [&](int k) { return ring2[(s2 + RL - (NT2 - 1) + k) % RL]; });
+                        if (out_live && t <= tb) {
+                            char *dst = tbase + (size_t)(t - bp.target.fy0) * trow;
+                            if (bp.out_half) *reinterpret_cast<uint32_t *>(dst) = cvs::f2h_rz2(o.x, o.y);
+                            else *reinterpret_cast<float2 *>(dst) = make_float2(o.x, o.y);
+                        }
+                    }
+                }
+            }
+
+            // ---- first stage: H1 of this source row, then the blurred row it completes
+            if (i < steps) {
+                const float4 *sb = rowS[i & 1];
+                ring1[j] = fir<NT1>(w1, [&](int k) { const float4 v = sb[lane + k]; return Px{ f32x2{ v.x, v.y }, f32x2{ v.z, v.w } }; });
+                if (i >= NT1 - 1) {
+                    Px b = fir<NT1>(w1, [&](int k) { return ring1[(j + RL - (NT1 - 1) + k) % RL]; });
+                    const int by = ys0 + i - C1;               // the blurred row just completed
+                    // outside the blurred frame's window: a skipped tap, i.e. zero (AND with a mask: four selects cost more)
+                    const uint32_t m = (by >= bp.sy0 && by <= bp.sy1) ? col_mask : 0u;
+                    rowB[i & 1][lane & 1][lane >> 1] = make_float4(__uint_as_float(__float_as_uint(b.rg.x) & m), __uint_as_float(__float_as_uint(b.rg.y) & m),
+                                                                   __uint_as_float(__float_as_uint(b.ba.x) & m), __uint_as_float(__float_as_uint(b.ba.y) & m));
+                }
+            }
+            return true;
+        };
+        each_slot(step, std::make_integer_sequence<int, RL>{});
+    }
+}
+
+template <class K>
+int resident_per_cu(K kernel, int block) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, 0) != hipSuccess || n < 1) n = 1;
+    return n;
+}
+
+template <int NT1, int NT2, int W>
+int launch(cvk_blur_halve_params bp, int cus, hipStream_t s) {
+    constexpr int OUTW = (W - NT1 - NT2 + 1) / 2 + 1;
+    const int cols = bp.tx1 - bp.tx0 + 1, rows = bp.ty1 - bp.ty0 + 1;
+    const int strips = (cols + OUTW - 1) / OUTW;
+    static int occ[2] = { 0, 0 };
+    int &mine = occ[bp.in_half ? 1 : 0];
+    if (!mine) mine = bp.in_half ? resident_per_cu(k_blur_halve<NT1, NT2, W, true>, W) : resident_per_cu(k_blur_halve<NT1, NT2, W, false>, W);
+    if (bp.rows_per_wg <= 0) {
+        // one wave of resident workgroups; a segment never shorter than its own halo (NT1 + NT2 - 2 source rows = that many / 2 target rows)
+        int segs = (mine * cus) / strips;
+        if (segs < 1) segs = 1;
+        int r = (rows + segs - 1) / segs;
+        const int lo = (NT1 + NT2) / 2;
+        if (r < lo) r = lo;
+        if (r > rows) r = rows;
+        bp.rows_per_wg = r;
+    }
+    dim3 grid((unsigned)strips, (unsigned)((rows + bp.rows_per_wg - 1) / bp.rows_per_wg));
+    if (bp.in_half) hipLaunchKernelGGL((k_blur_halve<NT1, NT2, W, true>), grid, dim3(W), 0, s, bp);
+    else            hipLaunchKernelGGL((k_blur_halve<NT1, NT2, W, false>), grid, dim3(W), 0, s, bp);
+    return (int)hipGetLastError();
+}
+
+template <int W>
+int pick(const cvk_blur_halve_params &bp, int cus, hipStream_t s) {
+    switch (bp.ntaps1) {
+    case 3:  return launch<3, 11, W>(bp, cus, s);
+    case 5:  return launch<5, 11, W>(bp, cus, s);
+    case 7:  return launch<7, 11, W>(bp, cus, s);
+    case 9:  return launch<9, 11, W>(bp, cus, s);
+    case 11: return launch<11, 11, W>(bp, cus, s);
+    default: return (int)hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+extern "C" int cvk_blur_halve_supported(int ntaps1, int ntaps2) {
+    return ntaps2 == 11 && (ntaps1 == 3 || ntaps1 == 5 || ntaps1 == 7 || ntaps1 == 9 || ntaps1 == 11);
+}
+
+extern "C" int cvk_blur_halve(const cvk_blur_halve_params *bp, int cus, void *stream) {
+    if (bp->tx1 < bp->tx0 || bp->ty1 < bp->ty0) return 0;
+    if (!cvk_blur_halve_supported(bp->ntaps1, bp->ntaps2)) return (int)hipErrorInvalidValue;
+    static int env_w = -1;
+    if (env_w < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_HALVE_WIDTH"); env_w = e ? atoi(e) : 0; }
+    const int cols = bp->tx1 - bp->tx0 + 1;
+    const int width = env_w == 128 || env_w == 256 ? env_w : (cols <= 60 ? 128 : 256);
+    return width == 128 ? pick<128>(*bp, cus, (hipStream_t)stream) : pick<256>(*bp, cus, (hipStream_t)stream);
+}

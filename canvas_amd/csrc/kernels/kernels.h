@@ -154,6 +154,22 @@ typedef struct {
 int cvk_blur_supported(int ntaps, int step);
 int cvk_blur(const cvk_blur_params *bp, int cus, void *stream);
 
+/* blur (ntaps1 odd, one list for every line) followed by the Lanczos halving resampler (ntaps2 taps, target line t reads
+ * blurred lines 2t - ntaps2/2 + k), both separable, in one sweep: blur_halve_ops.hip.  The blurred frame exists only
+ * inside the source's current window (sx0..sy1); target rectangle in target coordinates. */
+typedef struct {
+    cvk_view target, source;
+    int in_half, out_half;
+    int tx0, ty0, tx1, ty1;
+    int sx0, sy0, sx1, sy1;
+    int ntaps1, ntaps2;
+    int rows_per_wg;           /* 0: let the launcher choose */
+    int pad;
+    float taps1[16], taps2[16];
+} cvk_blur_halve_params;
+int cvk_blur_halve_supported(int ntaps1, int ntaps2);
+int cvk_blur_halve(const cvk_blur_halve_params *bp, int cus, void *stream);
+
 /* display / export edge: f16 RGBA -> 4 bytes per pixel through a 65536-entry half->u8 table (device pointer,
  * 16-byte aligned); dst is packed over the rectangle */
 enum { CVK_DISPLAY_RGBA8 = 0, CVK_DISPLAY_ARGB32_PREMUL = 1 };

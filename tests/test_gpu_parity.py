@@ -846,6 +846,32 @@ def test_config3_pipeline_f16(cvs, orc, ssize, tsize, fx, fy):
         assert_same_f16(got.array, want.array, "config 3 pipeline %r -> %r" % (ssize, tsize))
 
 
+@pytest.mark.parametrize("ntaps", [3, 5, 7, 9, 11, 13])          # 13: no fused instance, the two-launch form
+@pytest.mark.parametrize("ssize,scur,tsize", [
+    ((300, 170), None, (150, 85)),                     # several strips at 128 and 256 lanes, several segments
+    ((300, 170), (9, 6, 280, 150), (150, 85)),         # source window inside its buffer: blurred pixels OUTSIDE it must count as skipped taps
+    ((131, 77), (0, 0, 130, 76), (80, 50)),            # target larger than half the source: lines whose taps all fall outside
+    ((64, 36), (20, 10, 40, 30), (32, 18)),            # a window far from the buffer's edges
+])
+def test_blur_then_halving_in_one_sweep(cvs, orc, ntaps, ssize, scur, tsize):
+    """cvs_blur_lanczos_f16_dev at factor 1/2 with an odd blur runs blur x, blur y, resample x, resample y in ONE kernel
+    (blur_halve_ops.hip): no f32 frame in between.  Same sums in the same order as the two nodes of the oracle."""
+    rng = np.random.default_rng(ntaps * 1000 + ssize[0])
+    taps = rng.uniform(0.02, 0.3, ntaps).astype(np.float32)
+    taps = (taps / taps.sum(dtype=np.float32)).astype(np.float32)
+    full = (0, 0, ssize[0] - 1, ssize[1] - 1)
+    px = synth.layer_pixels(ssize[0], ssize[1], 1, 5)
+    layer = HostFrame(full, np.uint16, px, scur)
+    want = _oracle_config3(orc, layer, tsize, taps, 0.5, 0.5)
+    d_src = DeviceFrame.from_host(layer)
+    d_out = DeviceFrame((0, 0, tsize[0] - 1, tsize[1] - 1), np.uint16)
+    _lib.check(cvs.cvs_memset(d_out.ptr, 0x5A, d_out.nbytes, None))
+    _lib.check(cvs.cvs_blur_lanczos_f16_dev(d_out.ref(), d_src.ref(), f32p(taps), ntaps, C.c_float(0.5), C.c_float(0.5), 3, None))
+    got = d_out.download()
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f16(got.array, want.array, "blur %d taps + halving, %r window %r" % (ntaps, ssize, scur))
+
+
 def test_config3_full_size_properties(cvs, orc):
     """3840x2160 -> 1920x1080: a constant frame stays constant away from the borders (taps sum to 1 within
     float rounding), and the top-left corner block equals the oracle run on a crop that contains its footprint."""

@@ -16,6 +16,8 @@ template <int OP>
 __global__ void k(float *out, int iters, float seed) {
     float a[8]; f32x2 p[8];
     for (int i = 0; i < 8; i++) { a[i] = seed + threadIdx.x * 1e-3f + i; p[i] = f32x2{ a[i], a[i] + 0.5f }; }
+    unsigned long long smask = 0x5555555555555555ull ^ (unsigned long long)iters;
+    float vmask = __uint_as_float(0xFFFFFFFFu ^ (threadIdx.x == 12345 ? 1u : 0u));
     long long t0 = clock64();
     for (int it = 0; it < iters; it++) {
 #define MUL(i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(seed));
@@ -30,6 +32,12 @@ __global__ void k(float *out, int iters, float seed) {
 #define DIVSC(i) asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(a[i]) : "v"(seed) : "vcc");
 #define DIVFX(i) asm volatile("v_div_fixup_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(seed));
 #define CNDM(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(seed));
+#define CNDS(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(seed), "s"(smask));
+#define CNDCMP(i) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(seed) : "vcc");
+#define ANDM(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(vmask));
+#define PKADD(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(p[(i + 1) & 7]));
+#define PKADDDEP(i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[0]) : "v"(p[(i + 1) & 7]));
+#define MOV(i) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(seed));
 #define LSHLSDWA(i) asm volatile("v_lshlrev_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "+v"(a[i]) : "v"(1));
         if (OP == 0) { REP8(MUL) REP8(MUL) }
         if (OP == 1) { REP8(FMA) REP8(FMA) }
@@ -44,6 +52,12 @@ __global__ void k(float *out, int iters, float seed) {
         if (OP == 10) { REP8(DIVFX) REP8(DIVFX) }
         if (OP == 11) { REP8(CNDM) REP8(CNDM) }
         if (OP == 12) { REP8(LSHLSDWA) REP8(LSHLSDWA) }
+        if (OP == 13) { REP8(CNDS) REP8(CNDS) }
+        if (OP == 14) { REP8(CNDCMP) REP8(CNDCMP) }
+        if (OP == 15) { REP8(ANDM) REP8(ANDM) }
+        if (OP == 16) { REP8(PKADD) REP8(PKADD) }
+        if (OP == 17) { REP8(PKADDDEP) REP8(PKADDDEP) }
+        if (OP == 18) { REP8(MOV) REP8(MOV) }
     }
     long long t1 = clock64();
     float s = 0;
@@ -74,11 +88,12 @@ static void run(const char *name, float *d, int waves_per_simd) {
 
 int main() {
     float *d; CK(hipMalloc((void **)&d, (8 << 20) + 64));
-    for (int w : { 1, 2, 4 }) {
+    for (int w : { 2, 3, 4 }) {
         run<0>("v_mul_f32", d, w); run<1>("v_fma_f32", d, w); run<2>("v_pk_mul_f32", d, w); run<3>("v_pk_fma_f32", d, w);
         run<4>("v_cvt_f32_f16", d, w); run<5>("v_cvt_f32_f16_sdwa", d, w); run<6>("v_cvt_pkrtz", d, w); run<7>("v_rcp_f32", d, w);
         run<8>("v_max3_f32", d, w); run<9>("v_div_scale_f32", d, w); run<10>("v_div_fixup_f32", d, w); run<11>("v_cndmask_b32", d, w);
-        run<12>("v_lshlrev_sdwa", d, w);
+        run<12>("v_lshlrev_sdwa", d, w); run<13>("v_cndmask sgpr mask", d, w); run<14>("v_cmp+v_cndmask (2 instr)", d, w); run<15>("v_and_b32", d, w);
+        run<16>("v_pk_add_f32", d, w); run<17>("v_pk_add_f32 dependent chain", d, w); run<18>("v_mov_b32", d, w);
     }
     return 0;
 }
