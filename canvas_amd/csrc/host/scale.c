@@ -790,6 +790,23 @@ CVS_EXPORT int cvs_resample_lanczos_f32_dev(rgba_frame_f32 *target, const rgba_f
     return rc;
 }
 
+/* The resampler between two f16 frames: what an f16 pull of a Lanczos node over a half-native source computes -- widen
+ * (main.c:105-144), the two f32 passes, truncate (main.c:43-71) -- with the widen on the kernel's loads and the truncate on
+ * its stores: 8 B read per source pixel + 8 B written per target pixel, no f32 frame anywhere. */
+CVS_EXPORT int cvs_resample_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, float fx, float fy, int ksize, cvs_stream_t stream) {
+    if (cvs_enter() != 0) { box2i_set_empty(&target->current_window); return -1; }
+    CVS_REQUIRE_INSIDE(source, target, "cvs_resample_lanczos_f16_dev");
+    if (!(fx > 0.0f) || !(fy > 0.0f) || ksize < 1 || box2i_is_empty(&source->current_window) || box2i_is_empty(&target->full_window)) {
+        box2i_set_empty(&target->current_window);
+        return 0;
+    }
+    hipStream_t s = cvs_pick_stream(stream);
+    int rc = lanczos_fused(target->data, &target->full_window, 1, source->data, &source->full_window, &source->current_window, 1, fx, fy, ksize, s);
+    if (rc == 0) target->current_window = target->full_window;
+    else box2i_set_empty(&target->current_window);
+    return rc;
+}
+
 /* BASELINE config 3 on f16 frames: widen -> blur (f32) -> Lanczos resample (f32) -> truncate, as two fused
  * launches with one f32 intermediate; the widen and the truncate ride on the first load and the last store. */
 CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, const float *taps, int ntaps,
@@ -801,6 +818,8 @@ CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame
     hipStream_t s = cvs_pick_stream(stream);
     /* the blurred frame covers the source's current window (blur: output window = source window) */
     const box2i *sw = &source->current_window;
+    /* a one-tap "blur" with weight 1 is the identity (0.0f + x * 1.0f == x): the resampler alone, f16 to f16 */
+    if (ntaps == 1 && taps[0] == 1.0f) return cvs_resample_lanczos_f16_dev(target, source, fx, fy, ksize, stream);
     /* halving on both axes after an odd blur: one sweep, no intermediate frame (blur_halve_ops.hip) */
     if (fx == 0.5f && fy == 0.5f && (ntaps & 1) && !(atomic_load(&g_fir_path) & CVS_FIR_PATH_TABLES)) {
         fir_filter f = { NULL, 0, 0 };

@@ -31,6 +31,7 @@ using cvs::f32x2;
 
 constexpr int kW = 128;        // target columns (= lanes) per workgroup: narrow strips, so that a 1080p target still makes a thousand workgroups
 constexpr int kPF = 6;         // source pixels a lane fetches per row at most (strip footprint <= kPF * kW)
+constexpr int kPFD = 4;        // source rows in flight
 
 // a source pixel as it lies in memory (f16: in .x/.y), and as f32
 __device__ __forceinline__ uint4 fetch_src(const cvk_view &v, bool half, int x, int y) {
@@ -47,8 +48,9 @@ __device__ __forceinline__ float4 widen_src(uint4 p, bool half) {
 template <int MAXT, int NACC>
 __global__ __launch_bounds__(kW) void k_fir_stream(cvk_fir2d_params fp, int rows_per_wg, int lds_px) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    float4 *rowbuf = reinterpret_cast<float4 *>(lds_raw);                         // [2][lds_px]
-    float *vtap = reinterpret_cast<float *>(rowbuf + 2 * (size_t)lds_px);         // [rows_per_wg][v.stride]
+    float4 *rowbuf = reinterpret_cast<float4 *>(lds_raw);                         // [2][lds_px + 1]: one zero pixel behind each row
+    const int row_px = lds_px + 1;
+    float *vtap = reinterpret_cast<float *>(rowbuf + 2 * (size_t)row_px);         // [rows_per_wg][v.stride]
     int *vs0 = reinterpret_cast<int *>(vtap + (size_t)rows_per_wg * fp.v.stride); // [rows_per_wg] first source row of a target row
     int *vnn = vs0 + rows_per_wg;                                                 // [rows_per_wg] its tap count
 
@@ -76,16 +78,19 @@ __global__ __launch_bounds__(kW) void k_fir_stream(cvk_fir2d_params fp, int rows
         if (hi >= lo) { sx_lo = min(sx_lo, lo); sx_hi = max(sx_hi, hi); }
     }
     const int sw = sx_hi >= sx_lo ? min(sx_hi - sx_lo + 1, lds_px) : 0;           // (the host sized lds_px to cover every strip)
-    // this lane's horizontal taps, relative to the strip's first source column
+    // this lane's horizontal taps, relative to the strip's first source column.  Lists shorter than MAXT are padded with
+    // weight 0 on the ZERO PIXEL kept behind the row (index lds_px): acc + 0 * 0 == acc, so the sum needs no per-tap
+    // select (a padded tap on a real pixel would turn an Inf or NaN there into a NaN of the sum)
     const int hn = col_live ? min(fp.h.ntaps[tcol - fp.tx0], MAXT) : 0;
     int sidx[MAXT];
     float wt[MAXT];
 #pragma unroll
     for (int k = 0; k < MAXT; k++) {
         const bool live = k < hn;
-        sidx[k] = live ? fp.h.src[(size_t)(tcol - fp.tx0) * hstride + k] - sx_lo : 0;
+        sidx[k] = live ? fp.h.src[(size_t)(tcol - fp.tx0) * hstride + k] - sx_lo : lds_px;
         wt[k] = live ? fp.h.taps[(size_t)(tcol - fp.tx0) * hstride + k] : 0.0f;
     }
+    if (lane < 2) rowbuf[(size_t)lane * row_px + lds_px] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     __syncthreads();
 
     const size_t tpx = fp.out_half ? 8 : 16;
@@ -123,38 +128,51 @@ __global__ __launch_bounds__(kW) void k_fir_stream(cvk_fir2d_params fp, int rows
     }
 
     const bool in_half = fp.in_half != 0;
-    uint4 pf[kPF];                                                // the next source row, on its way
-    auto fetch_row = [&](int s) {
+    // kPFD source rows are on their way at any time (a row step is a few hundred cycles of work, a load from HBM takes a
+    // couple of thousand: with ONE row in flight -- the first version -- every step waited for memory).  Slot = row % kPFD,
+    // a compile-time index because the row loop below is unrolled kPFD times.
+    uint4 pf[kPFD][kPF];
+    auto fetch_row = [&](uint4 (&dst)[kPF], int s) {
 #pragma unroll
         for (int q = 0; q < kPF; q++) {
             const int x = lane + q * kW;
-            pf[q] = make_uint4(0u, 0u, 0u, 0u);
-            if (x < sw && s <= s_hi) pf[q] = fetch_src(fp.source, in_half, sx_lo + x, s);
+            dst[q] = make_uint4(0u, 0u, 0u, 0u);
+            if (x < sw && s <= s_hi) dst[q] = fetch_src(fp.source, in_half, sx_lo + x, s);
         }
     };
-    if (s_lo <= s_hi) fetch_row(s_lo);
-    for (int s = s_lo; s <= s_hi; s++) {                          // uniform bounds: every wave runs every iteration
-        float4 *buf = rowbuf + (size_t)((s - s_lo) & 1) * lds_px;
+    if (s_lo <= s_hi) {
+#pragma unroll
+        for (int d = 0; d < kPFD; d++) fetch_row(pf[d], s_lo + d);
+    }
+    for (int sb = s_lo; sb <= s_hi; sb += kPFD) {                 // uniform bounds: every wave runs every iteration
+#pragma unroll
+      for (int d = 0; d < kPFD; d++) {
+        const int s = sb + d;
+        if (s > s_hi) break;                                      // uniform
+        float4 *buf = rowbuf + (size_t)((s - s_lo) & 1) * row_px;
 #pragma unroll
         for (int q = 0; q < kPF; q++) {
             const int x = lane + q * kW;
-            if (x < sw) buf[x] = widen_src(pf[q], in_half);
+            if (x < sw) buf[x] = widen_src(pf[d][q], in_half);
         }
-        fetch_row(s + 1);                                         // in flight while this row is filtered
+        fetch_row(pf[d], s + kPFD);                               // in flight while the next kPFD rows are filtered
         __syncthreads();
         f32x2 hrg = { 0.0f, 0.0f }, hba = { 0.0f, 0.0f };
 #pragma unroll
-        for (int k0 = 0; k0 < MAXT; k0 += 8) {                    // groups of eight taps: reads first, then the sums in tap order
+        for (int k0 = 0; k0 < MAXT; k0 += 8) {                    // groups of eight taps: reads first, then products, then the sums in tap order
             float4 v[8];
 #pragma unroll
             for (int c = 0; c < 8; c++) v[c] = buf[sidx[k0 + c]];
+            f32x2 prg[8], pba[8];
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                const f32x2 nrg = hrg + f32x2{ v[c].x, v[c].y } * wt[k0 + c];
-                const f32x2 nba = hba + f32x2{ v[c].z, v[c].w } * wt[k0 + c];
-                const bool live = k0 + c < hn;
-                hrg = live ? nrg : hrg;
-                hba = live ? nba : hba;
+                prg[c] = f32x2{ v[c].x, v[c].y } * wt[k0 + c];
+                pba[c] = f32x2{ v[c].z, v[c].w } * wt[k0 + c];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                hrg = hrg + prg[c];
+                hba = hba + pba[c];
             }
         }
 #pragma unroll
@@ -170,6 +188,7 @@ __global__ __launch_bounds__(kW) void k_fir_stream(cvk_fir2d_params fp, int rows
                 }
             }
         }
+      }
     }
 }
 
@@ -178,7 +197,7 @@ int launch(const cvk_fir2d_params &fp, int cus, hipStream_t s) {
     const int cols = fp.tx1 - fp.tx0 + 1, rows = fp.ty1 - fp.ty0 + 1;
     const int strips = (cols + kW - 1) / kW;
     const int lds_px = fp.max_sw;                                   // widest strip footprint, from the host
-    auto lds_bytes = [&](int r) { return (size_t)2 * lds_px * sizeof(float4) + (size_t)r * fp.v.stride * sizeof(float) + (size_t)r * 2 * sizeof(int); };
+    auto lds_bytes = [&](int r) { return (size_t)2 * (lds_px + 1) * sizeof(float4) + (size_t)r * fp.v.stride * sizeof(float) + (size_t)r * 2 * sizeof(int); };
     static bool raised = false;
     if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_stream<MAXT, NACC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
     // rows per workgroup: about one wave of resident workgroups over the whole frame (as k_blur), at least twice the
@@ -188,7 +207,10 @@ int launch(const cvk_fir2d_params &fp, int cus, hipStream_t s) {
     int segs = (per_cu * (cus > 0 ? cus : 256)) / strips;
     if (segs < 1) segs = 1;
     int r = (rows + segs - 1) / segs;
-    if (r < NACC) r = NACC;
+    // a segment re-reads (and re-filters) the source rows its first target rows reach back to: about the tap count of a
+    // line.  Below 2 x NACC target rows that halo is most of the work (the first version ran 0.4x Lanczos segments of 8
+    // rows: 35 source rows walked for 20 useful ones)
+    if (r < 2 * NACC) r = 2 * NACC;
     if (r > 256) r = 256;
     if (lds_px > kPF * kW) return (int)hipErrorInvalidValue;           // a lane fetches at most kPF pixels per row
     if (r > rows) r = rows;

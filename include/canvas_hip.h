@@ -355,6 +355,8 @@ CVS_EXPORT int cvs_fir_blur_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16
 CVS_EXPORT int cvs_blur_over_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *source, const float *taps, int ntaps,
                                      const rgba_frame_f16 *const *overlays, int noverlays, cvs_stream_t stream);
 CVS_EXPORT int cvs_resample_lanczos_f32_dev(rgba_frame_f32 *target, const rgba_frame_f32 *source, float factor_x, float factor_y, int kernel_size, cvs_stream_t s);
+/* the same between f16 frames (widen on load, f32 passes, truncate on store): an f16 pull of the node over a half-native source */
+CVS_EXPORT int cvs_resample_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, float factor_x, float factor_y, int kernel_size, cvs_stream_t s);
 /* BASELINE config 3 on f16 frames: widen -> blur -> Lanczos resample -> truncate, f32 in between, two launches */
 CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, const float *taps_host, int ntaps,
                                         float factor_x, float factor_y, int kernel_size, cvs_stream_t s);

@@ -717,6 +717,34 @@ def test_lanczos_resample(cvs, orc, fx, fy, tsize):
     assert_same_f32(got.array, want.array, "lanczos")
 
 
+@pytest.mark.parametrize("ssize,scur,tsize,fx,fy", [
+    ((128, 72), None, (64, 36), 0.5, 0.5),
+    ((400, 300), (7, 5, 380, 290), (160, 120), 0.4, 0.4),
+    ((300, 200), None, (225, 150), 0.75, 0.75),
+    ((96, 54), None, (144, 81), 1.5, 1.5),
+    ((130, 70), None, (40, 200), 0.3, 3.0),
+])
+def test_lanczos_resample_between_f16_frames(cvs, orc, ssize, scur, tsize, fx, fy):
+    """cvs_resample_lanczos_f16_dev = widen, the two f32 passes, truncate -- with no f32 frame; and the same thing reached
+    through cvs_blur_lanczos_f16_dev with the identity blur (one tap of weight 1)."""
+    full = (0, 0, ssize[0] - 1, ssize[1] - 1)
+    src16 = HostFrame(full, np.uint16, synth.layer_pixels(ssize[0], ssize[1], 2, 7), scur)
+    src32 = HostFrame(full, np.float32, orc.half_to_float(src16.array), scur)
+    tfull = (0, 0, tsize[0] - 1, tsize[1] - 1)
+    want32 = HostFrame(tfull, np.float32)
+    orc.lib().orc_resample_lanczos_f32(want32.ref(), src32.ref(), C.c_float(fx), C.c_float(fy), 3)
+    want = orc.float_to_half(want32.array)
+    d_src, d_out = DeviceFrame.from_host(src16), DeviceFrame(tfull, np.uint16)
+    _lib.check(cvs.cvs_resample_lanczos_f16_dev(d_out.ref(), d_src.ref(), C.c_float(fx), C.c_float(fy), 3, None))
+    got = d_out.download()
+    assert same_window(got.current_window, want32.current_window)
+    assert_same_f16(got.array, want, "f16 lanczos %r" % ((fx, fy),))
+    one = np.array([1.0], np.float32)
+    _lib.check(cvs.cvs_memset(d_out.ptr, 0x11, d_out.nbytes, None))
+    _lib.check(cvs.cvs_blur_lanczos_f16_dev(d_out.ref(), d_src.ref(), f32p(one), 1, C.c_float(fx), C.c_float(fy), 3, None))
+    assert_same_f16(d_out.download().array, want, "identity blur + lanczos %r" % ((fx, fy),))
+
+
 @pytest.fixture
 def force_fir(request):
     """cvs_fir_path_override pins the general FIR path to one of its kernels (speed only: the point of these tests is that
@@ -731,6 +759,7 @@ def force_fir(request):
             mode |= _lib.FIR_PATH_SWEEP
         elif which == "tiled":
             mode |= _lib.FIR_PATH_TILED
+
         lib.cvs_fir_path_override(mode)
     yield pin
     pin(None)
