@@ -187,7 +187,7 @@ __global__ __launch_bounds__(1024) void k_lab(Batch batch, int njobs, const uint
     }
 }
 
-struct Variant { const char *name; int flags; int lanes; int split; };   // split: issue the batch as launches of this many frames (0: one launch)
+struct Variant { const char *name; int flags; int lanes; int split; int streams = 1; };   // split: issue the batch as launches of this many frames (0: one launch)
 
 static unsigned *g_ctr; static int g_every = 8;
 template <int F>
@@ -226,13 +226,20 @@ int main(int argc, char **argv) {
     CK(hipMalloc((void **)&g_ctr, 1024));
     hipStream_t s;
     CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    hipEvent_t e0, e1;
-    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipEvent_t e0, e1, ej;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&ej));
+    hipStream_t s2;
+    CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
     const Variant vs[] = {
         { "plain, one launch                            512", 0, 512, 0 },
         { "plain, launches of 8 frames back to back     512", 0, 512, 8 },
         { "plain, launches of 16 frames back to back    512", 0, 512, 16 },
         { "plain, launches of 4 frames back to back     512", 0, 512, 4 },
+        { "plain, launches of 4, alternating 2 streams  512", 0, 512, 4, 2 },
+        { "plain, launches of 2, alternating 2 streams  512", 0, 512, 2, 2 },
+        { "plain, launches of 8, alternating 2 streams  512", 0, 512, 8, 2 },
+        { "chunk walk + table + gathers, launches of 4, 2 streams", F_CHUNK | F_LUT | F_GATHER, 512, 4, 2 },
+        { "chunk walk + table + gathers, launches of 4, 1 stream ", F_CHUNK | F_LUT | F_GATHER, 512, 4 },
         { "plain, one launch, rendezvous every 8 frames 512", F_RESYNC, 512, -8 },
         { "plain, one launch, rendezvous every 2 frames 512", F_RESYNC, 512, -2 },
         { "plain, one launch, rendezvous every frame    512", F_RESYNC, 512, -1 },
@@ -257,11 +264,14 @@ int main(int argc, char **argv) {
         for (int v = 0; v < nv; v++) {
             CK(hipEventRecord(e0, s));
             if (vs[v].split > 0 && vs[v].split < njobs) {
-                for (int first = 0; first < njobs; first += vs[v].split) {
+                int turn = 0;
+                if (vs[v].streams == 2) { CK(hipEventRecord(ej, s)); CK(hipStreamWaitEvent(s2, ej, 0)); }
+                for (int first = 0; first < njobs; first += vs[v].split, turn++) {
                     Batch part = b;
                     for (int q = 0; q < vs[v].split && first + q < njobs; q++) part.j[q] = b.j[first + q];
-                    launch(vs[v].flags, part, std::min(vs[v].split, njobs - first), table, vs[v].lanes, s);
+                    launch(vs[v].flags, part, std::min(vs[v].split, njobs - first), table, vs[v].lanes, (vs[v].streams == 2 && (turn & 1)) ? s2 : s);
                 }
+                if (vs[v].streams == 2) { CK(hipEventRecord(ej, s2)); CK(hipStreamWaitEvent(s, ej, 0)); }
             } else if (vs[v].split < 0) { g_every = -vs[v].split; launch(vs[v].flags, b, njobs, table, vs[v].lanes, s); }
             else launch(vs[v].flags, b, njobs, table, vs[v].lanes, s);
             CK(hipEventRecord(e1, s));
