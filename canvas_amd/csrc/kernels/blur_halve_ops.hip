@@ -56,23 +56,28 @@ __device__ __forceinline__ float4 fetch_px(const char *p, bool live) {
     }
 }
 
-// sum of NT taps over values fetched by `at(k)`, ascending k, all products first (a packed add right behind the packed
-// multiply it depends on costs a hazard slot), same rounding and order as mul/add in sequence
+// sum of NT taps over values fetched by `at(k)`, ascending k.  Products are formed in groups of CH before their adds (a
+// packed add right behind the packed multiply it depends on costs a hazard slot); the groups keep the products of a long
+// list from occupying 4 x NT registers at once.  Same rounding and order as mul/add in sequence.
+constexpr int CH = 6;
 template <int NT, class At>
 __device__ __forceinline__ Px fir(const float (&w)[NT], At at) {
-    f32x2 prg[NT], pba[NT];
-#pragma unroll
-    for (int k = 0; k < NT; k++) {
-        const Px v = at(k);
-        prg[k] = v.rg * w[k];
-        pba[k] = v.ba * w[k];
-    }
-    __builtin_amdgcn_sched_barrier(0);
     Px o = { f32x2{ 0.0f, 0.0f }, f32x2{ 0.0f, 0.0f } };
 #pragma unroll
-    for (int k = 0; k < NT; k++) {
-        o.rg = o.rg + prg[k];
-        o.ba = o.ba + pba[k];
+    for (int k0 = 0; k0 < NT; k0 += CH) {
+        f32x2 prg[CH], pba[CH];
+#pragma unroll
+        for (int c = 0; c < CH; c++) if (k0 + c < NT) {
+            const Px v = at(k0 + c);
+            prg[c] = v.rg * w[k0 + c];
+            pba[c] = v.ba * w[k0 + c];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < CH; c++) if (k0 + c < NT) {
+            o.rg = o.rg + prg[c];
+            o.ba = o.ba + pba[c];
+        }
     }
     return o;
 }
@@ -80,13 +85,16 @@ __device__ __forceinline__ Px fir(const float (&w)[NT], At at) {
 // the same for one channel pair
 template <int NT, class At>
 __device__ __forceinline__ f32x2 fir1(const float (&w)[NT], At at) {
-    f32x2 p[NT];
-#pragma unroll
-    for (int k = 0; k < NT; k++) p[k] = at(k) * w[k];
-    __builtin_amdgcn_sched_barrier(0);
     f32x2 o = { 0.0f, 0.0f };
 #pragma unroll
-    for (int k = 0; k < NT; k++) o = o + p[k];
+    for (int k0 = 0; k0 < NT; k0 += 2 * CH) {
+        f32x2 p[2 * CH];
+#pragma unroll
+        for (int c = 0; c < 2 * CH; c++) if (k0 + c < NT) p[c] = at(k0 + c) * w[k0 + c];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 2 * CH; c++) if (k0 + c < NT) o = o + p[c];
+    }
     return o;
 }
 
