@@ -511,6 +511,27 @@ def test_chain_batch_and_lut_variants(cvs, orc):
             assert_same_f16(out.download().array, want.array, "batch pre=%d post=%d" % (pre, post))
 
 
+@pytest.mark.parametrize("nlayers,plain", [(1, False), (2, False), (3, True), (4, False)])
+def test_chain_batch_of_frames_of_different_sizes(cvs, orc, nlayers, plain):
+    """One call, frames of very different sizes, odd and even pixel counts, some smaller than one 8 KiB chunk: the
+    workgroups walk the whole batch as one run of chunks, crossing from frame to frame with partial last chunks, and the
+    last pixel of the odd-sized frames goes through the tail kernel.  70 jobs: more than one launch's job records."""
+    m = None if plain else np.array(REC709_RGB_TO_YPBPR, np.float32)
+    lut = None if plain else orc.transfer_table(0)
+    sizes = [(64, 36), (33, 7), (640, 360), (1, 2), (513, 1), (2, 1), (1023, 3), (96, 54), (3, 1), (1280, 719)]
+    jobs, wants = [], []
+    for i in range(70):
+        w, h = sizes[i % len(sizes)]
+        layers = _synth_layers(w, h, nlayers, i)
+        wants.append(orc.chain_color_over(layers, m, lut, None))
+        jobs.append((DeviceFrame((0, 0, w - 1, h - 1), np.uint16), [DeviceFrame.from_host(l) for l in layers]))
+    chain_color_over(jobs, m, _lib.LUT_NONE if plain else _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE)
+    _lib.check(cvs.cvs_stream_sync(None))
+    assert cvs.cvs_chain_last_was_fused() == 1
+    for i, ((out, _), want) in enumerate(zip(jobs, wants)):
+        assert_same_f16(out.download().array, want.array, "job %d, %r" % (i, sizes[i % len(sizes)]))
+
+
 def test_chain_ragged_windows_take_the_node_by_node_path(cvs, orc):
     m = np.array(REC709_RGB_TO_YPBPR, np.float32)
     rng = np.random.default_rng(12)
