@@ -176,7 +176,6 @@ CVS_EXPORT int cvs_chain_color_over_f16_dev(const cvs_chain_job *jobs, int njobs
         if (jobs[i].nlayers != uniform) uniform = 0;
         jobs[i].out->current_window = jobs[i].out->full_window;
     }
-    if (uniform > 4) uniform = 0;
     int rc = 0;
     cvk_chain_count_reset();
     for (int first = 0; rc == 0 && first < njobs; ) {       /* runs of mutually independent jobs, one (set of) launch(es) each */

@@ -406,7 +406,7 @@ def _synth_layers(w, h, n, frame=0):
     return [synth.layer_frame(w, h, k, frame) for k in range(n)]
 
 
-@pytest.mark.parametrize("nlayers", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("nlayers", [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("size", [(64, 36), (33, 7)])       # even and odd pixel counts
 def test_chain_fused_matches_oracle(cvs, orc, nlayers, size):
     w, h = size
@@ -472,7 +472,7 @@ def test_chain_shifted_overlap_of_output_and_layer_is_not_fused(cvs, orc):
     cvs.cvs_free(arena)
 
 
-@pytest.mark.parametrize("nlayers", [2, 3, 4])
+@pytest.mark.parametrize("nlayers", [2, 3, 4, 6, 8])
 def test_chain_fused_with_live_divides(cvs, orc, nlayers):
     """Every layer translucent (alpha 0, 1 and in between, per pixel): the x/1.0 shortcut of the kernel
     must not be taken where the blended alpha is not exactly 1, and alpha 0 must give the zero pixel."""
@@ -511,7 +511,7 @@ def test_chain_batch_and_lut_variants(cvs, orc):
             assert_same_f16(out.download().array, want.array, "batch pre=%d post=%d" % (pre, post))
 
 
-@pytest.mark.parametrize("nlayers,plain", [(1, False), (2, False), (3, True), (4, False)])
+@pytest.mark.parametrize("nlayers,plain", [(1, False), (2, False), (3, True), (4, False), (5, True), (7, False), (8, True)])
 def test_chain_batch_of_frames_of_different_sizes(cvs, orc, nlayers, plain):
     """One call, frames of very different sizes, odd and even pixel counts, some smaller than one 8 KiB chunk: the
     workgroups walk the whole batch as one run of chunks, crossing from frame to frame with partial last chunks, and the
@@ -1003,7 +1003,7 @@ def test_config4_8k_three_layer_properties(cvs, orc):
 
 # ------------------------------------------------------------------ config 5 pieces: plain stack, out-of-place colour, f16 blur
 
-@pytest.mark.parametrize("nlayers", [1, 2, 4, 5])
+@pytest.mark.parametrize("nlayers", [1, 2, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize("translucent", [False, True])
 def test_plain_over_stack_matches_oracle(cvs, orc, nlayers, translucent):
     """m == NULL: no colour node, just the workspace stack of f16 layers."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Workspace stacks of 2..8 layers at 3840x2160 (plain over, f16 in and out): 1-4 layers run the pipelined kernel,
-5-8 the first-version kernel.  8 frames per launch; GB/s against 8 B per layer pixel + 8 B per output pixel."""
+"""Workspace stacks of 2..8 layers at 3840x2160 (plain over, f16 in and out) through the chain kernel (1-4 layers:
+chain_ops.hip, 5-8: chain_deep_ops.hip).  8 frames per call; GB/s against 8 B per layer pixel + 8 B per output pixel."""
 import os
 import sys
 
