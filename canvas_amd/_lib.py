@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libcanvas_hip.so")
 
 CHAIN_MAX_LAYERS = 8
 DISPLAY_RGBA8, DISPLAY_ARGB32_PREMUL = 0, 1
-FIR_PATH_AUTO, FIR_PATH_SWEEP, FIR_PATH_TILED, FIR_PATH_TABLES = 0, 1, 2, 4
+FIR_PATH_AUTO, FIR_PATH_SWEEP, FIR_PATH_TILED, FIR_PATH_TABLES, FIR_PATH_LANES = 0, 1, 2, 4, 8
 LUT_NONE, LUT_REC709_TO_LINEAR_SCENE, LUT_REC709_TO_LINEAR_DISPLAY, LUT_LINEAR_TO_REC709, LUT_LINEAR_TO_SRGB = -1, 0, 1, 2, 3
 
 

@@ -22,7 +22,7 @@
 #include <stdatomic.h>
 
 static _Atomic int g_fir_path = CVS_FIR_PATH_AUTO;
-CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES)); }
+CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_LANES)); }
 
 typedef struct {
     int t0, t1;            /* target lines covered by the table */
@@ -408,18 +408,66 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
             }
         }
     }
+    int foot64 = 0;
+    for (int g = 0; g < lines; g += 64) {                   /* the lane-per-channel sweep's strips (sweep_ops.hip) */
+        int first = INT_MAX, last = INT_MIN;
+        for (int i = g; i < lines && i < g + 64; i++) {
+            if (!ntaps[i]) continue;
+            const int *src = tb->tap_src + (size_t)i * tb->stride;
+            if (src[0] < first) first = src[0];
+            if (src[ntaps[i] - 1] > last) last = src[ntaps[i] - 1];
+        }
+        if (last >= first && last - first + 1 > foot64) foot64 = last - first + 1;
+    }
+    /* the table by SOURCE line (kernels.h cvk_fir_axis.rec) */
+    uint32_t *rec = NULL;
+    int rec_s0 = 0, rec_n = 0, nacc = 0, rec_zero_weight = 0;
+    if (streamable && max_active >= 1 && max_active <= 32) {
+        nacc = max_active <= 8 ? 8 : max_active <= 16 ? 16 : 32;
+        int s_first = INT_MAX, s_last = INT_MIN;
+        for (int i = 0; i < lines; i++) {
+            if (!ntaps[i]) continue;
+            const int a = tb->tap_src[(size_t)i * tb->stride];
+            if (a < s_first) s_first = a;
+            if (a + ntaps[i] - 1 > s_last) s_last = a + ntaps[i] - 1;
+        }
+        if (s_last >= s_first) {
+            rec_s0 = s_first; rec_n = s_last - s_first + 1;
+            const size_t rs = (size_t)nacc + 4;
+            rec = calloc(((size_t)rec_n + 1) * rs, sizeof *rec);          /* + one spare record: the kernel loads a row ahead */
+            if (!rec) { free(foot); free(ntaps); return -1; }
+            for (int i = 0; i < lines; i++) {
+                const int n = ntaps[i];
+                if (!n) continue;
+                const int a = tb->tap_src[(size_t)i * tb->stride], slot = i & (nacc - 1);
+                for (int k = 0; k < n; k++) {
+                    uint32_t *r = rec + (size_t)(a + k - rec_s0) * rs;
+                    r[0] |= 1u << slot;
+                    memcpy(&r[4 + slot], &tb->taps[(size_t)i * tb->stride + k], 4);
+                    if (tb->taps[(size_t)i * tb->stride + k] == 0.0f) rec_zero_weight = 1;
+                    if (k == n - 1) {
+                        if (!r[1]) r[2] = (uint32_t)i;           /* lines come in ascending order: the first to end here */
+                        r[1] |= 1u << slot;
+                    }
+                }
+            }
+        }
+    }
     const size_t n_l = (size_t)(lines ? lines : 1), n_t = n_l * (size_t)tb->stride;
     const size_t off_src = (n_l * sizeof(int) + 255) & ~(size_t)255;
     const size_t off_tap = off_src + ((n_t * sizeof(int) + 255) & ~(size_t)255);
     const size_t off_foot = off_tap + ((n_t * sizeof(float) + 255) & ~(size_t)255);
-    const size_t total = off_foot + sizeof(int) * 2 * (size_t)(tiles ? tiles : 1);
+    const size_t off_rec = off_foot + ((sizeof(int) * 2 * (size_t)(tiles ? tiles : 1) + 255) & ~(size_t)255);
+    const size_t rec_bytes = rec ? ((size_t)rec_n + 1) * ((size_t)nacc + 4) * sizeof *rec : 0;
+    const size_t total = off_rec + (rec_bytes ? rec_bytes : 4);
     char *dev = NULL;
     hipError_t err = hipMalloc((void **)&dev, total);
     if (err == hipSuccess) err = hipMemcpy(dev, ntaps, n_l * sizeof(int), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(dev + off_src, tb->tap_src, n_t * sizeof(int), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(dev + off_tap, tb->taps, n_t * sizeof(float), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(dev + off_foot, foot, sizeof(int) * 2 * (size_t)(tiles ? tiles : 1), hipMemcpyHostToDevice);
-    free(foot); free(ntaps);
+    if (err == hipSuccess && rec_bytes) err = hipMemcpy(dev + off_rec, rec, rec_bytes, hipMemcpyHostToDevice);
+    free(foot); free(ntaps); free(rec);
     if (err != hipSuccess) { if (dev) hipFree(dev); cvs_set_error("FIR table upload: %s", hipGetErrorString(err)); return -1; }
     e->dev = dev;
     e->axis.ntaps = (const int *)dev;
@@ -428,6 +476,9 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     e->axis.foot = (const int *)(dev + off_foot);
     e->axis.stride = tb->stride;
     e->axis.max_taps = max_taps; e->axis.wide_foot = wide_foot; e->axis.max_active = max_active; e->axis.streamable = streamable;
+    e->axis.rec = rec_bytes ? (const uint32_t *)(dev + off_rec) : NULL;
+    e->axis.rec_s0 = rec_s0; e->axis.rec_n = rec_bytes ? rec_n : 0; e->axis.nacc = nacc;
+    e->axis.foot64 = foot64; e->axis.rec_zero_weight = rec_zero_weight;
     e->max_foot = max_foot;
     return 0;
 }
@@ -599,6 +650,15 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
      * Small footprints (enlargements, blurs) stay with the tiles, which are as fast or faster there.
      * cvs_fir_path_override() pins one or the other (parity tests of each kernel, A/B runs). */
     const int force = atomic_load(&g_fir_path);
+    /* First choice: the sweep with one lane per target column and channel (sweep_ops.hip), whenever the vertical table
+     * could be turned round for it and the lists fit. */
+    if ((force & CVS_FIR_PATH_LANES) || !(force & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED))) {
+        if (cvk_fir_lanes_supported(&fp)) {
+            int rc = cvk_fir_lanes(&fp, cvs_cus(), s);
+            if (rc == 0) return 0;
+            (void)hipGetLastError();                          /* did not launch: the older kernels decide */
+        }
+    }
     const bool can_stream = v->streamable && h->max_taps >= 1 && v->max_active >= 1 && cvk_fir_stream_supported(h->max_taps, v->max_active);
     const bool want_stream = (force & CVS_FIR_PATH_SWEEP) ? true : cvk_fir2d_lds_bytes(&fp) > 64 * 1024;
     if (can_stream && want_stream && !(force & CVS_FIR_PATH_TILED)) {

@@ -119,6 +119,15 @@ typedef struct {
     int wide_foot;             /* widest source footprint of any run of 128 lines starting at a multiple of 128 */
     int max_active;            /* as the vertical axis: the longest run of lines i..j such that line j starts at or before line i's last tap */
     int streamable;            /* every list is consecutive source lines, first and last taps never decrease from line to line */
+    /* the table turned round for the lane-per-channel sweep (sweep_ops.hip), present when streamable and max_active <= 32:
+     * one record of (nacc + 4) dwords per SOURCE line rec_s0 .. rec_s0 + rec_n - 1.  A target line's accumulator slot is
+     * its index & (nacc - 1).  [0] slots that take this source line, [1] slots for which it is the last tap, [2] index of
+     * the first target line that ends here, [3] 0, [4 + slot] the slot's weight for this source line (0 for the slots that
+     * do not take it).  One spare all-zero record follows the last. */
+    const uint32_t *rec;
+    int rec_s0, rec_n, nacc;
+    int rec_zero_weight;       /* some tap of the table has weight +-0 (the sweep tells "no tap" by weight 0: not for this table) */
+    int foot64;                /* widest source footprint of any run of 64 lines starting at a multiple of 64 */
 } cvk_fir_axis;
 typedef struct {
     cvk_view target, source;
@@ -132,6 +141,9 @@ typedef struct {
 /* the same tables, swept down the frame (resample_ops.hip): fp->max_sw = h.wide_foot; needs v.streamable */
 int cvk_fir_stream_supported(int h_taps, int v_active);
 int cvk_fir_stream(const cvk_fir2d_params *fp, int h_taps, int v_active, int cus, void *stream);
+/* the same tables again, one lane per target column and channel pair (sweep_ops.hip): needs h tap lists <= 32, v.rec */
+int cvk_fir_lanes_supported(const cvk_fir2d_params *fp);
+int cvk_fir_lanes(const cvk_fir2d_params *fp, int cus, void *stream);
 size_t cvk_fir2d_lds_bytes(const cvk_fir2d_params *fp);     /* dynamic LDS the launch would need */
 int cvk_fir2d(const cvk_fir2d_params *fp, void *stream);
 

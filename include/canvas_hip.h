@@ -361,11 +361,12 @@ CVS_EXPORT int cvs_resample_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_f
 CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame_f16 *source, const float *taps_host, int ntaps,
                                         float factor_x, float factor_y, int kernel_size, cvs_stream_t s);
 
-/* The separable FIR entry points choose among three kernels by footprint: the register-window kernel
- * (one tap list for every line), tiles in LDS, and a sweep down the frame.  All three compute the same sums in the same
- * order -- results are bit-equal, which the parity tests show by pinning each kernel in turn through this call.  It
- * changes speed only, never pixels; process-wide; 0 restores the automatic choice. */
-enum { CVS_FIR_PATH_AUTO = 0, CVS_FIR_PATH_SWEEP = 1, CVS_FIR_PATH_TILED = 2, CVS_FIR_PATH_TABLES = 4 /* skip the register-window kernel */ };
+/* The separable FIR entry points choose among four kernels: the register-window kernel (one tap list for
+ * every line), and for per-line tables the sweep with a lane per channel, tiles in LDS, and the sweep with a lane per pixel.
+ * All compute the same sums in the same order -- results are bit-equal, which the parity tests show by pinning each kernel
+ * in turn through this call.  It changes speed only, never pixels; process-wide; 0 restores the automatic choice. */
+enum { CVS_FIR_PATH_AUTO = 0, CVS_FIR_PATH_SWEEP = 1 /* lane per pixel */, CVS_FIR_PATH_TILED = 2, CVS_FIR_PATH_TABLES = 4 /* skip the register-window kernel */,
+       CVS_FIR_PATH_LANES = 8 /* lane per channel */ };
 CVS_EXPORT void cvs_fir_path_override(int mode);
 
 /* ------------------------------------------------------------------ (3) fused chain: BASELINE config 2

@@ -780,13 +780,15 @@ def force_fir(request):
             mode |= _lib.FIR_PATH_SWEEP
         elif which == "tiled":
             mode |= _lib.FIR_PATH_TILED
+        elif which == "lanes":
+            mode |= _lib.FIR_PATH_LANES
 
         lib.cvs_fir_path_override(mode)
     yield pin
     pin(None)
 
 
-@pytest.mark.parametrize("kernel", ["stream", "tiled"])
+@pytest.mark.parametrize("kernel", ["lanes", "stream", "tiled"])
 @pytest.mark.parametrize("ssize,scur,tsize,fx,fy", [
     ((64, 36), None, (32, 18), 0.5, 0.5),
     ((400, 300), None, (160, 120), 0.4, 0.4),                # several strips of 128 columns, several row segments
@@ -818,7 +820,7 @@ def test_lanczos_resample_both_kernels(cvs, orc, force_fir, kernel, ssize, scur,
     assert_same_f16(o16.download().array, want16.array, "lanczos f16 (%s)" % kernel)
 
 
-@pytest.mark.parametrize("kernel", ["stream", "tiled"])
+@pytest.mark.parametrize("kernel", ["lanes", "stream", "tiled"])
 @pytest.mark.parametrize("ntaps", [1, 2, 4, 10, 16])
 def test_even_and_short_blurs_both_kernels(cvs, orc, force_fir, kernel, ntaps):
     rng = np.random.default_rng(63)
@@ -843,14 +845,14 @@ def test_full_size_resample_agrees_between_the_two_kernels(cvs, force_fir):
     one = np.array([1.0], np.float32)
     d_src = DeviceFrame.from_host(synth.layer_frame(w, h, 1, 0))
     outs = []
-    for kernel in (None, "tiled", "stream"):
+    for kernel in (None, "tiled", "stream", "lanes"):
         force_fir(kernel)
         d_out = DeviceFrame((0, 0, tw - 1, th - 1), np.uint16)
         _lib.check(cvs.cvs_blur_lanczos_f16_dev(d_out.ref(), d_src.ref(), f32p(one), 1, C.c_float(f), C.c_float(f), 3, None))
         got = d_out.download()
         assert got.current_window.tuple() == (0, 0, tw - 1, th - 1)
         outs.append(got.array)
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
     assert len(np.unique(outs[0])) > 1000
 
 

@@ -38,7 +38,13 @@ def timed(name, fn, nbytes):
     print("%-58s %.3f ms  %6.0f GB/s" % (name, ms, nbytes / ms / 1e6))
 
 
-for f in (0.4, 0.75, 1.5):
+which = {"lanes": _lib.FIR_PATH_LANES, "stream": _lib.FIR_PATH_SWEEP, "tiled": _lib.FIR_PATH_TILED}
+pin = [a for a in sys.argv[1:] if a in which]
+factors = [float(a) for a in sys.argv[1:] if a not in which] or [0.4, 0.75, 1.5]
+if pin:                                       # one kernel of the table path pinned (blurs too go to the tables then)
+    lib.cvs_fir_path_override(which[pin[0]] | _lib.FIR_PATH_TABLES)
+    print("general FIR path pinned to:", pin[0])
+for f in factors:
     tw, th = int(w * f), int(h * f)
     out16 = DeviceFrame((0, 0, tw - 1, th - 1), np.uint16)
     timed("1-tap blur + Lanczos3 f16 -> f16, factor %.2f (%dx%d)" % (f, tw, th),
