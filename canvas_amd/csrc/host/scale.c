@@ -431,7 +431,17 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
             if (a < s_first) s_first = a;
             if (a + ntaps[i] - 1 > s_last) s_last = a + ntaps[i] - 1;
         }
-        if (s_last >= s_first) {
+        /* the lines that have taps must be one run of consecutive lines: the sweep stores them to consecutive rows in the
+         * order in which they end, and gives the second line that ends on a source row the next slot */
+        bool one_run = true;
+        {
+            int seen = 0, closed = 0;
+            for (int i = 0; i < lines; i++) {
+                if (ntaps[i]) { if (closed) one_run = false; seen = 1; }
+                else if (seen) closed = 1;
+            }
+        }
+        if (s_last >= s_first && one_run) {
             rec_s0 = s_first; rec_n = s_last - s_first + 1;
             const size_t rs = (size_t)nacc + 4;
             rec = calloc(((size_t)rec_n + 1) * rs, sizeof *rec);          /* + one spare record: the kernel loads a row ahead */

@@ -22,6 +22,7 @@
 // Bound: LDS gather rate / VALU issue (HBM traffic is source once + target once).  Algorithmic bytes: source pixel once +
 // target pixel once.
 #include <climits>
+#include <cstdlib>
 #include "kernels.h"
 #include "chain_math.hpp"
 
@@ -29,10 +30,11 @@ namespace {
 
 using cvs::f32x2;
 
-constexpr int kCols = 64;       // target columns per workgroup
-constexpr int kLanes = 128;     // = kCols x 2 channel pairs
+constexpr int kCols = 32;       // target columns per workgroup (one tile of the host's footprint table)
+constexpr int kLanes = 64;      // = kCols x 2 channel pairs: ONE WAVE.  Its LDS rows are its own, LDS executes a wave's accesses
+                                // in order, so a row step needs no barrier and no wave ever waits for another
 constexpr int kPFD = 4;         // source rows in flight
-constexpr int kRowPx = 512;     // source pixels under a strip at most; the LDS row is this long whatever the factor, so that
+constexpr int kRowPx = 256;     // source pixels under a strip at most; the LDS row is this long whatever the factor, so that
                                 // the second row buffer and the zero pixel sit at compile-time offsets
 constexpr int kRowFl = (kRowPx + 1) * 4;
 
@@ -51,24 +53,54 @@ __device__ __forceinline__ float mul_zero_wins(float x, float w) {
     return r;
 }
 
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <bool INH> struct SrcPx;
-template <> struct SrcPx<true> { uint2 v; };        // rgba_f16
-template <> struct SrcPx<false> { uint4 v; };       // rgba_f32
+template <> struct SrcPx<true> { u32x2 v; };        // rgba_f16
+template <> struct SrcPx<false> { u32x4 v; };       // rgba_f32
 
-template <int MAXT, int NACC, int NQ, bool INH>
+// Source rows are fetched a GROUP of four rows ahead, from inline asm.  Written as plain loads hipcc keeps the four rows
+// in flight in loop-carried registers and answers them with s_waitcnt vmcnt(0) at the loop header -- right behind the
+// newest load, one full memory latency every fourth row (cdna_hip_programming.md 5.7; the first form of this kernel spent
+// two thirds of its time there).  The compiler cannot see asm loads, so the wait is written by hand too: vmcnt(0) at the
+// top of a group, when the loads it waits for are a whole group of rows old.
+// address = 64-bit scalar row pointer + 32-bit lane offset (the global saddr form)
+__device__ __forceinline__ void asm_ld(SrcPx<true> &dst, const void *row, uint32_t voff) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst.v) : "v"(voff), "s"(row));
+}
+__device__ __forceinline__ void asm_ld(SrcPx<false> &dst, const void *row, uint32_t voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst.v) : "v"(voff), "s"(row));
+}
+
+// HAND: whether this instance fetches its rows by the asm pipeline above.  Registers that asm loads are in flight into must
+// stay where they are until the hand-written wait; under register pressure hipcc moves live values about (an instance with
+// 32 slots copied a just-requested pixel to an AGPR and took the register for something else: wrong pixels, then a load
+// landing on an address -- a fault).  So only instances with registers to spare take it (tests/test_abi_cpu.py reads their
+// counts from the code object: no AGPRs, under 200 VGPRs); the others use plain loads and leave the waiting to the compiler.
+constexpr bool hand_pipelined(int maxt, int nacc, int nq, bool inh) {
+    return nacc <= 16 && 2 * maxt + 2 * nacc + 16 + 2 * kPFD * nq * (inh ? 2 : 4) + 40 <= 192;
+}
+
+template <int MAXT, int NACC, int NQ, bool INH, bool HAND>
 __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int rows_per_wg) {
     static_assert(NQ * kLanes <= kRowPx, "a lane stages pixels lane + q * kLanes of the strip's footprint");
     __shared__ __align__(16) float lds[2 * kRowFl];     // two source rows, one zero pixel behind each
-    __shared__ int seg[3];                          // first / last source row of the segment, "a line has no taps"
+    __shared__ int seg[4];                          // first / last source row of the segment, "a line has no taps", first line with taps
+#ifdef CVS_DIAG
+    const int skip = rows_per_wg >> 16;             // tools/: parts of the row step switched off (WRONG pixels: timing only)
+    rows_per_wg &= 0xFFFF;
+#else
+    constexpr int skip = 0;
+#endif
     const int lane = threadIdx.x, pr = lane & 1;
-    const int c0 = fp.tx0 + (int)blockIdx.x * kCols, c1 = min(c0 + kCols - 1, fp.tx1);
+    const int c0 = fp.tx0 + (int)blockIdx.x * kCols;
     const int tcol = c0 + (lane >> 1);
     const bool col_live = tcol <= fp.tx1;
     const int nlines = fp.ty1 - fp.ty0 + 1;
     const int ia = (int)blockIdx.y * rows_per_wg, ib = min(ia + rows_per_wg - 1, nlines - 1);     // target lines, 0-based
     const int vstride = fp.v.stride, hstride = fp.h.stride;
 
-    if (lane == 0) { seg[0] = INT_MAX; seg[1] = INT_MIN; seg[2] = 0; }
+    if (lane == 0) { seg[0] = INT_MAX; seg[1] = INT_MIN; seg[2] = 0; seg[3] = INT_MAX; }
     __syncthreads();
     for (int i = ia + lane; i <= ib; i += kLanes) {
         const int n = min(fp.v.ntaps[i], vstride);
@@ -76,15 +108,16 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
             const int a = fp.v.src[(size_t)i * vstride];
             atomicMin(&seg[0], a);
             atomicMax(&seg[1], a + n - 1);
+            atomicMin(&seg[3], i);
         } else seg[2] = 1;
     }
-    // source columns under the strip: union of the footprints of its 32-column tiles (host-built, first > last = empty)
-    int sx_lo = INT_MAX, sx_hi = INT_MIN;
-    for (int t = (c0 - fp.tx0) / CVK_FIR2D_TILE_X; t <= (c1 - fp.tx0) / CVK_FIR2D_TILE_X; t++) {
-        const int lo = fp.h.foot[2 * t], hi = fp.h.foot[2 * t + 1];
-        if (hi >= lo) { sx_lo = min(sx_lo, lo); sx_hi = max(sx_hi, hi); }
-    }
+    // source columns under the strip (host-built; first > last = empty)
+    static_assert(kCols == CVK_FIR2D_TILE_X, "a strip is one tile of the footprint table");
+    const konst foot = as_konst(fp.h.foot);
+    int sx_lo = (int)foot[2 * blockIdx.x], sx_hi = (int)foot[2 * blockIdx.x + 1];
     if (sx_hi < sx_lo) sx_lo = sx_hi = fp.source.fx0;                         // no column of the strip has taps: any pixel will do
+    sx_lo = __builtin_amdgcn_readfirstlane(sx_lo);                            // (the row pointer below must be in scalar registers)
+    sx_hi = __builtin_amdgcn_readfirstlane(sx_hi);
     const int sw = min(sx_hi - sx_lo + 1, NQ * kLanes);                       // (the host chose NQ to cover every strip)
     // this lane's horizontal taps as float offsets into the LDS row.  Lists shorter than MAXT are padded with weight 0 on
     // the zero pixel: acc + 0 * 0 == acc (a padded tap on a real pixel would turn an Inf or NaN there into a NaN of the sum)
@@ -107,7 +140,7 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
     char *tbase = reinterpret_cast<char *>(fp.target.data) + ((size_t)(tcol - fp.target.fx0)) * tpx + (size_t)pr * (tpx / 2);
     const size_t trow = (size_t)fp.target.pitch * tpx;
     const bool out_half = fp.out_half != 0;
-    auto store_line = [&](int i, f32x2 v) {
+    auto store_line = [&](int i, f32x2 v) __attribute__((always_inline)) {
         if (!col_live) return;
         char *o = tbase + (size_t)(fp.ty0 + i - fp.target.fy0) * trow;
         if (out_half) *reinterpret_cast<uint32_t *>(o) = cvs::f2h_rz2(v.x, v.y);
@@ -118,31 +151,66 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
             if (fp.v.ntaps[i] <= 0) store_line(i, f32x2{ 0.0f, 0.0f });
     }
     if (s_lo > s_hi) return;                        // uniform
+    // The lines with taps are one run of consecutive lines (the host checked) and end in ascending order, so the stores of
+    // this segment go to consecutive target rows: a pointer that moves down a row per store, no address arithmetic.
+    char *optr = tbase + (size_t)(fp.ty0 + __builtin_amdgcn_readfirstlane(seg[3]) - fp.target.fy0) * trow;
+    auto store_next = [&](f32x2 v) __attribute__((always_inline)) {
+        if (col_live) {
+            if (out_half) *reinterpret_cast<uint32_t *>(optr) = cvs::f2h_rz2(v.x, v.y);
+            else *reinterpret_cast<float2 *>(optr) = make_float2(v.x, v.y);
+        }
+        optr += trow;
+    };
 
-    f32x2 acc[NACC];
-#pragma unroll
-    for (int j = 0; j < NACC; j++) acc[j] = f32x2{ 0.0f, 0.0f };
+    // The accumulators: slot j is elements 2j, 2j + 1 of ONE register vector (the widest register tuple is 32 wide: 16 slots
+    // at most).  The row step addresses the slots with constants; the line that ends on a row is in
+    // a slot only known at run time -- wave-uniform, so hipcc reads and clears it through the GPR index register
+    // (s_set_gpr_idx_on + v_mov), with no branch.  (A taken branch costs this kernel an instruction fetch, ~64 cycles with
+    // two or three waves per SIMD: the first form chose the slot with a switch and spent a third of a 1.5x enlargement
+    // in it, profiles/r02/general_fir_attempts.txt.)
+    static_assert(NACC == 8 || NACC == 16, "one register vector of 2 * NACC floats");
+    typedef float accvec __attribute__((ext_vector_type(2 * NACC)));
+    accvec acc = 0.0f;
 
     // staging: a lane fetches the pixels lane + q * kLanes of the strip's footprint (clamped to its last pixel: every load
     // is unconditional; what lands beyond the footprint in LDS is never read).  The row pointer is wave-uniform and moves
-    // by one row per step; past the segment's last row it stays where it is.
+    // by one row per fetch; past the segment's last row it stays where it is (the same row again: valid memory, never used).
     constexpr int PXB = INH ? 8 : 16;
-    int loff[NQ];
+    uint32_t loff[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; q++) loff[q] = min(lane + q * kLanes, sw - 1) * PXB;
-    const size_t rowb = (size_t)fp.source.pitch * PXB;
-    const char *rp = reinterpret_cast<const char *>(fp.source.data) + (size_t)(sx_lo - fp.source.fx0) * PXB + (size_t)(s_lo - fp.source.fy0) * rowb;
+    for (int q = 0; q < NQ; q++) loff[q] = (uint32_t)(min(lane + q * kLanes, sw - 1) * PXB);
+    const uint32_t rowb = __builtin_amdgcn_readfirstlane((uint32_t)fp.source.pitch * PXB);     // (the host admits rows below 4 GiB)
+    const char *rp;
+    {   // (the 64-bit product below is VALU work: back into scalar registers by hand, the asm loads take an SGPR pair)
+        const uint64_t a = reinterpret_cast<uint64_t>(fp.source.data) + (uint64_t)(sx_lo - fp.source.fx0) * PXB + (uint64_t)(s_lo - fp.source.fy0) * (uint64_t)rowb;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+        rp = reinterpret_cast<const char *>(((uint64_t)hi << 32) | lo);
+    }
     int s_next = s_lo;
-    SrcPx<INH> pf[kPFD][NQ];
-    auto fetch_row = [&](SrcPx<INH> (&dst)[NQ]) {
+    typedef SrcPx<INH> Group[kPFD][NQ];
+    auto issue_group = [&](Group &g) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            if constexpr (INH) dst[q].v = *reinterpret_cast<const uint2 *>(rp + loff[q]);
-            else dst[q].v = *reinterpret_cast<const uint4 *>(rp + loff[q]);
+        for (int d = 0; d < kPFD; d++) {
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                if constexpr (HAND) asm_ld(g[d][q], rp, loff[q]);
+                else g[d][q].v = *reinterpret_cast<const decltype(g[d][q].v) *>(rp + loff[q]);
+            }
+            const bool more = s_next < s_hi;                       // uniform; scalar selects, scalar add
+            rp += more ? rowb : 0u;
+            s_next += more ? 1 : 0;
         }
-        if (s_next < s_hi) { rp += rowb; s_next++; }               // uniform
     };
-    auto stage_row = [&](float *buf, const SrcPx<INH> (&src)[NQ]) {
+    auto wait_group = [&](Group &g) __attribute__((always_inline)) {
+        if constexpr (!HAND) return;
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#pragma unroll
+        for (int d = 0; d < kPFD; d++) {
+#pragma unroll
+            for (int q = 0; q < NQ; q++) asm volatile("" : "+v"(g[d][q].v));      // what reads g from here on reads it after the wait
+        }
+    };
+    auto stage_row = [&](float *buf, const SrcPx<INH> (&src)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < NQ; q++) {
             float4 v;
@@ -151,14 +219,12 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
             *reinterpret_cast<float4 *>(buf + 4 * (lane + q * kLanes)) = v;
         }
     };
-#pragma unroll
-    for (int d = 0; d < kPFD; d++) fetch_row(pf[d]);
 
     // a source row's record (cvk_fir_axis.rec): slots that end there, first line that ends there, weight per slot (0 for
     // the slots that do not take the row).  Scalar loads, a row ahead; the host keeps one spare record behind the last.
     struct Rec { uint32_t ends; int first_end; float w[NACC]; };
     konst rec_next = as_konst(fp.v.rec) + (ptrdiff_t)(s_lo - fp.v.rec_s0) * (NACC + 4);
-    auto load_rec = [&]() {
+    auto load_rec = [&]() __attribute__((always_inline)) {
         Rec r;
         r.ends = rec_next[1]; r.first_end = (int)rec_next[2];
 #pragma unroll
@@ -166,11 +232,16 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
         rec_next += NACC + 4;
         return r;
     };
-    auto filter_row = [&](const float *buf, const Rec &rec) {
+    // one source row, first half: LDS -> horizontal sum -> every accumulator slot
+    auto filter = [&](float *buf, const SrcPx<INH> (&px)[NQ], const Rec &rec, Rec &rec_after) __attribute__((always_inline)) {
+        if (!(skip & 8)) stage_row(buf, px);
+        __builtin_amdgcn_wave_barrier();                           // (compiler fence; the hardware keeps a wave's LDS accesses in order)
         f32x2 h = { 0.0f, 0.0f };
+        if (skip & 4) h = f32x2{ __uint_as_float(px[0].v.x), 1.0f };
+        else
 #pragma unroll
-        for (int k0 = 0; k0 < MAXT; k0 += 8) {                     // reads first, then products, then the sum in tap order
-            constexpr int CH = MAXT - 0 < 8 ? MAXT : 8;
+        for (int k0 = 0; k0 < MAXT; k0 += 16) {                    // reads first, then products, then the sum in tap order
+            constexpr int CH = MAXT < 16 ? MAXT : 16;
             f32x2 x[CH];
 #pragma unroll
             for (int c = 0; c < CH; c++) if (k0 + c < MAXT) x[c] = *reinterpret_cast<const f32x2 *>(buf + aoff[k0 + c]);
@@ -179,58 +250,86 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
 #pragma unroll
             for (int c = 0; c < CH; c++) if (k0 + c < MAXT) h = h + x[c];
         }
+        // the next row's record goes out here: behind the last LDS read (an outstanding scalar load makes every LDS wait a
+        // wait for everything), a whole accumulator pass and the next row's staging before anyone needs it
+        __builtin_amdgcn_sched_barrier(0);
+        rec_after = load_rec();
+        __builtin_amdgcn_sched_barrier(0);
+        // every slot takes the row; the slots it does not belong to have weight 0.  0 * h is a zero that leaves the sum as it
+        // is -- unless h is Inf or NaN: then (rare: one test per row for the whole wave) the product that lets zero win
+        const bool odd = __builtin_amdgcn_class(h.x, 0x207) || __builtin_amdgcn_class(h.y, 0x207);       // NaN, -Inf, +Inf
+        auto add_to = [&](int j, f32x2 p) __attribute__((always_inline)) {
+            const f32x2 t = f32x2{ acc[2 * j], acc[2 * j + 1] } + p;
+            acc[2 * j] = t.x; acc[2 * j + 1] = t.y;
+        };
+        if (skip & 2) add_to(0, h);
+        else if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) == 0, 1)) {
 #pragma unroll
-        for (int j = 0; j < NACC; j++) acc[j] = acc[j] + f32x2{ mul_zero_wins(h.x, rec.w[j]), mul_zero_wins(h.y, rec.w[j]) };
-        if (rec.ends) {                                            // uniform
+            for (int j = 0; j < NACC; j++) add_to(j, h * rec.w[j]);
+        } else {
+            cvs::rare_path();
 #pragma unroll
-            for (int j = 0; j < NACC; j++) {
-                if (rec.ends & (1u << j)) {
-                    const int i = rec.first_end + ((j - rec.first_end) & (NACC - 1));
-                    if (i >= ia && i <= ib) store_line(i, acc[j]);
-                    acc[j] = f32x2{ 0.0f, 0.0f };
-                }
-            }
+            for (int j = 0; j < NACC; j++) add_to(j, f32x2{ mul_zero_wins(h.x, rec.w[j]), mul_zero_wins(h.y, rec.w[j]) });
         }
     };
-    static_assert(kPFD == 4, "the loop body below is four steps written out: row buffer and record alternate");
+    // second half: the lines that end on this row are stored
+    auto finish = [&](const Rec &rec) __attribute__((always_inline)) {
+        if (rec.ends && !(skip & 1)) {                             // uniform
+            // lines end in ascending order, a line's slot is its index & (NACC - 1): one or two lines here (more only on the
+            // frame's last rows), each taken out of its slot through the GPR index and stored if it is the segment's own
+            int n_end = __builtin_popcount(rec.ends);
+            int i = rec.first_end;
+            do {
+                const int e = 2 * (i & (NACC - 1));
+                const f32x2 v = { acc[e], acc[e + 1] };
+                acc[e] = 0.0f; acc[e + 1] = 0.0f;
+                if (i >= ia && i <= ib) store_next(v);
+                i++;
+            } while (--n_end);
+        }
+    };
+    static_assert(kPFD == 4, "four steps written out: row buffer and record alternate");
     Rec ra = load_rec(), rb;
-    for (int sb = s_lo; sb <= s_hi; sb += kPFD) {                  // uniform bounds: every wave runs every iteration
-        // step 0
-        stage_row(lds, pf[0]); fetch_row(pf[0]);
-        __syncthreads();
-        rb = load_rec();
-        filter_row(lds, ra);
-        if (sb + 1 > s_hi) break;
-        // step 1
-        stage_row(lds + kRowFl, pf[1]); fetch_row(pf[1]);
-        __syncthreads();
-        ra = load_rec();
-        filter_row(lds + kRowFl, rb);
-        if (sb + 2 > s_hi) break;
-        // step 2
-        stage_row(lds, pf[2]); fetch_row(pf[2]);
-        __syncthreads();
-        rb = load_rec();
-        filter_row(lds, ra);
-        if (sb + 3 > s_hi) break;
-        // step 3
-        stage_row(lds + kRowFl, pf[3]); fetch_row(pf[3]);
-        __syncthreads();
-        ra = load_rec();
-        filter_row(lds + kRowFl, rb);
-    }
+    int s = s_lo;
+    // Four rows out of the group `cur`.  The wait for the NEXT group's pixels (vmcnt(0): it waits for this wave's stores too)
+    // and the request for the group after it sit between the two halves of the last row: the youngest store outstanding at
+    // the wait is then a whole row old, not a few instructions (a 1.5x enlargement stores on every row).
+    // false: the segment's last row has been filtered (uniform)
+    auto four_rows = [&](Group &cur, Group &nxt) __attribute__((always_inline)) -> bool {
+        filter(lds, cur[0], ra, rb);
+        finish(ra);
+        if (++s > s_hi) return false;
+        filter(lds + kRowFl, cur[1], rb, ra);
+        finish(rb);
+        if (++s > s_hi) return false;
+        filter(lds, cur[2], ra, rb);
+        finish(ra);
+        if (++s > s_hi) return false;
+        filter(lds + kRowFl, cur[3], rb, ra);
+        wait_group(nxt);
+        issue_group(cur);
+        finish(rb);
+        return ++s <= s_hi;
+    };
+    Group ga, gb;
+    issue_group(ga);
+    wait_group(ga);
+    issue_group(gb);
+    while (four_rows(ga, gb) && four_rows(gb, ga)) {}
+    if constexpr (HAND) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");        // nothing of this wave is in flight when it ends
 }
 
 // rows per workgroup: one round of resident workgroups over the frame, but segments of at least three times the rows a
 // source row feeds (a segment re-filters the source rows its first lines reach back to: about max_active target rows' worth)
 template <int MAXT, int NACC, int NQ, bool INH>
 int launch(const cvk_fir2d_params &fp, int cus, hipStream_t s) {
+    constexpr bool HAND = hand_pipelined(MAXT, NACC, NQ, INH);
     const int cols = fp.tx1 - fp.tx0 + 1, rows = fp.ty1 - fp.ty0 + 1;
     const int strips = (cols + kCols - 1) / kCols;
     static int per_cu = 0;
     if (!per_cu) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fir_lanes<MAXT, NACC, NQ, INH>, kLanes, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fir_lanes<MAXT, NACC, NQ, INH, HAND>, kLanes, 0) != hipSuccess || n < 1) n = 1;
         per_cu = n;
     }
     int segs = (per_cu * (cus > 0 ? cus : 256)) / strips;
@@ -239,8 +338,14 @@ int launch(const cvk_fir2d_params &fp, int cus, hipStream_t s) {
     if (r < 3 * fp.v.max_active) r = 3 * fp.v.max_active;
     if (r > 256) r = 256;
     if (r > rows) r = rows;
+#ifdef CVS_DIAG
+    if (const char *e = getenv("CVS_LANES_ROWS")) { const int v = atoi(e); if (v > 0 && v <= 4096) r = v < rows ? v : rows; }
+#endif
     dim3 grid((unsigned)strips, (unsigned)((rows + r - 1) / r));
-    hipLaunchKernelGGL((k_fir_lanes<MAXT, NACC, NQ, INH>), grid, dim3(kLanes), 0, s, fp, r);
+#ifdef CVS_DIAG
+    if (const char *e = getenv("CVS_LANES_SKIP")) r |= atoi(e) << 16;
+#endif
+    hipLaunchKernelGGL((k_fir_lanes<MAXT, NACC, NQ, INH, HAND>), grid, dim3(kLanes), 0, s, fp, r);
     return (int)hipGetLastError();
 }
 
@@ -251,16 +356,15 @@ int launch(const cvk_fir2d_params &fp, int cus, hipStream_t s) {
 struct Instance { int maxt, nacc, nq; int (*f16)(const cvk_fir2d_params &, int, hipStream_t); int (*f32)(const cvk_fir2d_params &, int, hipStream_t); };
 #define CVK_LANES_INSTANCE(T, A, Q) { T, A, Q, launch<T, A, Q, true>, launch<T, A, Q, false> }
 const Instance kInstances[] = {
-    CVK_LANES_INSTANCE(8, 8, 1),   CVK_LANES_INSTANCE(8, 16, 1),  CVK_LANES_INSTANCE(8, 32, 1),      // enlarging (7 taps), short blurs
-    CVK_LANES_INSTANCE(12, 8, 1),  CVK_LANES_INSTANCE(12, 8, 2),  CVK_LANES_INSTANCE(12, 16, 1),     // 0.5 < factor < 1
+    CVK_LANES_INSTANCE(8, 8, 1),   CVK_LANES_INSTANCE(8, 16, 1),                                     // short blurs
+    CVK_LANES_INSTANCE(12, 8, 1),  CVK_LANES_INSTANCE(12, 8, 2),  CVK_LANES_INSTANCE(12, 16, 1),     // 0.5 < factor < 1; enlarging up to 1.6x
     CVK_LANES_INSTANCE(16, 8, 2),  CVK_LANES_INSTANCE(16, 16, 1),                                    // 0.4 <= factor <= 0.5
-    CVK_LANES_INSTANCE(24, 8, 4),  CVK_LANES_INSTANCE(24, 32, 1),                                    // down to 0.26; blurs of 17..24
-    CVK_LANES_INSTANCE(32, 8, 4),  CVK_LANES_INSTANCE(32, 32, 1),                                    // down to 0.19; blurs of 25..32
-    CVK_LANES_INSTANCE(32, 16, 4), CVK_LANES_INSTANCE(32, 32, 4),
+    CVK_LANES_INSTANCE(24, 8, 4),                                                                    // down to 0.26
+    CVK_LANES_INSTANCE(32, 8, 4),  CVK_LANES_INSTANCE(32, 16, 4),                                    // down to 0.19, and whatever else fits
 };
 
 const Instance *pick(const cvk_fir2d_params *fp) {
-    const int nq = (fp->h.foot64 + kLanes - 1) / kLanes;
+    const int nq = (fp->max_sw + kLanes - 1) / kLanes;            // max_sw: widest footprint of a 32-column tile
     for (const Instance &in : kInstances)
         if (fp->h.max_taps <= in.maxt && fp->v.nacc == in.nacc && nq <= in.nq) return &in;
     return NULL;
@@ -269,8 +373,8 @@ const Instance *pick(const cvk_fir2d_params *fp) {
 }  // namespace
 
 extern "C" int cvk_fir_lanes_supported(const cvk_fir2d_params *fp) {
-    return fp->v.rec != NULL && !fp->v.rec_zero_weight && (fp->v.nacc == 8 || fp->v.nacc == 16 || fp->v.nacc == 32) &&
-           fp->v.max_active >= 1 && fp->v.max_active <= fp->v.nacc && fp->h.max_taps >= 1 && fp->h.foot64 >= 1 && pick(fp) != NULL;
+    return fp->v.rec != NULL && !fp->v.rec_zero_weight && (fp->v.nacc == 8 || fp->v.nacc == 16) &&      /* 32 slots: the older kernels */
+           fp->v.max_active >= 1 && fp->v.max_active <= fp->v.nacc && fp->h.max_taps >= 1 && fp->max_sw >= 1 && fp->max_sw <= kRowPx && pick(fp) != NULL;
 }
 
 extern "C" int cvk_fir_lanes(const cvk_fir2d_params *fp, int cus, void *stream) {
