@@ -76,9 +76,11 @@ __device__ __forceinline__ void asm_ld(SrcPx<false> &dst, const void *row, uint3
 // stay where they are until the hand-written wait; under register pressure hipcc moves live values about (an instance with
 // 32 slots copied a just-requested pixel to an AGPR and took the register for something else: wrong pixels, then a load
 // landing on an address -- a fault).  So only instances with registers to spare take it (tests/test_abi_cpu.py reads their
-// counts from the code object: no AGPRs, under 200 VGPRs); the others use plain loads and leave the waiting to the compiler.
+// counts from the code object: no AGPRs, at most 224 VGPRs); the others use plain loads and leave the waiting to the compiler.
+// (8 slots: the instances that gather a row ahead and hold two rows of taps, see `filter`)
+constexpr bool taps_row_ahead(int nacc) { return nacc == 8; }
 constexpr bool hand_pipelined(int maxt, int nacc, int nq, bool inh) {
-    return nacc <= 16 && 2 * maxt + 2 * nacc + 16 + 2 * kPFD * nq * (inh ? 2 : 4) + 40 <= 192;
+    return (taps_row_ahead(nacc) ? 4 : 2) * maxt + 2 * nacc + 2 * kPFD * nq * (inh ? 2 : 4) + 60 <= 200;
 }
 
 template <int MAXT, int NACC, int NQ, bool INH, bool HAND>
@@ -232,23 +234,38 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
         rec_next += NACC + 4;
         return r;
     };
-    // one source row, first half: LDS -> horizontal sum -> every accumulator slot
-    auto filter = [&](float *buf, const SrcPx<INH> (&px)[NQ], const Rec &rec, Rec &rec_after) __attribute__((always_inline)) {
-        if (!(skip & 8)) stage_row(buf, px);
-        __builtin_amdgcn_wave_barrier();                           // (compiler fence; the hardware keeps a wave's LDS accesses in order)
+    // With 8 slots (reductions: long tap lists, few slots) a row step is software-pipelined over two rows: the taps of row
+    // s + 1 are gathered from LDS (into `xn`) before the accumulator pass of row s, so that the LDS round trip (~200 cycles
+    // with two or three waves per SIMD) runs under it.  With 16 slots (enlargements) the second set of tap registers would cost
+    // a wave per SIMD, which costs more than the round trip: those instances gather and sum in the same step.
+    constexpr bool AHEAD = taps_row_ahead(NACC);
+    typedef f32x2 Taps[MAXT];
+    auto gather = [&](const float *buf, Taps &x) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < MAXT; k++) x[k] = *reinterpret_cast<const f32x2 *>(buf + aoff[k]);
+    };
+    // AHEAD: row s: horizontal sum of its taps `xc` (gathered a step ago) -> row s + 1 (`px`) into the LDS buffer `buf`, its
+    // taps requested into `xn` -> every accumulator slot takes row s.
+    // otherwise: row s (`px`) into `buf`, gathered into `xc`, summed, every slot takes it (`xn` unused).
+    auto filter = [&](Taps &xc, Taps &xn, float *buf, const SrcPx<INH> (&px)[NQ], const Rec &rec, Rec &rec_after) __attribute__((always_inline)) {
+        if constexpr (!AHEAD) {
+            if (!(skip & 8)) stage_row(buf, px);
+            __builtin_amdgcn_wave_barrier();                       // (compiler fence; the hardware keeps a wave's LDS accesses in order)
+            gather(buf, xc);
+        }
         f32x2 h = { 0.0f, 0.0f };
         if (skip & 4) h = f32x2{ __uint_as_float(px[0].v.x), 1.0f };
-        else
+        else {                                                     // products, then the sum in tap order
 #pragma unroll
-        for (int k0 = 0; k0 < MAXT; k0 += 16) {                    // reads first, then products, then the sum in tap order
-            constexpr int CH = MAXT < 16 ? MAXT : 16;
-            f32x2 x[CH];
+            for (int k = 0; k < MAXT; k++) xc[k] = xc[k] * wt[k];
 #pragma unroll
-            for (int c = 0; c < CH; c++) if (k0 + c < MAXT) x[c] = *reinterpret_cast<const f32x2 *>(buf + aoff[k0 + c]);
-#pragma unroll
-            for (int c = 0; c < CH; c++) if (k0 + c < MAXT) x[c] = x[c] * wt[k0 + c];
-#pragma unroll
-            for (int c = 0; c < CH; c++) if (k0 + c < MAXT) h = h + x[c];
+            for (int k = 0; k < MAXT; k++) h = h + xc[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (AHEAD) {
+            if (!(skip & 8)) stage_row(buf, px);
+            __builtin_amdgcn_wave_barrier();
+            gather(buf, xn);
         }
         // the next row's record goes out here: behind the last LDS read (an outstanding scalar load makes every LDS wait a
         // wait for everything), a whole accumulator pass and the next row's staging before anyone needs it
@@ -291,30 +308,52 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
     static_assert(kPFD == 4, "four steps written out: row buffer and record alternate");
     Rec ra = load_rec(), rb;
     int s = s_lo;
-    // Four rows out of the group `cur`.  The wait for the NEXT group's pixels (vmcnt(0): it waits for this wave's stores too)
-    // and the request for the group after it sit between the two halves of the last row: the youngest store outstanding at
-    // the wait is then a whole row old, not a few instructions (a 1.5x enlargement stores on every row).
+    Group ga, gb;
+    Taps xa, xb;
+    // Four rows out of the group `cur` (AHEAD: its first row is in LDS and gathered already).
     // false: the segment's last row has been filtered (uniform)
     auto four_rows = [&](Group &cur, Group &nxt) __attribute__((always_inline)) -> bool {
-        filter(lds, cur[0], ra, rb);
-        finish(ra);
-        if (++s > s_hi) return false;
-        filter(lds + kRowFl, cur[1], rb, ra);
-        finish(rb);
-        if (++s > s_hi) return false;
-        filter(lds, cur[2], ra, rb);
-        finish(ra);
-        if (++s > s_hi) return false;
-        filter(lds + kRowFl, cur[3], rb, ra);
-        wait_group(nxt);
-        issue_group(cur);
-        finish(rb);
+        if constexpr (AHEAD) {
+            filter(xa, xb, lds + kRowFl, cur[1], ra, rb);
+            finish(ra);
+            if (++s > s_hi) return false;
+            filter(xb, xa, lds, cur[2], rb, ra);
+            finish(rb);
+            if (++s > s_hi) return false;
+            filter(xa, xb, lds + kRowFl, cur[3], ra, rb);
+            finish(ra);
+            if (++s > s_hi) return false;
+            wait_group(nxt);                                       // the row after this group's last is the next group's first
+            issue_group(cur);                                      // (cur[3] went to LDS a step ago)
+            filter(xb, xa, lds, nxt[0], rb, ra);
+            finish(rb);
+        } else {
+            filter(xa, xa, lds, cur[0], ra, rb);
+            finish(ra);
+            if (++s > s_hi) return false;
+            filter(xa, xa, lds + kRowFl, cur[1], rb, ra);
+            finish(rb);
+            if (++s > s_hi) return false;
+            filter(xa, xa, lds, cur[2], ra, rb);
+            finish(ra);
+            if (++s > s_hi) return false;
+            filter(xa, xa, lds + kRowFl, cur[3], rb, ra);
+            // the wait for the next group (vmcnt(0): it waits for this wave's stores too) between the halves of the last row:
+            // the youngest store outstanding is then a row old (an enlargement stores on every row)
+            wait_group(nxt);
+            issue_group(cur);
+            finish(rb);
+        }
         return ++s <= s_hi;
     };
-    Group ga, gb;
     issue_group(ga);
     wait_group(ga);
     issue_group(gb);
+    if constexpr (AHEAD) {
+        stage_row(lds, ga[0]);
+        __builtin_amdgcn_wave_barrier();
+        gather(lds, xa);
+    }
     while (four_rows(ga, gb) && four_rows(gb, ga)) {}
     if constexpr (HAND) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");        // nothing of this wave is in flight when it ends
 }

@@ -223,7 +223,7 @@ def test_hot_kernels_keep_their_state_in_registers():
                 # in flight into it must not be touched before the hand-written wait
                 for agprs, name, vgprs in re.findall(r"\.agpr_count:\s+(\d+)(?:(?!\.agpr_count).)*?\.name:\s+(\S*k_fir_lanes\S+)(?:(?!\.agpr_count).)*?\.vgpr_count:\s+(\d+)", notes, re.S):
                     if name.endswith("Lb1EEEv16cvk_fir2d_paramsi"):
-                        assert int(agprs) == 0 and int(vgprs) <= 200, (name, agprs, vgprs)
+                        assert int(agprs) == 0 and int(vgprs) <= 224, (name, agprs, vgprs)
                         hand += 1
     assert checked >= 20, checked
     assert hand >= 10, hand
