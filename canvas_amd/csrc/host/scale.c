@@ -443,7 +443,7 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
         }
         if (s_last >= s_first && one_run) {
             rec_s0 = s_first; rec_n = s_last - s_first + 1;
-            const size_t rs = (size_t)nacc + 4;
+            const size_t rs = 2 * (size_t)nacc + 4;              /* every weight twice: a register PAIR for the packed multiply */
             rec = calloc(((size_t)rec_n + 1) * rs, sizeof *rec);          /* + one spare record: the kernel loads a row ahead */
             if (!rec) { free(foot); free(ntaps); return -1; }
             for (int i = 0; i < lines; i++) {
@@ -453,7 +453,8 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
                 for (int k = 0; k < n; k++) {
                     uint32_t *r = rec + (size_t)(a + k - rec_s0) * rs;
                     r[0] |= 1u << slot;
-                    memcpy(&r[4 + slot], &tb->taps[(size_t)i * tb->stride + k], 4);
+                    memcpy(&r[4 + 2 * slot], &tb->taps[(size_t)i * tb->stride + k], 4);
+                    r[5 + 2 * slot] = r[4 + 2 * slot];
                     if (tb->taps[(size_t)i * tb->stride + k] == 0.0f) rec_zero_weight = 1;
                     if (k == n - 1) {
                         if (!r[1]) r[2] = (uint32_t)i;           /* lines come in ascending order: the first to end here */
@@ -468,7 +469,7 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     const size_t off_tap = off_src + ((n_t * sizeof(int) + 255) & ~(size_t)255);
     const size_t off_foot = off_tap + ((n_t * sizeof(float) + 255) & ~(size_t)255);
     const size_t off_rec = off_foot + ((sizeof(int) * 2 * (size_t)(tiles ? tiles : 1) + 255) & ~(size_t)255);
-    const size_t rec_bytes = rec ? ((size_t)rec_n + 1) * ((size_t)nacc + 4) * sizeof *rec : 0;
+    const size_t rec_bytes = rec ? ((size_t)rec_n + 1) * (2 * (size_t)nacc + 4) * sizeof *rec : 0;
     const size_t total = off_rec + (rec_bytes ? rec_bytes : 4);
     char *dev = NULL;
     hipError_t err = hipMalloc((void **)&dev, total);

@@ -77,10 +77,10 @@ __device__ __forceinline__ void asm_ld(SrcPx<false> &dst, const void *row, uint3
 // 32 slots copied a just-requested pixel to an AGPR and took the register for something else: wrong pixels, then a load
 // landing on an address -- a fault).  So only instances with registers to spare take it (tests/test_abi_cpu.py reads their
 // counts from the code object: no AGPRs, at most 224 VGPRs); the others use plain loads and leave the waiting to the compiler.
-// (8 slots: the instances that gather a row ahead and hold two rows of taps, see `filter`)
-constexpr bool taps_row_ahead(int nacc) { return nacc == 8; }
+// (8 slots, lists up to 16: the instances that gather a row ahead and hold two rows of taps, see `filter`)
+constexpr bool taps_row_ahead(int maxt, int nacc) { return nacc == 8 && maxt <= 16; }
 constexpr bool hand_pipelined(int maxt, int nacc, int nq, bool inh) {
-    return (taps_row_ahead(nacc) ? 4 : 2) * maxt + 2 * nacc + 2 * kPFD * nq * (inh ? 2 : 4) + 60 <= 200;
+    return (taps_row_ahead(maxt, nacc) ? 4 : 2) * maxt + 2 * nacc + 2 * kPFD * nq * (inh ? 2 : 4) + 60 <= 200;
 }
 
 template <int MAXT, int NACC, int NQ, bool INH, bool HAND>
@@ -224,21 +224,23 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
 
     // a source row's record (cvk_fir_axis.rec): slots that end there, first line that ends there, weight per slot (0 for
     // the slots that do not take the row).  Scalar loads, a row ahead; the host keeps one spare record behind the last.
-    struct Rec { uint32_t ends; int first_end; float w[NACC]; };
-    konst rec_next = as_konst(fp.v.rec) + (ptrdiff_t)(s_lo - fp.v.rec_s0) * (NACC + 4);
+    // (every weight comes twice: a scalar register pair is what the packed multiply takes; one copy would be moved to a
+    // vector register pair first, sixteen moves a row)
+    struct Rec { uint32_t ends; int first_end; f32x2 w[NACC]; };
+    konst rec_next = as_konst(fp.v.rec) + (ptrdiff_t)(s_lo - fp.v.rec_s0) * (2 * NACC + 4);
     auto load_rec = [&]() __attribute__((always_inline)) {
         Rec r;
         r.ends = rec_next[1]; r.first_end = (int)rec_next[2];
 #pragma unroll
-        for (int j = 0; j < NACC; j++) r.w[j] = __uint_as_float(rec_next[4 + j]);
-        rec_next += NACC + 4;
+        for (int j = 0; j < NACC; j++) r.w[j] = f32x2{ __uint_as_float(rec_next[4 + 2 * j]), __uint_as_float(rec_next[5 + 2 * j]) };
+        rec_next += 2 * NACC + 4;
         return r;
     };
-    // With 8 slots (reductions: long tap lists, few slots) a row step is software-pipelined over two rows: the taps of row
-    // s + 1 are gathered from LDS (into `xn`) before the accumulator pass of row s, so that the LDS round trip (~200 cycles
-    // with two or three waves per SIMD) runs under it.  With 16 slots (enlargements) the second set of tap registers would cost
-    // a wave per SIMD, which costs more than the round trip: those instances gather and sum in the same step.
-    constexpr bool AHEAD = taps_row_ahead(NACC);
+    // With 8 slots and lists up to 16 (reductions down to 0.4x) a row step is software-pipelined over two rows: the taps of
+    // row s + 1 are gathered from LDS (into `xn`) before the accumulator pass of row s, so that the LDS round trip (~200
+    // cycles with two or three waves per SIMD) runs under it.  With 16 slots (enlargements) or longer lists the second set of
+    // tap registers would cost a wave per SIMD, which costs more than the round trip: those gather and sum in the same step.
+    constexpr bool AHEAD = taps_row_ahead(MAXT, NACC);
     typedef f32x2 Taps[MAXT];
     auto gather = [&](const float *buf, Taps &x) __attribute__((always_inline)) {
 #pragma unroll
@@ -272,21 +274,26 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
         __builtin_amdgcn_sched_barrier(0);
         rec_after = load_rec();
         __builtin_amdgcn_sched_barrier(0);
-        // every slot takes the row; the slots it does not belong to have weight 0.  0 * h is a zero that leaves the sum as it
-        // is -- unless h is Inf or NaN: then (rare: one test per row for the whole wave) the product that lets zero win
+        // Every slot takes the row; the slots it does not belong to have weight 0: 0 * h is a zero that leaves the sum as it
+        // is -- unless h is Inf or NaN.  Lanes with such an h (rare) put 0 through the packed pass instead (adds an exact zero
+        // to every slot) and, in a pass of their own that only runs when the wave has such a lane, the product that lets zero
+        // win: a slot that takes the row gets acc + h * w with one rounding, as the gather would give it; the others acc + 0.
         const bool odd = __builtin_amdgcn_class(h.x, 0x207) || __builtin_amdgcn_class(h.y, 0x207);       // NaN, -Inf, +Inf
+        const f32x2 h_plain = odd ? f32x2{ 0.0f, 0.0f } : h;
         auto add_to = [&](int j, f32x2 p) __attribute__((always_inline)) {
             const f32x2 t = f32x2{ acc[2 * j], acc[2 * j + 1] } + p;
             acc[2 * j] = t.x; acc[2 * j + 1] = t.y;
         };
         if (skip & 2) add_to(0, h);
-        else if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) == 0, 1)) {
+        else {
 #pragma unroll
-            for (int j = 0; j < NACC; j++) add_to(j, h * rec.w[j]);
-        } else {
-            cvs::rare_path();
+            for (int j = 0; j < NACC; j++) add_to(j, h_plain * rec.w[j]);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0, 0)) {
+                cvs::rare_path();
+                const f32x2 h_odd = odd ? h : f32x2{ 0.0f, 0.0f };
 #pragma unroll
-            for (int j = 0; j < NACC; j++) add_to(j, f32x2{ mul_zero_wins(h.x, rec.w[j]), mul_zero_wins(h.y, rec.w[j]) });
+                for (int j = 0; j < NACC; j++) add_to(j, f32x2{ mul_zero_wins(h_odd.x, rec.w[j].x), mul_zero_wins(h_odd.y, rec.w[j].x) });
+            }
         }
     };
     // second half: the lines that end on this row are stored

@@ -821,6 +821,31 @@ def test_lanczos_resample_both_kernels(cvs, orc, force_fir, kernel, ssize, scur,
 
 
 @pytest.mark.parametrize("kernel", ["lanes", "stream", "tiled"])
+@pytest.mark.parametrize("ssize,tsize,fx,fy", [((400, 300), (160, 120), 0.4, 0.4), ((96, 54), (144, 81), 1.5, 1.5), ((300, 200), (225, 150), 0.75, 0.75)])
+def test_lanczos_resample_with_inf_and_nan_pixels(cvs, orc, force_fir, kernel, ssize, tsize, fx, fy):
+    """Inf and NaN in the source spread exactly as far as the taps that touch them: a tap the gather skips (a padded list
+    entry, an accumulator slot that does not take the row) must not turn them into NaNs elsewhere (0 * Inf)."""
+    rng = np.random.default_rng(64)
+    sfull = (0, 0, ssize[0] - 1, ssize[1] - 1)
+    src = rand_f32_frame(rng, sfull, None, lo=-0.5, hi=1.5)
+    h, w = src.array.shape[:2]
+    for k, v in enumerate([np.inf, -np.inf, np.nan, np.inf, np.nan, -np.inf]):
+        src.array[(37 * k + 5) % h, (53 * k + 11) % w, k % 4] = v
+    src.array[h - 1, w - 1, :] = np.inf                    # a frame corner, where lists are clipped
+    src.array[0, 0, 1] = np.nan
+    tfull = (0, 0, tsize[0] - 1, tsize[1] - 1)
+    want = HostFrame(tfull, np.float32)
+    orc.lib().orc_resample_lanczos_f32(want.ref(), src.ref(), C.c_float(fx), C.c_float(fy), 3)
+    assert 0 < np.count_nonzero(~np.isfinite(want.array)) < want.array.size // 4
+    force_fir(kernel)
+    d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(tfull, np.float32)
+    _lib.check(cvs.cvs_resample_lanczos_f32_dev(d_out.ref(), d_src.ref(), C.c_float(fx), C.c_float(fy), 3, None))
+    got = d_out.download()
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f32(got.array, want.array, "lanczos with non-finite pixels (%s)" % kernel)
+
+
+@pytest.mark.parametrize("kernel", ["lanes", "stream", "tiled"])
 @pytest.mark.parametrize("ntaps", [1, 2, 4, 10, 16])
 def test_even_and_short_blurs_both_kernels(cvs, orc, force_fir, kernel, ntaps):
     rng = np.random.default_rng(63)
