@@ -37,7 +37,7 @@ if w:
     print("waiting share (s_waitcnt/barrier) %.3f" % (tot["SQ_WAIT_ANY"] / w))
     print("issue-stall share                 %.3f" % (tot["SQ_WAIT_INST_ANY"] / w))
     if tot.get("SQ_BUSY_CYCLES"):
-        print("waves resident per SIMD (wave cycles / busy cycles / 4 per CU-SE accounting is approximate) %.2f" % (w / tot["SQ_BUSY_CYCLES"]))
+        print("waves resident per shader engine (wave quad-cycles * 4 / busy cycles) %.2f" % (4 * w / tot["SQ_BUSY_CYCLES"]))
 if "SQ_INSTS_VALU" in tot and "SQ_WAVES" in tot:
     n = tot["SQ_WAVES"]
     print("per wave: VALU %.0f  SALU %.0f  SMEM %.0f  LDS %.0f  VMEM rd %.0f wr %.0f  branch %.0f" % tuple(tot.get(k, 0) / n for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH")))
