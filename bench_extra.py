@@ -9,6 +9,8 @@ with copies of config 2's ring (same value distribution, opaque bottom layer), w
   config 3   3840x2160 -> 9-tap separable Gaussian (sigma 1.5) -> Lanczos3 to 1920x1080      cvs_blur_lanczos_f16_dev
   config 4   7680x4320 3-layer alpha-over stack                                             cvs_chain_color_over_f16_dev (m = NULL)
   config 5   3840x2160 10-node graph (4 sources, colour -> blur -> 4-step composite)        canvas_amd.stream.GraphStream
+  lanczos3_x0.40 / x0.75 / x1.50   3840x2160 Lanczos3 at factors other than 1/2: the GENERAL FIR path (per-line tap
+             tables, sweep_ops.hip), not a BASELINE config                                  cvs_resample_lanczos_f16_dev
 """
 import ctypes as C
 import time
@@ -86,6 +88,29 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
         out.append(rec)
     for d in smalls:
         d.free()
+
+    # ---------------------------------------------------------------- the general FIR path (no BASELINE config: VERDICT r01 item 6)
+    for factor, tag in ((0.4, "0.40"), (0.75, "0.75"), (1.5, "1.50")):
+        tw, th = int(w * factor), int(h * factor)
+        nout = 16 if factor < 1.0 else 6                                        # 16 x 66 MB of sources rotate either way
+        outs = [DeviceFrame((0, 0, tw - 1, th - 1), np.uint16) for _ in range(nout)]
+
+        def pass_l():
+            for i, src in enumerate(sources):
+                _lib.check(lib.cvs_resample_lanczos_f16_dev(outs[i % nout].ref(), src.ref(), C.c_float(factor), C.c_float(factor), 3, stream), "lanczos")
+
+        n, dt = _timed_passes(lib, _lib, [stream], pass_l, seconds / 3)
+        if nout < len(sources):                     # slot 0 was last written from another source: the generator's frame once more
+            _lib.check(lib.cvs_resample_lanczos_f16_dev(outs[0].ref(), sources[0].ref(), C.c_float(factor), C.c_float(factor), 3, stream), "lanczos")
+        digest = verify.canon_sha256(outs[0].download(stream).array)
+        in_bytes, out_bytes = 8, 8 * (tw * th) / (w * h)
+        rec = _record(dist, gather_stats, checksum52, "lanczos3_x" + tag, "3840x2160 f16 -> Lanczos3 -> %dx%d f16 (per-line tap tables)" % (tw, th),
+                      n * len(sources), w * h, dt, digest, verify.stream_fixture("lanczos3_3840x2160_x" + tag, g0), round(in_bytes + out_bytes, 2),
+                      "Mpixels/s and bytes are per INPUT pixel: source read once + target written once", rank)
+        if rec:
+            out.append(rec)
+        for d in outs:
+            d.free()
 
     # ---------------------------------------------------------------- config 4
     w8, h8, nl = 7680, 4320, 3

@@ -136,15 +136,24 @@ static int triangle_pass(any_frame *target, float tmin, const any_frame *source,
     const int t0 = axis ? trect.min.x : trect.min.y, t1 = axis ? trect.max.x : trect.max.y;
     cvk_view tv = cvs_view(target->data, &target->full), sv = cvs_view(source->data, &source->full);
 
-    /* video_scale.c:25-32,44: the target starts as zeros (all-zero bytes are 0.0 in either format) */
-    if (any_bytes(target)) CVS_HIP(hipMemsetAsync(target->data, 0, any_bytes(target), s));
-
     /* the per-line taps depend only on the geometry, which repeats from frame to frame: planned once, kept on the
-     * device; steady state is the zero fill and one gather launch, nothing synchronous */
+     * device; steady state is one gather launch (and the zero fill, when the pass leaves part of the target alone),
+     * nothing synchronous */
     cvk_fir_axis table;
     int used_lo, used_hi, pin = -1;
     int rc = triangle_table_cached(tmin, smin, factor, s0, s1, t0, t1, axis == 0 || lo <= hi, &table, &used_lo, &used_hi, &pin);
     if (rc != 0) return rc;
+    /* video_scale.c:25-32,44: the target starts as zeros (all-zero bytes are 0.0 in either format).  The gather writes every
+     * pixel of lines used_lo..used_hi x lo..hi (a line without taps gets its zeros there): when that is the whole buffer --
+     * the usual case -- the fill would only be overwritten (an enlarging 4K pass: 500 MB of the 1.3 GB it moved). */
+    {
+        const int o0 = axis ? trect.min.y : trect.min.x, o1 = axis ? trect.max.y : trect.max.x;
+        const bool covers = used_hi >= used_lo && hi >= lo && used_lo == t0 && used_hi == t1 && lo == o0 && hi == o1;
+        if (!covers && any_bytes(target)) {
+            hipError_t e_ = hipMemsetAsync(target->data, 0, any_bytes(target), s);
+            if (e_ != hipSuccess) { axis_done(pin, s); cvs_set_error("zero fill: %s", hipGetErrorString(e_)); return -1; }
+        }
+    }
     if (used_hi >= used_lo && hi >= lo) {
         /* the gather reads source lines named in the table; they lie inside the source window by construction */
         const size_t first = (size_t)(used_lo - t0);
@@ -408,17 +417,6 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
             }
         }
     }
-    int foot64 = 0;
-    for (int g = 0; g < lines; g += 64) {                   /* the lane-per-channel sweep's strips (sweep_ops.hip) */
-        int first = INT_MAX, last = INT_MIN;
-        for (int i = g; i < lines && i < g + 64; i++) {
-            if (!ntaps[i]) continue;
-            const int *src = tb->tap_src + (size_t)i * tb->stride;
-            if (src[0] < first) first = src[0];
-            if (src[ntaps[i] - 1] > last) last = src[ntaps[i] - 1];
-        }
-        if (last >= first && last - first + 1 > foot64) foot64 = last - first + 1;
-    }
     /* the table by SOURCE line (kernels.h cvk_fir_axis.rec) */
     uint32_t *rec = NULL;
     int rec_s0 = 0, rec_n = 0, nacc = 0, rec_zero_weight = 0;
@@ -489,7 +487,7 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     e->axis.max_taps = max_taps; e->axis.wide_foot = wide_foot; e->axis.max_active = max_active; e->axis.streamable = streamable;
     e->axis.rec = rec_bytes ? (const uint32_t *)(dev + off_rec) : NULL;
     e->axis.rec_s0 = rec_s0; e->axis.rec_n = rec_bytes ? rec_n : 0; e->axis.nacc = nacc;
-    e->axis.foot64 = foot64; e->axis.rec_zero_weight = rec_zero_weight;
+    e->axis.rec_zero_weight = rec_zero_weight;
     e->max_foot = max_foot;
     return 0;
 }
@@ -661,7 +659,7 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
      * Small footprints (enlargements, blurs) stay with the tiles, which are as fast or faster there.
      * cvs_fir_path_override() pins one or the other (parity tests of each kernel, A/B runs). */
     const int force = atomic_load(&g_fir_path);
-    /* First choice: the sweep with one lane per target column and channel (sweep_ops.hip), whenever the vertical table
+    /* First choice: the sweep with one lane per target column and channel pair (sweep_ops.hip), whenever the vertical table
      * could be turned round for it and the lists fit. */
     if ((force & CVS_FIR_PATH_LANES) || !(force & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED))) {
         if (cvk_fir_lanes_supported(&fp)) {

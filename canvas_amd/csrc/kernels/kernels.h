@@ -119,7 +119,7 @@ typedef struct {
     int wide_foot;             /* widest source footprint of any run of 128 lines starting at a multiple of 128 */
     int max_active;            /* as the vertical axis: the longest run of lines i..j such that line j starts at or before line i's last tap */
     int streamable;            /* every list is consecutive source lines, first and last taps never decrease from line to line */
-    /* the table turned round for the lane-per-channel sweep (sweep_ops.hip), present when streamable and max_active <= 32:
+    /* the table turned round for the channel-pair sweep (sweep_ops.hip), present when streamable and max_active <= 32:
      * one record of (2 * nacc + 4) dwords per SOURCE line rec_s0 .. rec_s0 + rec_n - 1.  A target line's accumulator slot is
      * its index & (nacc - 1).  [0] slots that take this source line, [1] slots for which it is the last tap, [2] index of
      * the first target line that ends here, [3] 0, [4 + 2 * slot] and [5 + 2 * slot] the slot's weight for this source line,
@@ -127,7 +127,6 @@ typedef struct {
     const uint32_t *rec;
     int rec_s0, rec_n, nacc;
     int rec_zero_weight;       /* some tap of the table has weight +-0 (the sweep tells "no tap" by weight 0: not for this table) */
-    int foot64;                /* widest source footprint of any run of 64 lines starting at a multiple of 64 */
 } cvk_fir_axis;
 typedef struct {
     cvk_view target, source;

@@ -7,6 +7,7 @@ with the committed hashes, so a libm or generator drift shows up as a mismatch r
 
     python tests/golden/make_checksums.py            # takes about a minute
     python tests/golden/make_checksums.py --stream 8 # frames 0..7 of every config -> stream_frames_sha256.json (minutes)
+    python tests/golden/make_checksums.py --stream 8 lanczos3_3840x2160_x0.40 ...   # only the named cases, merged into the file
 """
 import ctypes as C
 import hashlib
@@ -62,7 +63,21 @@ def config5(oracle, g=0):
     return oracle_graph(oracle, layers, np.array(REC709_RGB_TO_YPBPR, np.float32), oracle.transfer_table(0), None, synth.gaussian_taps(9, 1.5)).array
 
 
+def lanczos3(factor):
+    """stream-only cases (bench.py's `extra` records of the general FIR path): Lanczos3 of layer 1 at a factor that is not 1/2"""
+    def run(oracle, g=0):
+        from canvas_amd import synth
+        from canvas_amd.abi import HostFrame
+        src16 = synth.layer_frame(3840, 2160, 1, g)
+        src32 = HostFrame(src16.full_window, np.float32, oracle.half_to_float(src16.array))
+        out = HostFrame((0, 0, int(3840 * factor) - 1, int(2160 * factor) - 1), np.float32)
+        oracle.lib().orc_resample_lanczos_f32(out.ref(), src32.ref(), C.c_float(factor), C.c_float(factor), 3)
+        return oracle.float_to_half(out.array)
+    return run
+
+
 CASES = {"config2_3840x2160": config2, "config3_3840x2160_to_1920x1080": config3, "config4_7680x4320": config4, "config5_3840x2160": config5}
+STREAM_ONLY = {"lanczos3_3840x2160_x0.40": lanczos3(0.4), "lanczos3_3840x2160_x0.75": lanczos3(0.75), "lanczos3_3840x2160_x1.50": lanczos3(1.5)}
 
 
 def checksums(only=None):
@@ -85,7 +100,7 @@ def stream_checksums(nframes=8, only=None):
     import oracle
     oracle.lib()
     out = {}
-    for name, fn in CASES.items():
+    for name, fn in list(CASES.items()) + list(STREAM_ONLY.items()):
         if only and name not in only:
             continue
         out[name] = {}
@@ -99,8 +114,14 @@ def stream_checksums(nframes=8, only=None):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--stream":
         path = os.path.join(HERE, "stream_frames_sha256.json")
+        only = sys.argv[3:] or None                # names after the count: only those cases, merged into the file
+        new = stream_checksums(int(sys.argv[2]) if len(sys.argv) > 2 else 8, only)
+        if only and os.path.exists(path):
+            merged = json.load(open(path))
+            merged.update(new)
+            new = merged
         with open(path, "w") as f:
-            json.dump(stream_checksums(int(sys.argv[2]) if len(sys.argv) > 2 else 8), f, indent=1, sort_keys=True)
+            json.dump(new, f, indent=1, sort_keys=True)
             f.write("\n")
         print("wrote", path)
         sys.exit(0)
