@@ -37,6 +37,10 @@ odd = DeviceFrame((0, 0, int(w * 0.4) - 1, int(h * 0.4) - 1), np.uint16)
 taps21 = synth.gaussian_taps(21, 3.5)
 t21p = taps21.ctypes.data_as(C.POINTER(C.c_float))
 wide = DeviceFrame(full, np.uint16)
+# the channel-pair sweep with 16 slots (1.5x enlargement) and its 12-tap form (0.75x); a deep stack on the chain kernel
+big = DeviceFrame((0, 0, int(w * 1.5) - 1, int(h * 1.5) - 1), np.uint16)
+mid = DeviceFrame((0, 0, int(w * 0.75) - 1, int(h * 0.75) - 1), np.uint16)
+deep = DeviceFrame(full, np.uint16)
 
 
 def once():
@@ -46,12 +50,16 @@ def once():
     _lib.check(lib.cvs_blur_lanczos_f16_dev(small.ref(), sets[0][1][1].ref(), f32p, 9, C.c_float(0.5), C.c_float(0.5), 3, stream))
     _lib.check(lib.cvs_blur_lanczos_f16_dev(odd.ref(), sets[1][1][1].ref(), onep, 1, C.c_float(0.4), C.c_float(0.4), 3, stream))
     _lib.check(lib.cvs_fir_blur_f16_dev(wide.ref(), sets[2][1][1].ref(), t21p, 21, stream))
+    _lib.check(lib.cvs_resample_lanczos_f16_dev(big.ref(), sets[3][1][1].ref(), C.c_float(1.5), C.c_float(1.5), 3, stream))
+    _lib.check(lib.cvs_resample_lanczos_f16_dev(mid.ref(), sets[0][1][0].ref(), C.c_float(0.75), C.c_float(0.75), 3, stream))
+    chain_color_over([(deep, [sets[i % 4][1][i % 2] for i in range(6)])], None, _lib.LUT_NONE, _lib.LUT_NONE, stream)
 
 
 def snapshot():
     _lib.check(lib.cvs_stream_sync(stream))
     return [s[0].download().array.copy() for s in sets] + [graph.slots[0]["out"].download().array.copy(), graph.slots[1]["out"].download().array.copy(),
-                                                        small.download().array.copy(), odd.download().array.copy(), wide.download().array.copy()]
+                                                        small.download().array.copy(), odd.download().array.copy(), wide.download().array.copy(),
+                                                        big.download().array.copy(), mid.download().array.copy(), deep.download().array.copy()]
 
 
 once()
@@ -68,5 +76,5 @@ while time.perf_counter() - t0 < seconds:
             print("MISMATCH after %d iterations: %d values differ" % (n, bad))
             sys.exit(1)
     checks += 1
-print("soak ok: %d iterations (%d launches of the chain over 8 frames, %d config-5 frames, %d config-3 frames, as many 0.4x resamples and 21-tap blurs), %d full compares, %.1f s"
+print("soak ok: %d iterations (%d launches of the chain over 8 frames, %d config-5 frames, %d config-3 frames, as many 0.4x / 0.75x / 1.5x resamples, 21-tap blurs and 6-layer stacks), %d full compares, %.1f s"
       % (n, n, 2 * n, n, checks, time.perf_counter() - t0))
