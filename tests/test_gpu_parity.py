@@ -1192,6 +1192,25 @@ def test_blur_over_node_by_node(cvs, orc, case):
     assert_same_f16(got.window_view(), want.window_view(), "blur+over %s" % case)
 
 
+@pytest.mark.parametrize("kernel", ["lanes", "stream", "tiled"])
+@pytest.mark.parametrize("ntaps", [9, 10])
+def test_blur_over_node_by_node_through_the_table_kernels(cvs, orc, force_fir, kernel, ntaps):
+    """The node-by-node form blurs an f16 source into an f32 frame; with the register-window kernels out of the way that is
+    the table kernels' f16-in / f32-out form, which no other entry reaches."""
+    from tests.util import oracle_blur_over
+    full = (0, 0, 59, 33)
+    rng = np.random.default_rng(810 + ntaps)
+    src = rand_f16_frame(rng, full, full)
+    # windows: see test_chain_ragged_windows for why the upper layers sit where they do
+    overlays = [rand_f16_frame(rng, full, w) for w in [(5, 3, 40, 25), (20, 2, 59, 20)]]
+    taps = synth.gaussian_taps(ntaps | 1, 1.5)[:ntaps].copy()
+    want = oracle_blur_over(orc, src, taps, overlays)
+    force_fir(kernel)
+    got = _blur_over(cvs, full, src, taps, overlays)
+    assert same_window(got.current_window, want.current_window)
+    assert_same_f16(got.window_view(), want.window_view(), "blur+over node by node (%s)" % kernel)
+
+
 # ------------------------------------------------------------------ display / export edge (survey N2)
 
 def _all_codes_frame(full, cur):
