@@ -862,21 +862,35 @@ def test_even_and_short_blurs_both_kernels(cvs, orc, force_fir, kernel, ntaps):
     assert_same_f32(got.window_view(), want.window_view(), "blur %d taps (%s)" % (ntaps, kernel))
 
 
-def test_full_size_resample_agrees_between_the_two_kernels(cvs, force_fir):
-    """3840x2160 -> 1536x864 Lanczos3 (f16 in and out): the footprint rule sends this to the sweep kernel; the tiled kernel,
-    forced, must produce the same frame bit for bit (each is checked against the oracle at small sizes)."""
-    w, h, f = 3840, 2160, 0.4
+@pytest.mark.parametrize("f", [0.4, 0.75, 1.5, 1.0 / 3.0])
+@pytest.mark.parametrize("fmt", ["f16", "f32"])
+def test_full_size_resample_agrees_between_the_kernels(cvs, force_fir, f, fmt):
+    """3840x2160 Lanczos3 at factors that take different instances of the channel-pair sweep (16 / 12 taps with 8 slots, 12
+    taps with 16 slots, 24 taps), f16 and f32 frames: the tiled kernel and the lane-per-pixel sweep -- independent code --
+    must produce the same frame bit for bit (each is checked against the oracle at small sizes, and bench.py proves the f16
+    frames at 0.4x / 0.75x / 1.5x against SHA-256 fixtures of the oracle).  This is also the full-size check of the
+    hand-written load pipeline of sweep_ops.hip."""
+    w, h = 3840, 2160
     tw, th = int(w * f), int(h * f)
-    one = np.array([1.0], np.float32)
-    d_src = DeviceFrame.from_host(synth.layer_frame(w, h, 1, 0))
+    src16 = synth.layer_frame(w, h, 1, 0)
+    if fmt == "f16":
+        d_src, dtype = DeviceFrame.from_host(src16), np.uint16
+    else:
+        from tests.models import h2f_ieee
+        d_src, dtype = DeviceFrame.from_host(HostFrame(src16.full_window, np.float32, h2f_ieee(src16.array).astype(np.float32))), np.float32
     outs = []
-    for kernel in (None, "tiled", "stream", "lanes"):
+    for kernel in (None, "tiled", "lanes"):
         force_fir(kernel)
-        d_out = DeviceFrame((0, 0, tw - 1, th - 1), np.uint16)
-        _lib.check(cvs.cvs_blur_lanczos_f16_dev(d_out.ref(), d_src.ref(), f32p(one), 1, C.c_float(f), C.c_float(f), 3, None))
+        d_out = DeviceFrame((0, 0, tw - 1, th - 1), dtype)
+        if fmt == "f16":
+            _lib.check(cvs.cvs_resample_lanczos_f16_dev(d_out.ref(), d_src.ref(), C.c_float(f), C.c_float(f), 3, None))
+        else:
+            _lib.check(cvs.cvs_resample_lanczos_f32_dev(d_out.ref(), d_src.ref(), C.c_float(f), C.c_float(f), 3, None))
         got = d_out.download()
         assert got.current_window.tuple() == (0, 0, tw - 1, th - 1)
-        outs.append(got.array)
+        outs.append(got.array.copy())
+        d_out.free()
+    d_src.free()
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
     assert len(np.unique(outs[0])) > 1000
 
