@@ -80,7 +80,7 @@ __device__ __forceinline__ void asm_ld(SrcPx<false> &dst, const void *row, uint3
 // (8 slots, lists up to 16: the instances that gather a row ahead and hold two rows of taps, see `filter`)
 constexpr bool taps_row_ahead(int maxt, int nacc) { return nacc == 8 && maxt <= 16; }
 constexpr bool hand_pipelined(int maxt, int nacc, int nq, bool inh) {
-    return (taps_row_ahead(maxt, nacc) ? 4 : 2) * maxt + 2 * nacc + 2 * kPFD * nq * (inh ? 2 : 4) + 60 <= 200;
+    return nacc <= 16 && (taps_row_ahead(maxt, nacc) ? 4 : 2) * maxt + 2 * nacc + 2 * kPFD * nq * (inh ? 2 : 4) + 60 <= 200;
 }
 
 template <int MAXT, int NACC, int NQ, bool INH, bool HAND>
@@ -164,15 +164,16 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
         optr += trow;
     };
 
-    // The accumulators: slot j is elements 2j, 2j + 1 of ONE register vector (the widest register tuple is 32 wide: 16 slots
-    // at most).  The row step addresses the slots with constants; the line that ends on a row is in
+    // The accumulators: slot j is elements 2j, 2j + 1 of a register vector (the widest register tuple is 32 wide: 16 slots;
+    // a 32-slot instance has two).  The row step addresses the slots with constants; the line that ends on a row is in
     // a slot only known at run time -- wave-uniform, so hipcc reads and clears it through the GPR index register
     // (s_set_gpr_idx_on + v_mov), with no branch.  (A taken branch costs this kernel an instruction fetch, ~64 cycles with
     // two or three waves per SIMD: the first form chose the slot with a switch and spent a third of a 1.5x enlargement
     // in it, profiles/r02/general_fir_attempts.txt.)
-    static_assert(NACC == 8 || NACC == 16, "one register vector of 2 * NACC floats");
-    typedef float accvec __attribute__((ext_vector_type(2 * NACC)));
-    accvec acc = 0.0f;
+    static_assert(NACC == 8 || NACC == 16 || NACC == 32, "register vectors of 32 floats at most: one, or two of 16 slots");
+    constexpr int VS = NACC < 16 ? NACC : 16;          // slots per register vector
+    typedef float accvec __attribute__((ext_vector_type(2 * VS)));
+    accvec acc = 0.0f, acc_hi = 0.0f;                   // acc_hi: slots 16..31 of a 32-slot instance (enlargements 1.6x .. 2.2x)
 
     // staging: a lane fetches the pixels lane + q * kLanes of the strip's footprint (clamped to its last pixel: every load
     // is unconditional; what lands beyond the footprint in LDS is never read).  The row pointer is wave-uniform and moves
@@ -249,7 +250,11 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
     // AHEAD: row s: horizontal sum of its taps `xc` (gathered a step ago) -> row s + 1 (`px`) into the LDS buffer `buf`, its
     // taps requested into `xn` -> every accumulator slot takes row s.
     // otherwise: row s (`px`) into `buf`, gathered into `xc`, summed, every slot takes it (`xn` unused).
-    auto filter = [&](Taps &xc, Taps &xn, float *buf, const SrcPx<INH> (&px)[NQ], const Rec &rec, Rec &rec_after) __attribute__((always_inline)) {
+    // (32 slots: two records of 64 weight registers do not fit the scalar file; the row's own record is loaded at the top of its
+    // step instead of a row ahead)
+    constexpr bool REC_AHEAD = NACC < 32;
+    auto filter = [&](Taps &xc, Taps &xn, float *buf, const SrcPx<INH> (&px)[NQ], Rec &rec, Rec &rec_after) __attribute__((always_inline)) {
+        if constexpr (!REC_AHEAD) rec = load_rec();
         if constexpr (!AHEAD) {
             if (!(skip & 8)) stage_row(buf, px);
             __builtin_amdgcn_wave_barrier();                       // (compiler fence; the hardware keeps a wave's LDS accesses in order)
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
         // the next row's record goes out here: behind the last LDS read (an outstanding scalar load makes every LDS wait a
         // wait for everything), a whole accumulator pass and the next row's staging before anyone needs it
         __builtin_amdgcn_sched_barrier(0);
-        rec_after = load_rec();
+        if constexpr (REC_AHEAD) rec_after = load_rec();
         __builtin_amdgcn_sched_barrier(0);
         // Every slot takes the row; the slots it does not belong to have weight 0: 0 * h is a zero that leaves the sum as it
         // is -- unless h is Inf or NaN.  Lanes with such an h (rare) put 0 through the packed pass instead (adds an exact zero
@@ -280,19 +285,31 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
         // win: a slot that takes the row gets acc + h * w with one rounding, as the gather would give it; the others acc + 0.
         const bool odd = __builtin_amdgcn_class(h.x, 0x207) || __builtin_amdgcn_class(h.y, 0x207);       // NaN, -Inf, +Inf
         const f32x2 h_plain = odd ? f32x2{ 0.0f, 0.0f } : h;
-        auto add_to = [&](int j, f32x2 p) __attribute__((always_inline)) {
+        auto add_lo = [&](int j, f32x2 p) __attribute__((always_inline)) {
             const f32x2 t = f32x2{ acc[2 * j], acc[2 * j + 1] } + p;
             acc[2 * j] = t.x; acc[2 * j + 1] = t.y;
         };
-        if (skip & 2) add_to(0, h);
+        auto add_hi = [&](int j, f32x2 p) __attribute__((always_inline)) {
+            const f32x2 t = f32x2{ acc_hi[2 * j], acc_hi[2 * j + 1] } + p;
+            acc_hi[2 * j] = t.x; acc_hi[2 * j + 1] = t.y;
+        };
+        if (skip & 2) add_lo(0, h);
         else {
 #pragma unroll
-            for (int j = 0; j < NACC; j++) add_to(j, h_plain * rec.w[j]);
+            for (int j = 0; j < VS; j++) add_lo(j, h_plain * rec.w[j]);
+            if constexpr (NACC > 16) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) add_hi(j, h_plain * rec.w[16 + j]);
+            }
             if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0, 0)) {
                 cvs::rare_path();
                 const f32x2 h_odd = odd ? h : f32x2{ 0.0f, 0.0f };
 #pragma unroll
-                for (int j = 0; j < NACC; j++) add_to(j, f32x2{ mul_zero_wins(h_odd.x, rec.w[j].x), mul_zero_wins(h_odd.y, rec.w[j].x) });
+                for (int j = 0; j < VS; j++) add_lo(j, f32x2{ mul_zero_wins(h_odd.x, rec.w[j].x), mul_zero_wins(h_odd.y, rec.w[j].x) });
+                if constexpr (NACC > 16) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) add_hi(j, f32x2{ mul_zero_wins(h_odd.x, rec.w[16 + j].x), mul_zero_wins(h_odd.y, rec.w[16 + j].x) });
+                }
             }
         }
     };
@@ -304,16 +321,24 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
             int n_end = __builtin_popcount(rec.ends);
             int i = rec.first_end;
             do {
-                const int e = 2 * (i & (NACC - 1));
-                const f32x2 v = { acc[e], acc[e + 1] };
-                acc[e] = 0.0f; acc[e + 1] = 0.0f;
+                const int slot = i & (NACC - 1), e = 2 * (slot & 15);
+                f32x2 v = { acc[e], acc[e + 1] };
+                if constexpr (NACC <= 16) { acc[e] = 0.0f; acc[e + 1] = 0.0f; }
+                else {                                             // both vectors read and rewritten, selects instead of a branch
+                    const bool low = slot < 16;
+                    const f32x2 vh = { acc_hi[e], acc_hi[e + 1] };
+                    acc[e] = low ? 0.0f : v.x; acc[e + 1] = low ? 0.0f : v.y;
+                    acc_hi[e] = low ? vh.x : 0.0f; acc_hi[e + 1] = low ? vh.y : 0.0f;
+                    v = low ? v : vh;
+                }
                 if (i >= ia && i <= ib) store_next(v);
                 i++;
             } while (--n_end);
         }
     };
     static_assert(kPFD == 4, "four steps written out: row buffer and record alternate");
-    Rec ra = load_rec(), rb;
+    Rec ra, rb;
+    if constexpr (REC_AHEAD) ra = load_rec();
     int s = s_lo;
     Group ga, gb;
     Taps xa, xb;
@@ -407,6 +432,7 @@ const Instance kInstances[] = {
     CVK_LANES_INSTANCE(16, 8, 2),  CVK_LANES_INSTANCE(16, 16, 1),                                    // 0.4 <= factor <= 0.5
     CVK_LANES_INSTANCE(24, 8, 4),                                                                    // down to 0.26
     CVK_LANES_INSTANCE(32, 8, 4),  CVK_LANES_INSTANCE(32, 16, 4),                                    // down to 0.19, and whatever else fits
+    CVK_LANES_INSTANCE(16, 32, 1),                                                                   // enlarging 1.6x .. 2.2x
 };
 
 const Instance *pick(const cvk_fir2d_params *fp) {
@@ -419,7 +445,7 @@ const Instance *pick(const cvk_fir2d_params *fp) {
 }  // namespace
 
 extern "C" int cvk_fir_lanes_supported(const cvk_fir2d_params *fp) {
-    return fp->v.rec != NULL && !fp->v.rec_zero_weight && (fp->v.nacc == 8 || fp->v.nacc == 16) &&      /* 32 slots: the older kernels */
+    return fp->v.rec != NULL && !fp->v.rec_zero_weight && (fp->v.nacc == 8 || fp->v.nacc == 16 || fp->v.nacc == 32) &&
            fp->v.max_active >= 1 && fp->v.max_active <= fp->v.nacc && fp->h.max_taps >= 1 && fp->max_sw >= 1 && fp->max_sw <= kRowPx && pick(fp) != NULL;
 }
 

@@ -795,6 +795,8 @@ def force_fir(request):
     ((400, 300), (7, 5, 380, 290), (160, 120), 0.4, 0.4),    # source window inside its buffer: border lines have short tap lists
     ((300, 200), None, (100, 150), 1.0 / 3.0, 0.75),         # a factor that is not a power of two: every line its own taps
     ((96, 54), None, (240, 81), 2.5, 1.5),                   # enlarging: one source row feeds up to 15 target rows
+    ((96, 54), None, (192, 108), 2.0, 2.0),                  # ... up to 26: the sweep's 32-slot instance
+    ((64, 40), (2, 1, 60, 37), (100, 84), 1.5625, 2.1),      # the same with clipped lists at the window's edges
     ((130, 70), None, (40, 200), 0.3, 3.0),                  # more target rows than the source covers: lines without taps
 ])
 def test_lanczos_resample_both_kernels(cvs, orc, force_fir, kernel, ssize, scur, tsize, fx, fy):
@@ -821,7 +823,8 @@ def test_lanczos_resample_both_kernels(cvs, orc, force_fir, kernel, ssize, scur,
 
 
 @pytest.mark.parametrize("kernel", ["lanes", "stream", "tiled"])
-@pytest.mark.parametrize("ssize,tsize,fx,fy", [((400, 300), (160, 120), 0.4, 0.4), ((96, 54), (144, 81), 1.5, 1.5), ((300, 200), (225, 150), 0.75, 0.75)])
+@pytest.mark.parametrize("ssize,tsize,fx,fy", [((400, 300), (160, 120), 0.4, 0.4), ((96, 54), (144, 81), 1.5, 1.5), ((300, 200), (225, 150), 0.75, 0.75),
+                                               ((96, 54), (192, 108), 2.0, 2.0)])
 def test_lanczos_resample_with_inf_and_nan_pixels(cvs, orc, force_fir, kernel, ssize, tsize, fx, fy):
     """Inf and NaN in the source spread exactly as far as the taps that touch them: a tap the gather skips (a padded list
     entry, an accumulator slot that does not take the row) must not turn them into NaNs elsewhere (0 * Inf)."""
@@ -862,11 +865,11 @@ def test_even_and_short_blurs_both_kernels(cvs, orc, force_fir, kernel, ntaps):
     assert_same_f32(got.window_view(), want.window_view(), "blur %d taps (%s)" % (ntaps, kernel))
 
 
-@pytest.mark.parametrize("f", [0.4, 0.75, 1.5, 1.0 / 3.0])
-@pytest.mark.parametrize("fmt", ["f16", "f32"])
+@pytest.mark.parametrize("f,fmt", [(0.4, "f16"), (0.4, "f32"), (0.75, "f16"), (0.75, "f32"), (1.5, "f16"), (1.5, "f32"),
+                                   (1.0 / 3.0, "f16"), (1.0 / 3.0, "f32"), (2.0, "f16")])
 def test_full_size_resample_agrees_between_the_kernels(cvs, force_fir, f, fmt):
     """3840x2160 Lanczos3 at factors that take different instances of the channel-pair sweep (16 / 12 taps with 8 slots, 12
-    taps with 16 slots, 24 taps), f16 and f32 frames: the tiled kernel and the lane-per-pixel sweep -- independent code --
+    taps with 16 slots, 24 taps, 16 taps with 32 slots), f16 and f32 frames: the tiled kernel and the lane-per-pixel sweep -- independent code --
     must produce the same frame bit for bit (each is checked against the oracle at small sizes, and bench.py proves the f16
     frames at 0.4x / 0.75x / 1.5x against SHA-256 fixtures of the oracle).  This is also the full-size check of the
     hand-written load pipeline of sweep_ops.hip."""
