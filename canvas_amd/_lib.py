@@ -161,6 +161,7 @@ SIGNATURES = {
     # (3) fused chain
     "cvs_chain_color_over_f16_dev": (C.c_int, [P(chain_job), C.c_int, _f32p, C.c_int, C.c_int, _vp]),
     "cvs_chain_last_was_fused": (C.c_int, []),
+    "cvs_scale_last_was_fused": (C.c_int, []),
     "cvs_chain_last_launch_count": (C.c_int, []),
     "cvs_mix_cross_f16_dev": (C.c_int, [_F16, _F16, _F16, C.c_float, _vp]),
 }

@@ -22,6 +22,8 @@
 #include <stdatomic.h>
 
 static _Atomic int g_fir_path = CVS_FIR_PATH_AUTO;
+static _Thread_local int t_scale_fused;         /* the calling thread's last scaler call ran both passes in one launch */
+CVS_EXPORT int cvs_scale_last_was_fused(void) { return t_scale_fused; }
 CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_LANES)); }
 
 typedef struct {
@@ -119,7 +121,7 @@ static int plan_triangle(tap_table *tb, float tmin, float smin, float factor, in
 
 /* device-resident, cached form of plan_triangle's table (defined with the table cache below) */
 static int triangle_table_cached(float tmin, float smin, float factor, int s0, int s1, int t0, int t1, bool count_touch,
-                                 cvk_fir_axis *axis, int *used_lo, int *used_hi, int *pin);
+                                 cvk_fir_axis *axis, int *used_lo, int *used_hi, int *pin, int *max_foot);
 static void axis_done(int pin, hipStream_t s);
 
 /* one pass of video_scale.c:34-127 (axis 0) or :129-229 (axis 1) on device frames */
@@ -141,7 +143,7 @@ static int triangle_pass(any_frame *target, float tmin, const any_frame *source,
      * nothing synchronous */
     cvk_fir_axis table;
     int used_lo, used_hi, pin = -1;
-    int rc = triangle_table_cached(tmin, smin, factor, s0, s1, t0, t1, axis == 0 || lo <= hi, &table, &used_lo, &used_hi, &pin);
+    int rc = triangle_table_cached(tmin, smin, factor, s0, s1, t0, t1, axis == 0 || lo <= hi, &table, &used_lo, &used_hi, &pin, NULL);
     if (rc != 0) return rc;
     /* video_scale.c:25-32,44: the target starts as zeros (all-zero bytes are 0.0 in either format).  The gather writes every
      * pixel of lines used_lo..used_hi x lo..hi (a line without taps gets its zeros there): when that is the whole buffer --
@@ -173,10 +175,51 @@ static int triangle_pass(any_frame *target, float tmin, const any_frame *source,
     return 0;
 }
 
+/* Both passes of video_scale_bilinear_f32 in one launch when the vertical pass comes first (equal factors, or the vertical
+ * one smaller: video_scale.c:252) -- sweep_vh_ops.hip.  Same tables, same windows as the two triangle_pass calls below
+ * would use: the frame between the passes (`mid_full`, video_scale.c:254-272) never exists, only its geometry does.
+ * 0 = done, 1 = not for this kernel (the caller runs the two passes), < 0 = error. */
+static int triangle_fused_vh(any_frame *target, v2f tp, const any_frame *source, v2f sp, v2f fac, const box2i *mid_full, hipStream_t s) {
+    const box2i *tf = &target->full, *sc = &source->cur;
+    /* pass 1 (vertical) into the frame between the passes */
+    const int lo1 = sc->min.x > mid_full->min.x ? sc->min.x : mid_full->min.x, hi1 = sc->max.x < mid_full->max.x ? sc->max.x : mid_full->max.x;
+    cvk_fir_axis tv, th;
+    int vlo, vhi, hlo, hhi, pv = -1, ph = -1, hfoot = 0;
+    if (hi1 < lo1) return 1;
+    if (triangle_table_cached(tp.y, sp.y, fac.y, sc->min.y, sc->max.y, mid_full->min.y, mid_full->max.y, true, &tv, &vlo, &vhi, &pv, NULL) != 0) return -1;
+    int rc = 1;
+    if (vhi >= vlo) {
+        /* pass 2 (horizontal) from that frame's window (lo1..hi1 x vlo..vhi) into the target */
+        const int lo2 = vlo > tf->min.y ? vlo : tf->min.y, hi2 = vhi < tf->max.y ? vhi : tf->max.y;
+        if (hi2 >= lo2 && triangle_table_cached(tp.x, sp.x, fac.x, lo1, hi1, tf->min.x, tf->max.x, true, &th, &hlo, &hhi, &ph, &hfoot) == 0) {
+            cvk_fir2d_params fp;
+            memset(&fp, 0, sizeof fp);
+            fp.target = cvs_view(target->data, tf);
+            fp.source = cvs_view(source->data, &source->full);
+            fp.in_half = source->half; fp.out_half = target->half;
+            fp.tx0 = tf->min.x; fp.tx1 = tf->max.x;                  /* every column: those without taps are zeros, as the fill leaves them */
+            fp.ty0 = mid_full->min.y; fp.ty1 = hi2;                   /* the vertical table's lines; lo2 .. hi2 of them are produced */
+            fp.h = th; fp.v = tv;
+            fp.max_sw = hfoot > 0 ? hfoot : 1;
+            if (hhi >= hlo && cvk_fir_vh_supported(&fp)) {
+                /* video_scale.c:25-32,44: rows the pass leaves alone are zeros */
+                const bool covers = lo2 == tf->min.y && hi2 == tf->max.y;
+                hipError_t e = covers || !any_bytes(target) ? hipSuccess : hipMemsetAsync(target->data, 0, any_bytes(target), s);
+                int krc = e == hipSuccess ? cvk_fir_vh(&fp, lo2 - fp.ty0, cvs_cus(), s) : (int)e;
+                if (krc == 0) { box2i_set(&target->cur, hlo, lo2, hhi, hi2); rc = 0; }
+                else { (void)hipGetLastError(); rc = 1; }               /* did not launch: the two passes decide */
+            }
+        }
+    }
+    axis_done(pv, s); axis_done(ph, s);
+    return rc;
+}
+
 /* video_scale_bilinear_f32 (video_scale.c:231-286) between frames of either format: f16 sources are widened as they
  * are read, f16 targets truncated as they are written (what the pulls around an f32 scaler node do, main.c:43-71,
  * 105-144); the frame between the two passes is always f32.  The caller has dealt with the all-identity case. */
 static int scale_core(any_frame *target, v2f tp, const any_frame *source, v2f sp, v2f fac, hipStream_t s) {
+    t_scale_fused = 0;
     if (fac.x == 1.0f && tp.x == sp.x) return triangle_pass(target, tp.y, source, sp.y, fac.y, 0, s);
     if (fac.y == 1.0f && tp.y == sp.y) return triangle_pass(target, tp.x, source, sp.x, fac.x, 1, s);
 
@@ -192,6 +235,11 @@ static int scale_core(any_frame *target, v2f tp, const any_frame *source, v2f sp
                   sc->max.x, (int)(sp.y + (tf->max.y - tp.y) * fac.y));
     box2i_intersect(&mid.full, &mid.full, tf);
     mid.cur = mid.full;
+    if (!x_first && !(atomic_load(&g_fir_path) & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED))) {
+        int rc = triangle_fused_vh(target, tp, source, sp, fac, &mid.full, s);
+        if (rc == 0) t_scale_fused = 1;
+        if (rc <= 0) return rc;                              /* done, or failed; 1: not for the fused kernel */
+    }
     size_t n = cvs_box_pixels(&mid.full);
     mid.data = cvs_pool_malloc(sizeof(rgba_f32) * (n ? n : 1), s);
     if (!mid.data) return -1;
@@ -601,13 +649,15 @@ static int axis_get(const axis_key *key, const float *taps, float factor, cvk_fi
 }
 
 static int triangle_table_cached(float tmin, float smin, float factor, int s0, int s1, int t0, int t1, bool count_touch,
-                                 cvk_fir_axis *axis, int *used_lo, int *used_hi, int *pin) {
+                                 cvk_fir_axis *axis, int *used_lo, int *used_hi, int *pin, int *max_foot) {
     uint32_t fb, tb, sb;
     memcpy(&fb, &factor, 4); memcpy(&tb, &tmin, 4); memcpy(&sb, &smin, 4);
     const axis_key key = make_key(3, fb, count_touch ? 1 : 0, ((uint64_t)tb << 32) | sb, t0, t1, s0, s1, CVK_FIR2D_TILE_X);
     const axis_plan pl = { NULL, factor, tmin, smin };
     int foot;
-    return axis_get_ex(&key, &pl, axis, &foot, used_lo, used_hi, pin);
+    int rc = axis_get_ex(&key, &pl, axis, &foot, used_lo, used_hi, pin);
+    if (max_foot) *max_foot = foot;
+    return rc;
 }
 
 /* The same two cached tables as two launches through an f32 frame in HBM (k_fir: one lane per target pixel, taps gathered

@@ -143,6 +143,10 @@ int cvk_fir_stream(const cvk_fir2d_params *fp, int h_taps, int v_active, int cus
 /* the same tables again, one lane per target column and channel pair (sweep_ops.hip): needs h tap lists <= 32, v.rec */
 int cvk_fir_lanes_supported(const cvk_fir2d_params *fp);
 int cvk_fir_lanes(const cvk_fir2d_params *fp, int cus, void *stream);
+/* the same tables with the VERTICAL pass first (sweep_vh_ops.hip): what video_scale_bilinear_f32 does when the factors are
+ * equal or the vertical one is smaller.  fp->ty0 = first line of the vertical table; lines ty0 + line0 .. ty1 are produced */
+int cvk_fir_vh_supported(const cvk_fir2d_params *fp);
+int cvk_fir_vh(const cvk_fir2d_params *fp, int line0, int cus, void *stream);
 size_t cvk_fir2d_lds_bytes(const cvk_fir2d_params *fp);     /* dynamic LDS the launch would need */
 int cvk_fir2d(const cvk_fir2d_params *fp, void *stream);
 

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include "kernels.h"
 #include "chain_math.hpp"
+#include "sweep_common.hpp"
 
 namespace {
 
@@ -37,21 +38,6 @@ constexpr int kPFD = 4;         // source rows in flight
 constexpr int kRowPx = 256;     // source pixels under a strip at most; the LDS row is this long whatever the factor, so that
                                 // the second row buffer and the zero pixel sit at compile-time offsets
 constexpr int kRowFl = (kRowPx + 1) * 4;
-
-// tables the kernel only reads, at wave-uniform addresses: through the constant address space, so that hipcc may use scalar
-// loads (a plain global pointer next to the kernel's own stores gets vector loads: nothing tells it the two never alias)
-typedef const __attribute__((address_space(4))) uint32_t *konst;
-__device__ __forceinline__ konst as_konst(const void *p) { return (konst)(uintptr_t)p; }
-
-// x * w with "0 * anything = 0" (measured on gfx950, tools/legacy_mul_test.hip: bit-equal to v_mul_f32 whenever neither
-// operand is zero, +0 when either is).  The accumulator slots that do not take a source row get weight 0 from the host:
-// acc + 0 is acc whatever the row holds, Inf and NaN included, so the slots need no branch.  A sum never is -0 (it starts
-// at +0 and x + (-x) = +0), so the +0 this gives where v_mul_f32 gives -0 adds up to the same bits.
-__device__ __forceinline__ float mul_zero_wins(float x, float w) {
-    float r;
-    asm("v_mul_legacy_f32 %0, %1, %2" : "=v"(r) : "s"(w), "v"(x));
-    return r;
-}
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

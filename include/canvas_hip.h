@@ -388,6 +388,9 @@ CVS_EXPORT int cvs_chain_color_over_f16_dev(const cvs_chain_job *jobs, int njobs
 /* how the last chain call ran: 1 = single fused kernel, 0 = node-by-node device kernels
  * (windows did not all cover the output's full window) */
 CVS_EXPORT int cvs_chain_last_was_fused(void);
+/* 1 when the calling thread's last scaler call (cvs_scale_bilinear_*_dev, video_scale_bilinear_f32) ran both passes in one
+ * launch (vertical pass first, factors >= ~0.55: sweep_vh_ops.hip); tests and tools */
+CVS_EXPORT int cvs_scale_last_was_fused(void);
 /* kernel launches the calling thread's last fused chain call was cut into (about eight 4K frames' worth of bytes each) */
 CVS_EXPORT int cvs_chain_last_launch_count(void);
 /* crossfade of two f16 frames, f16 result: widen, video_mix_cross_f32 (video_mix.c:107-235), truncate -- one launch when

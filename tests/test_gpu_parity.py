@@ -1792,6 +1792,41 @@ def test_scale_bilinear_random_geometry(cvs, orc):
             assert_same_f32(got.window_view(), want.window_view(), "scale, random case %d %r" % (case, fac))
 
 
+@pytest.mark.parametrize("fac,fmt", [((1.5, 1.5), "f32"), ((2.0, 2.0), "f16"), ((0.75, 0.75), "f16"), ((1.25, 1.125), "f32"), ((0.8, 0.6), "f32")])
+def test_scaler_in_one_launch_agrees_with_the_two_passes(cvs, force_fir, fac, fmt):
+    """1920x1080 through the triangle scaler: the automatic choice runs both passes in one launch when the vertical pass
+    comes first (sweep_vh_ops.hip); pinned to the older kernels it runs the reference's two passes through an f32 frame.
+    Same tables, same order of roundings: the frames must be equal bit for bit (each form is checked against the oracle at
+    small sizes by the tests above)."""
+    w, h = 1920, 1080
+    tw, th = int(w * fac[0]), int(h * fac[1])
+    src16 = synth.layer_frame(w, h, 1, 0)
+    src16.array[5, 7, 1] = 0x7C00                                    # an Inf and a NaN: they must spread the same way
+    src16.array[400, 900, 2] = 0x7E00
+    outs, fused = [], []
+    for kernel in (None, "stream"):
+        force_fir(kernel)
+        if fmt == "f16":
+            d_src, d_out = DeviceFrame.from_host(src16), DeviceFrame((0, 0, tw - 1, th - 1), np.uint16)
+            _lib.check(cvs.cvs_scale_bilinear_f16_dev(d_out.ref(), v2f(0, 0), d_src.ref(), v2f(0, 0), v2f(*fac), None))
+        else:
+            from tests.models import h2f_ieee
+            d_src = DeviceFrame.from_host(HostFrame(src16.full_window, np.float32, h2f_ieee(src16.array).astype(np.float32)))
+            d_out = DeviceFrame((0, 0, tw - 1, th - 1), np.float32)
+            _lib.check(cvs.cvs_scale_bilinear_f32_dev(d_out.ref(), v2f(0, 0), d_src.ref(), v2f(0, 0), v2f(*fac), None))
+        fused.append(cvs.cvs_scale_last_was_fused())
+        got = d_out.download()
+        outs.append((got.current_window.tuple(), got.array.copy()))
+        d_src.free(); d_out.free()
+    assert fused == [1 if fac[1] <= fac[0] else 0, 0]
+    assert outs[0][0] == outs[1][0]
+    a, b = outs[0][1], outs[1][1]
+    if fmt == "f16":
+        assert_same_f16(a, b, "scaler, one launch against two")
+    else:
+        assert_same_f32(a, b, "scaler, one launch against two")
+
+
 def test_fir_blur_random_geometry(cvs, orc):
     """150 random blurs: tap counts 1..34 (odd ones from 3 to 31 take the register-window kernel, the rest the tiled
     gather kernel), source windows inside their buffers, targets with other origins, f32 and f16 entry points."""
