@@ -215,6 +215,43 @@ static int triangle_fused_vh(any_frame *target, v2f tp, const any_frame *source,
     return rc;
 }
 
+/* The other order (horizontal factor strictly smaller: the horizontal pass first) is the order of sweep_ops.hip's kernel.
+ * 0 = done, 1 = not for this kernel, < 0 = error. */
+static int triangle_fused_hv(any_frame *target, v2f tp, const any_frame *source, v2f sp, v2f fac, const box2i *mid_full, hipStream_t s) {
+    const box2i *tf = &target->full, *sc = &source->cur;
+    /* pass 1 (horizontal) into the frame between the passes: rows lo1..hi1 */
+    const int lo1 = sc->min.y > mid_full->min.y ? sc->min.y : mid_full->min.y, hi1 = sc->max.y < mid_full->max.y ? sc->max.y : mid_full->max.y;
+    cvk_fir_axis tv, th;
+    int vlo, vhi, hlo, hhi, pv = -1, ph = -1, hfoot = 0;
+    if (hi1 < lo1) return 1;
+    if (triangle_table_cached(tp.x, sp.x, fac.x, sc->min.x, sc->max.x, mid_full->min.x, mid_full->max.x, true, &th, &hlo, &hhi, &ph, &hfoot) != 0) return -1;
+    int rc = 1;
+    if (hhi >= hlo) {
+        /* pass 2 (vertical) from that frame's window (hlo..hhi x lo1..hi1) into the target: columns lo2..hi2 */
+        const int lo2 = hlo > tf->min.x ? hlo : tf->min.x, hi2 = hhi < tf->max.x ? hhi : tf->max.x;
+        if (hi2 >= lo2 && triangle_table_cached(tp.y, sp.y, fac.y, lo1, hi1, tf->min.y, tf->max.y, true, &tv, &vlo, &vhi, &pv, NULL) == 0) {
+            cvk_fir2d_params fp;
+            memset(&fp, 0, sizeof fp);
+            fp.target = cvs_view(target->data, tf);
+            fp.source = cvs_view(source->data, &source->full);
+            fp.in_half = source->half; fp.out_half = target->half;
+            fp.tx0 = mid_full->min.x; fp.tx1 = hi2;                   /* from the horizontal table's first column; those without taps are zeros */
+            fp.ty0 = tf->min.y; fp.ty1 = tf->max.y;                   /* every line: those without taps are written as zeros */
+            fp.h = th; fp.v = tv;
+            fp.max_sw = hfoot > 0 ? hfoot : 1;
+            if (vhi >= vlo && cvk_fir_lanes_supported(&fp)) {
+                const bool covers = fp.tx0 == tf->min.x && hi2 == tf->max.x;
+                hipError_t e = covers || !any_bytes(target) ? hipSuccess : hipMemsetAsync(target->data, 0, any_bytes(target), s);
+                int krc = e == hipSuccess ? cvk_fir_lanes(&fp, cvs_cus(), s) : (int)e;
+                if (krc == 0) { box2i_set(&target->cur, lo2, vlo, hi2, vhi); rc = 0; }
+                else { (void)hipGetLastError(); rc = 1; }
+            }
+        }
+    }
+    axis_done(pv, s); axis_done(ph, s);
+    return rc;
+}
+
 /* video_scale_bilinear_f32 (video_scale.c:231-286) between frames of either format: f16 sources are widened as they
  * are read, f16 targets truncated as they are written (what the pulls around an f32 scaler node do, main.c:43-71,
  * 105-144); the frame between the two passes is always f32.  The caller has dealt with the all-identity case. */
@@ -235,8 +272,8 @@ static int scale_core(any_frame *target, v2f tp, const any_frame *source, v2f sp
                   sc->max.x, (int)(sp.y + (tf->max.y - tp.y) * fac.y));
     box2i_intersect(&mid.full, &mid.full, tf);
     mid.cur = mid.full;
-    if (!x_first && !(atomic_load(&g_fir_path) & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED))) {
-        int rc = triangle_fused_vh(target, tp, source, sp, fac, &mid.full, s);
+    if (!(atomic_load(&g_fir_path) & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED))) {
+        int rc = x_first ? triangle_fused_hv(target, tp, source, sp, fac, &mid.full, s) : triangle_fused_vh(target, tp, source, sp, fac, &mid.full, s);
         if (rc == 0) t_scale_fused = 1;
         if (rc <= 0) return rc;                              /* done, or failed; 1: not for the fused kernel */
     }
