@@ -11,6 +11,7 @@ with copies of config 2's ring (same value distribution, opaque bottom layer), w
   config 5   3840x2160 10-node graph (4 sources, colour -> blur -> 4-step composite)        canvas_amd.stream.GraphStream
   lanczos3_x0.40 / x0.75 / x1.50   3840x2160 Lanczos3 at factors other than 1/2: the GENERAL FIR path (per-line tap
              tables, sweep_ops.hip), not a BASELINE config                                  cvs_resample_lanczos_f16_dev
+  scaler_x2.00   1920x1080 -> 3840x2160 through the reference's own scaler        cvs_scale_bilinear_f16_dev
 """
 import ctypes as C
 import time
@@ -111,6 +112,33 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
             out.append(rec)
         for d in outs:
             d.free()
+
+    # ---------------------------------------------------------------- the reference's own scaler, 1080p -> 4K (A9; no BASELINE config)
+    from canvas_amd.abi import v2f
+    small_w, small_h = w // 2, h // 2
+    srcs = []
+    for i, donor in enumerate(sources):
+        d = DeviceFrame((0, 0, small_w - 1, small_h - 1), np.uint16)
+        if i == 0:
+            d.upload(synth.layer_pixels(small_w, small_h, 1, g0))
+        else:                                                                      # a quarter of a 4K frame's pixels: same distribution
+            _lib.check(lib.cvs_memcpy_d2d(d.ptr, donor.ptr, d.nbytes, stream), "d2d")
+        srcs.append(d)
+    bigs = [DeviceFrame((0, 0, w - 1, h - 1), np.uint16) for _ in srcs]              # 16 x (17 + 66) MB rotate
+
+    def pass_s():
+        for src, dst in zip(srcs, bigs):
+            _lib.check(lib.cvs_scale_bilinear_f16_dev(dst.ref(), v2f(0, 0), src.ref(), v2f(0, 0), v2f(2.0, 2.0), stream), "scaler")
+
+    n, dt = _timed_passes(lib, _lib, [stream], pass_s, seconds / 2)
+    digest = verify.canon_sha256(bigs[0].download(stream).array)
+    rec = _record(dist, gather_stats, checksum52, "scaler_x2.00", "1920x1080 f16 -> video_scale_bilinear (triangle) x2 -> 3840x2160 f16",
+                  n * len(srcs), w * h, dt, digest, verify.stream_fixture("scaler_1920x1080_x2.00", g0), 10,
+                  "Mpixels/s and bytes are per OUTPUT pixel: source read once (2 B per output px) + target written once; both passes in one launch", rank)
+    if rec:
+        out.append(rec)
+    for d in srcs + bigs:
+        d.free()
 
     # ---------------------------------------------------------------- config 4
     w8, h8, nl = 7680, 4320, 3

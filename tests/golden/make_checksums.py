@@ -76,8 +76,23 @@ def lanczos3(factor):
     return run
 
 
+def scaler(w, h, factor):
+    """stream-only cases: the reference's own scaler (video_scale_bilinear_f32) between f16 frames: widen, both passes, truncate"""
+    def run(oracle, g=0):
+        from canvas_amd import synth
+        from canvas_amd.abi import HostFrame, v2f
+        src16 = synth.layer_frame(w, h, 1, g)
+        src32 = HostFrame(src16.full_window, np.float32, oracle.half_to_float(src16.array))
+        out = HostFrame((0, 0, int(w * factor) - 1, int(h * factor) - 1), np.float32)
+        oracle.lib().orc_scale_bilinear_f32(out.ref(), v2f(0, 0), src32.ref(), v2f(0, 0), v2f(factor, factor))
+        assert out.current_window.tuple() == out.full_window.tuple(), out.current_window.tuple()
+        return oracle.float_to_half(out.array)
+    return run
+
+
 CASES = {"config2_3840x2160": config2, "config3_3840x2160_to_1920x1080": config3, "config4_7680x4320": config4, "config5_3840x2160": config5}
-STREAM_ONLY = {"lanczos3_3840x2160_x0.40": lanczos3(0.4), "lanczos3_3840x2160_x0.75": lanczos3(0.75), "lanczos3_3840x2160_x1.50": lanczos3(1.5)}
+STREAM_ONLY = {"lanczos3_3840x2160_x0.40": lanczos3(0.4), "lanczos3_3840x2160_x0.75": lanczos3(0.75), "lanczos3_3840x2160_x1.50": lanczos3(1.5),
+               "scaler_1920x1080_x2.00": scaler(1920, 1080, 2.0)}       # (reducing, the reference covers only part of the target: video_scale.c:256-262)
 
 
 def checksums(only=None):
