@@ -1,26 +1,36 @@
-// sweep_ops.hip -- separable FIR with per-line tap tables, both passes in one sweep down the frame, one lane per target
-// column and CHANNEL PAIR.
+// sweep_ops.hip -- separable FIR with per-line tap tables (Lanczos at any factor, the triangle scaler when its horizontal
+// pass comes first), both passes in one sweep down the frame: one lane per target column and CHANNEL PAIR, one wave per
+// workgroup.
 //
 // Third form of the general FIR path (after the LDS tiles of fir_ops.hip and the lane-per-pixel sweep of resample_ops.hip).
 // What the lane-per-pixel sweep measured (profiles/r02/general_fir_attempts.txt): a 4K -> 1536 x 864 Lanczos has 24 waves
 // of target columns; to fill 1 024 SIMDs it must cut the frame into 54 row segments (15 halo rows for 40 useful ones) and
-// still runs 1.3 waves per SIMD, every wave paying its own chain of LDS, scalar-table and barrier latencies: 11 cycles per
-// instruction.  The sums of a pixel's four channels are independent, so here a lane owns ONE channel of one target column:
-//   * four times the waves for the same frame: segments three times as long (halo ~30 %) at ~4 waves per SIMD;
-//   * H: the lane gathers its taps from the LDS row with ds_read_b32 -- the four lanes of a column read 16 contiguous
-//     bytes, columns 16 / factor bytes apart: near conflict-free at any factor;  (LDS: 16 KiB per workgroup)
-//   * V: the vertical table comes TURNED ROUND from the host (cvk_fir_axis.rec): per SOURCE line which accumulator slots
-//     take it, with what weight, and which slots end there.  A line's slot is its index modulo the slot count, so the
-//     record does not depend on where a segment starts and the kernel does no bookkeeping at all: two scalar loads per
-//     source row (weights arrive in SGPRs and feed v_mul_f32 directly), one bit test per slot.
-//     Slots of lines that began above the segment accumulate partial sums that are never stored; each slot is cleared
-//     when its line ends, before the next line of the same slot begins (the host guarantees lines slot-count apart never
-//     overlap: max_active <= nacc).
+// still runs 1.3 waves per SIMD, every wave paying its own chain of LDS, table and barrier latencies: 11 cycles per
+// instruction.  What this kernel does instead (each step measured: the same file):
+//   * the sums of a pixel's channel pairs are independent: a lane owns one PAIR of one target column (packed f32 costs the
+//     issue slot of scalar f32, so pairs halve the arithmetic per pixel; single channels would not) -- twice the waves for
+//     the same frame, segments twice as long;
+//   * a workgroup is ONE wave (32 columns): its two LDS rows are its own and LDS runs a wave's accesses in order, so a row
+//     step has no barrier;
+//   * H: the lane gathers its taps from the LDS row (ds_read_b64 at per-tap offsets held in registers, weights in
+//     registers: both are constant down the sweep);
+//   * V: the vertical table comes TURNED ROUND from the host (cvk_fir_axis.rec, scale.c axis_upload): per SOURCE line the
+//     slots that end there, the first line that ends there and one weight per accumulator slot -- as a scalar register
+//     pair, 0 for the slots that do not take the line.  A line's slot is its index modulo the slot count, so the record
+//     does not depend on where a segment starts and the kernel keeps no books: two scalar loads per source row, a row
+//     ahead.  Slots of lines that began above the segment accumulate partial sums that are never stored; a slot is cleared
+//     when its line ends, before the next line of the same slot begins (max_active <= nacc, checked by the host);
+//   * the row step is straight-line code: a taken branch costs a wave an instruction fetch (~64 cycles) that two to four
+//     waves per SIMD do not hide.  The accumulators are a register VECTOR; the slot that ends is read and cleared through
+//     the GPR index register; staging loads are unconditional (clamped lane offsets); pointers advance by scalar adds;
+//   * source rows are fetched a group of four ahead by asm loads with a hand-written wait (instances with registers to
+//     spare), 8-slot instances also gather the next row's taps before the accumulator pass of the current one.
 // Arithmetic: every sum starts at 0.0f, products and additions rounded separately, ascending source order -- bit for bit
 // the two gather passes of video_scale.c:93-122,193-226 on the planners' tables.  Padded horizontal taps (lists shorter
-// than MAXT) read the ZERO PIXEL kept behind the LDS row with weight 0: acc + 0 * 0 == acc.
-// Bound: LDS gather rate / VALU issue (HBM traffic is source once + target once).  Algorithmic bytes: source pixel once +
-// target pixel once.
+// than MAXT) read the ZERO PIXEL kept behind the LDS row with weight 0: acc + 0 * 0 == acc; a slot's weight 0 on an Inf or
+// NaN row is handled by an additive pass with v_mul_legacy_f32 (see `filter`).
+// Bound: LDS gather latency / VALU issue at 2-4 waves per SIMD (HBM traffic is source once + target once).
+// Algorithmic bytes: source pixel once + target pixel once.
 #include <climits>
 #include <cstdlib>
 #include "kernels.h"
