@@ -44,7 +44,7 @@ __device__ __forceinline__ f32x2 widen(const Unit<false> &u) { return f32x2{ __u
 
 template <int MAXT, int NACC, int NQ, bool INH>
 __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows_per_wg, int line0) {
-    static_assert(NQ * kLanes <= 2 * kRowPx && (NACC == 8 || NACC == 16), "units per lane; one register vector of slots per unit");
+    static_assert(NQ >= 1 && NQ <= 4 && NQ * kLanes <= 2 * kRowPx && (NACC == 8 || NACC == 16), "units per lane; one register vector of slots per unit");
     __shared__ __align__(16) float lds[kRowFl];     // the vertical sums of one target line, a zero pixel behind them
     __shared__ int seg[4];                          // first / last source row of the segment, "a line has no taps", first line with taps
     const int lane = threadIdx.x, pr = lane & 1;
@@ -107,9 +107,10 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
     char *optr = tbase + (size_t)(fp.ty0 + __builtin_amdgcn_readfirstlane(seg[3]) - fp.target.fy0) * trow;
 
     typedef float accvec __attribute__((ext_vector_type(2 * NACC)));
-    accvec acc[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) acc[q] = 0.0f;
+    // one register vector per unit, as NAMED variables: an array of three or more is merged by hipcc into one vector wider
+    // than the widest register tuple, and lands in scratch
+    accvec acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
+#define CVK_ACC(q) ((q) == 0 ? acc0 : (q) == 1 ? acc1 : (q) == 2 ? acc2 : acc3)      /* q: a constant after unrolling */
 
     // source units lane + 64 q of the strip's footprint (clamped to its last unit: every load unconditional), fetched a group
     // of four rows ahead by asm loads and a hand-written vmcnt(0) (see sweep_ops.hip)
@@ -172,8 +173,8 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
             const f32x2 xp = mine ? f32x2{ 0.0f, 0.0f } : x[q];
 #pragma unroll
             for (int j = 0; j < NACC; j++) {
-                const f32x2 t = f32x2{ acc[q][2 * j], acc[q][2 * j + 1] } + xp * rec.w[j];
-                acc[q][2 * j] = t.x; acc[q][2 * j + 1] = t.y;
+                const f32x2 t = f32x2{ CVK_ACC(q)[2 * j], CVK_ACC(q)[2 * j + 1] } + xp * rec.w[j];
+                CVK_ACC(q)[2 * j] = t.x; CVK_ACC(q)[2 * j + 1] = t.y;
             }
         }
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0, 0)) {
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
                 const f32x2 xo = mine ? x[q] : f32x2{ 0.0f, 0.0f };
 #pragma unroll
                 for (int j = 0; j < NACC; j++) {
-                    const f32x2 t = f32x2{ acc[q][2 * j], acc[q][2 * j + 1] } + f32x2{ mul_zero_wins(xo.x, rec.w[j].x), mul_zero_wins(xo.y, rec.w[j].x) };
-                    acc[q][2 * j] = t.x; acc[q][2 * j + 1] = t.y;
+                    const f32x2 t = f32x2{ CVK_ACC(q)[2 * j], CVK_ACC(q)[2 * j + 1] } + f32x2{ mul_zero_wins(xo.x, rec.w[j].x), mul_zero_wins(xo.y, rec.w[j].x) };
+                    CVK_ACC(q)[2 * j] = t.x; CVK_ACC(q)[2 * j + 1] = t.y;
                 }
             }
         }
@@ -196,8 +197,8 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
                 const int e = 2 * (i & (NACC - 1));
 #pragma unroll
                 for (int q = 0; q < NQ; q++) {
-                    const f32x2 v = { acc[q][e], acc[q][e + 1] };
-                    acc[q][e] = 0.0f; acc[q][e + 1] = 0.0f;
+                    const f32x2 v = { CVK_ACC(q)[e], CVK_ACC(q)[e + 1] };
+                    CVK_ACC(q)[e] = 0.0f; CVK_ACC(q)[e + 1] = 0.0f;
                     *reinterpret_cast<f32x2 *>(lds + 2 * (lane + q * kLanes)) = v;
                 }
                 __builtin_amdgcn_wave_barrier();                   // (compiler fence; the hardware keeps a wave's LDS accesses in order)
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
     issue_group(gb);
     while (four_rows(ga, gb) && four_rows(gb, ga)) {}
     asm volatile("s_waitcnt vmcnt(0)" : : : "memory");             // nothing of this wave is in flight when it ends
+#undef CVK_ACC
 }
 
 template <int MAXT, int NACC, int NQ, bool INH>
@@ -269,8 +271,8 @@ struct Instance { int maxt, nacc, nq; int (*f16)(const cvk_fir2d_params &, int, 
 const Instance kInstances[] = {
     CVK_VH_INSTANCE(4, 8, 1),  CVK_VH_INSTANCE(4, 16, 1),          // the triangle scaler enlarging up to 2x (and 1 : 1 shifts)
     CVK_VH_INSTANCE(8, 8, 2),  CVK_VH_INSTANCE(8, 16, 1),          // reducing down to ~0.55x; enlarging up to 4x
-    // (more than two units per lane -- reductions below ~0.55x -- sent hipcc's register vectors to scratch; the two-launch
-    // form takes those, and is already within a fifth of its memory traffic there)
+    CVK_VH_INSTANCE(4, 8, 3),  CVK_VH_INSTANCE(8, 8, 3),           // down to ~0.4x (0.5x: three taps, 67 source columns)
+    CVK_VH_INSTANCE(8, 8, 4),                                      // down to ~0.3x; below, the two launches
 };
 
 const Instance *pick(const cvk_fir2d_params *fp) {

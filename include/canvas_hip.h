@@ -389,7 +389,7 @@ CVS_EXPORT int cvs_chain_color_over_f16_dev(const cvs_chain_job *jobs, int njobs
  * (windows did not all cover the output's full window) */
 CVS_EXPORT int cvs_chain_last_was_fused(void);
 /* 1 when the calling thread's last scaler call (cvs_scale_bilinear_*_dev, video_scale_bilinear_f32) ran both passes in one
- * launch (sweep_vh_ops.hip when the vertical pass comes first, sweep_ops.hip otherwise; factors >= ~0.55); tests and tools */
+ * launch (sweep_vh_ops.hip when the vertical pass comes first, sweep_ops.hip otherwise; factors >= ~0.3); tests and tools */
 CVS_EXPORT int cvs_scale_last_was_fused(void);
 /* kernel launches the calling thread's last fused chain call was cut into (about eight 4K frames' worth of bytes each) */
 CVS_EXPORT int cvs_chain_last_launch_count(void);

@@ -227,7 +227,7 @@ def test_hot_kernels_keep_their_state_in_registers():
                         hand += 1
                 # sweep_vh_ops.hip: every instance fetches that way
                 for agprs, name, vgprs in re.findall(r"\.agpr_count:\s+(\d+)(?:(?!\.agpr_count).)*?\.name:\s+(\S*k_fir_vh\S+)(?:(?!\.agpr_count).)*?\.vgpr_count:\s+(\d+)", notes, re.S):
-                    assert int(agprs) == 0 and int(vgprs) <= 160, (name, agprs, vgprs)
+                    assert int(agprs) == 0 and int(vgprs) <= 224, (name, agprs, vgprs)
                     hand += 1
     assert checked >= 20, checked
-    assert hand >= 18, hand
+    assert hand >= 20, hand
