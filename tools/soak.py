@@ -41,6 +41,11 @@ wide = DeviceFrame(full, np.uint16)
 big = DeviceFrame((0, 0, int(w * 1.5) - 1, int(h * 1.5) - 1), np.uint16)
 mid = DeviceFrame((0, 0, int(w * 0.75) - 1, int(h * 0.75) - 1), np.uint16)
 deep = DeviceFrame(full, np.uint16)
+# the reference's scaler in one launch: vertical pass first (2x, 0.5x) and horizontal first (0.75 x 1.5)
+from canvas_amd.abi import v2f  # noqa: E402
+up2 = DeviceFrame((0, 0, 2 * w - 1, 2 * h - 1), np.uint16)
+half = DeviceFrame((0, 0, w // 2 - 1, h // 2 - 1), np.uint16)
+anam = DeviceFrame((0, 0, int(w * 0.75) - 1, int(h * 1.5) - 1), np.uint16)
 
 
 def once():
@@ -53,13 +58,17 @@ def once():
     _lib.check(lib.cvs_resample_lanczos_f16_dev(big.ref(), sets[3][1][1].ref(), C.c_float(1.5), C.c_float(1.5), 3, stream))
     _lib.check(lib.cvs_resample_lanczos_f16_dev(mid.ref(), sets[0][1][0].ref(), C.c_float(0.75), C.c_float(0.75), 3, stream))
     chain_color_over([(deep, [sets[i % 4][1][i % 2] for i in range(6)])], None, _lib.LUT_NONE, _lib.LUT_NONE, stream)
+    _lib.check(lib.cvs_scale_bilinear_f16_dev(up2.ref(), v2f(0, 0), sets[1][1][0].ref(), v2f(0, 0), v2f(2.0, 2.0), stream))
+    _lib.check(lib.cvs_scale_bilinear_f16_dev(half.ref(), v2f(0, 0), sets[2][1][0].ref(), v2f(0, 0), v2f(0.5, 0.5), stream))
+    _lib.check(lib.cvs_scale_bilinear_f16_dev(anam.ref(), v2f(0, 0), sets[3][1][0].ref(), v2f(0, 0), v2f(0.75, 1.5), stream))
 
 
 def snapshot():
     _lib.check(lib.cvs_stream_sync(stream))
     return [s[0].download().array.copy() for s in sets] + [graph.slots[0]["out"].download().array.copy(), graph.slots[1]["out"].download().array.copy(),
                                                         small.download().array.copy(), odd.download().array.copy(), wide.download().array.copy(),
-                                                        big.download().array.copy(), mid.download().array.copy(), deep.download().array.copy()]
+                                                        big.download().array.copy(), mid.download().array.copy(), deep.download().array.copy(),
+                                                        up2.download().array.copy(), half.download().array.copy(), anam.download().array.copy()]
 
 
 once()
@@ -76,5 +85,5 @@ while time.perf_counter() - t0 < seconds:
             print("MISMATCH after %d iterations: %d values differ" % (n, bad))
             sys.exit(1)
     checks += 1
-print("soak ok: %d iterations (%d launches of the chain over 8 frames, %d config-5 frames, %d config-3 frames, as many 0.4x / 0.75x / 1.5x resamples, 21-tap blurs and 6-layer stacks), %d full compares, %.1f s"
+print("soak ok: %d iterations (%d launches of the chain over 8 frames, %d config-5 frames, %d config-3 frames, as many 0.4x / 0.75x / 1.5x resamples, 21-tap blurs, 6-layer stacks and scaler calls at 2x, 0.5x and 0.75 x 1.5), %d full compares, %.1f s"
       % (n, n, 2 * n, n, checks, time.perf_counter() - t0))
