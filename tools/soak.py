@@ -85,5 +85,7 @@ while time.perf_counter() - t0 < seconds:
             print("MISMATCH after %d iterations: %d values differ" % (n, bad))
             sys.exit(1)
     checks += 1
+    if checks % 50 == 0:                      # (a silent GPU command is taken for hung after a few minutes)
+        print("  %d iterations, %d compares, %.0f s" % (n, checks, time.perf_counter() - t0), flush=True)
 print("soak ok: %d iterations (%d launches of the chain over 8 frames, %d config-5 frames, %d config-3 frames, as many 0.4x / 0.75x / 1.5x resamples, 21-tap blurs, 6-layer stacks and scaler calls at 2x, 0.5x and 0.75 x 1.5), %d full compares, %.1f s"
       % (n, n, 2 * n, n, checks, time.perf_counter() - t0))
