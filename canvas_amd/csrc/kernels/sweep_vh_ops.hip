@@ -171,9 +171,15 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
         for (int q = 0; q < NQ; q++) {
             const bool mine = __builtin_amdgcn_class(x[q].x, 0x207) || __builtin_amdgcn_class(x[q].y, 0x207);
             const f32x2 xp = mine ? f32x2{ 0.0f, 0.0f } : x[q];
+            // all products, then all sums: a packed add right behind the packed multiply it depends on costs a hazard slot
+            // (an s_nop per slot, and this kernel is short of scalar issue, not of registers)
+            f32x2 p[NACC];
+#pragma unroll
+            for (int j = 0; j < NACC; j++) p[j] = xp * rec.w[j];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NACC; j++) {
-                const f32x2 t = f32x2{ CVK_ACC(q)[2 * j], CVK_ACC(q)[2 * j + 1] } + xp * rec.w[j];
+                const f32x2 t = f32x2{ CVK_ACC(q)[2 * j], CVK_ACC(q)[2 * j + 1] } + p[j];
                 CVK_ACC(q)[2 * j] = t.x; CVK_ACC(q)[2 * j + 1] = t.y;
             }
         }
