@@ -31,6 +31,7 @@
 // NaN row is handled by an additive pass with v_mul_legacy_f32 (see `filter`).
 // Bound: LDS gather latency / VALU issue at 2-4 waves per SIMD (HBM traffic is source once + target once).
 // Algorithmic bytes: source pixel once + target pixel once.
+#include <atomic>
 #include <climits>
 #include <cstdlib>
 #include "kernels.h"
@@ -393,11 +394,13 @@ int launch(const cvk_fir2d_params &fp, int cus, hipStream_t s) {
     constexpr bool HAND = hand_pipelined(MAXT, NACC, NQ, INH);
     const int cols = fp.tx1 - fp.tx0 + 1, rows = fp.ty1 - fp.ty0 + 1;
     const int strips = (cols + kCols - 1) / kCols;
-    static int per_cu = 0;
+    static std::atomic<int> cached{ 0 };            // (several threads may launch at once: pull-queue workers)
+    int per_cu = cached.load(std::memory_order_relaxed);
     if (!per_cu) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fir_lanes<MAXT, NACC, NQ, INH, HAND>, kLanes, 0) != hipSuccess || n < 1) n = 1;
         per_cu = n;
+        cached.store(n, std::memory_order_relaxed);
     }
     int segs = (per_cu * (cus > 0 ? cus : 256)) / strips;
     if (segs < 1) segs = 1;

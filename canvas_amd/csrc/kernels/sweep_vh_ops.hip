@@ -14,6 +14,7 @@
 //     pair from there -- sum from 0.0f in ascending tap order -- and stores.
 // LDS is touched once per TARGET line, not per source row.  Padded horizontal taps read the zero pixel behind the row.
 // Bound: VALU issue / latency at 2-4 waves per SIMD.  Algorithmic bytes: source pixel once + target pixel once.
+#include <atomic>
 #include <climits>
 #include "kernels.h"
 #include "chain_math.hpp"
@@ -252,11 +253,13 @@ template <int MAXT, int NACC, int NQ, bool INH>
 int launch(const cvk_fir2d_params &fp, int line0, int cus, hipStream_t s) {
     const int cols = fp.tx1 - fp.tx0 + 1, rows = fp.ty1 - fp.ty0 + 1 - line0;
     const int strips = (cols + kCols - 1) / kCols;
-    static int per_cu = 0;
+    static std::atomic<int> cached{ 0 };            // (several threads may launch at once: pull-queue workers)
+    int per_cu = cached.load(std::memory_order_relaxed);
     if (!per_cu) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fir_vh<MAXT, NACC, NQ, INH>, kLanes, 0) != hipSuccess || n < 1) n = 1;
         per_cu = n;
+        cached.store(n, std::memory_order_relaxed);
     }
     // one round of resident workgroups over the frame; a segment re-reads (but does not re-filter horizontally) the source
     // rows its first lines reach back to
