@@ -51,6 +51,8 @@ SIGNATURES = {
     "gettime": (C.c_int64, []),
     "video_get_frame_f16": (None, [P(video_source), C.c_int, _F16]),
     "video_get_frame_f32": (None, [P(video_source), C.c_int, _F32]),
+    "video_get_frame_f16_gl": (None, [P(video_source), C.c_int, _F16]),
+    "video_get_frame_f32_gl": (None, [P(video_source), C.c_int, _F32]),
     "video_get_frame_dev": (None, [P(video_source), C.c_int, P(rgba_frame_dev)]),
     "video_copy_frame_f16": (None, [_F16, _F16]),
     "video_copy_frame_alpha_f32": (None, [_F32, _F32, C.c_float]),

@@ -402,6 +402,29 @@ CVS_EXPORT void video_get_frame_f32(video_source *source, int frame_index, rgba_
     box2i_set_empty(&frame->current_window);
 }
 
+/* src/cprocess/main.c:78-103,146-172: "get a frame, but forcibly pull it from the GL pipeline" -- what
+ * get_frame_f16/f32(..., force_gl=True) calls (src/process/RgbaFrameF16.c:247-249).  Slot 3 is the device slot
+ * here, so the forced pull goes through the source's device entry even when it also fills a host slot; a source
+ * without a device slot is pulled the ordinary way (the reference leaves the window empty there: it has no other
+ * way to reach its GL pipeline, while every pixel entry of this library runs on the device anyway). */
+static int cvs_device_only(video_source *source, video_frame_source_funcs *f, video_source *forced) {
+    if (!source || !source->funcs || !(source->funcs->flags & VIDEO_SOURCE_FLAG_DEVICE) || !source->funcs->get_frame_dev) return 0;
+    *f = *source->funcs;
+    f->get_frame = NULL;
+    f->get_frame_32 = NULL;
+    forced->obj = source->obj;
+    forced->funcs = f;
+    return 1;
+}
+CVS_EXPORT void video_get_frame_f16_gl(video_source *source, int frame_index, rgba_frame_f16 *frame) {
+    video_frame_source_funcs f; video_source forced;
+    video_get_frame_f16(cvs_device_only(source, &f, &forced) ? &forced : source, frame_index, frame);
+}
+CVS_EXPORT void video_get_frame_f32_gl(video_source *source, int frame_index, rgba_frame_f32 *frame) {
+    video_frame_source_funcs f; video_source forced;
+    video_get_frame_f32(cvs_device_only(source, &f, &forced) ? &forced : source, frame_index, frame);
+}
+
 /* Fill a device frame from any source: slot 3 when the source has one, else a host pull + upload. */
 CVS_EXPORT void video_get_frame_dev(video_source *source, int frame_index, rgba_frame_dev *frame) {
     if (!source || !source->funcs || cvs_enter() != 0) { box2i_set_empty(&frame->current_window); return; }

@@ -52,35 +52,42 @@ PyObject *py_RgbaFrameF32_new(box2i *full_window, rgba_frame_f32 **frame) {
     return (PyObject *)f;
 }
 
-static bool parse_pull_args(PyObject *args, PyObject *kw, int *frame_index, box2i *window) {
+/* force_gl (RgbaFrameF16.c:221-249): "pull through vtable slot 3".  Slot 3 is the device slot here, so a true
+ * value forces the source's device entry (video_get_frame_f16_gl / _f32_gl); there is no GL path. */
+static bool parse_pull_args(PyObject *args, PyObject *kw, int *frame_index, box2i *window, bool *forced) {
     static char *kwlist[] = { "frame_index", "data_window", "force_gl", NULL };
-    PyObject *window_obj = NULL, *force_gl = NULL;      /* force_gl is accepted and ignored: there is no GL path */
+    PyObject *window_obj = NULL, *force_gl = NULL;
     if (!PyArg_ParseTupleAndKeywords(args, kw, "iO|O", kwlist, frame_index, &window_obj, &force_gl)) return false;
+    int truth = force_gl ? PyObject_IsTrue(force_gl) : 0;
+    if (truth < 0) return false;
+    *forced = truth != 0;
     return py_parse_box2i(window_obj, window);
 }
 
 PyObject *py_get_frame_f16(PyObject *self, PyObject *args, PyObject *kw) {
-    int frame_index; box2i window; rgba_frame_f16 *frame;
-    if (!parse_pull_args(args, kw, &frame_index, &window)) return NULL;
+    int frame_index; box2i window; rgba_frame_f16 *frame; bool forced;
+    if (!parse_pull_args(args, kw, &frame_index, &window, &forced)) return NULL;
     PyObject *result = py_RgbaFrameF16_new(&window, &frame);
     if (!result) return NULL;
     video_source *source = NULL;
     if (!py_video_take_source(self, &source)) { Py_DECREF(result); return NULL; }
     frame->current_window = frame->full_window;
-    video_get_frame_f16(source, frame_index, frame);
+    if (forced) video_get_frame_f16_gl(source, frame_index, frame);
+    else video_get_frame_f16(source, frame_index, frame);
     py_video_take_source(NULL, &source);
     return result;
 }
 
 PyObject *py_get_frame_f32(PyObject *self, PyObject *args, PyObject *kw) {
-    int frame_index; box2i window; rgba_frame_f32 *frame;
-    if (!parse_pull_args(args, kw, &frame_index, &window)) return NULL;
+    int frame_index; box2i window; rgba_frame_f32 *frame; bool forced;
+    if (!parse_pull_args(args, kw, &frame_index, &window, &forced)) return NULL;
     PyObject *result = py_RgbaFrameF32_new(&window, &frame);
     if (!result) return NULL;
     video_source *source = NULL;
     if (!py_video_take_source(self, &source)) { Py_DECREF(result); return NULL; }
     frame->current_window = frame->full_window;
-    video_get_frame_f32(source, frame_index, frame);
+    if (forced) video_get_frame_f32_gl(source, frame_index, frame);
+    else video_get_frame_f32(source, frame_index, frame);
     py_video_take_source(NULL, &source);
     return result;
 }
@@ -99,7 +106,7 @@ static PyObject *pull_bytes(PyObject *self, PyObject *args, PyObject *kw, bool w
         PyObject *window_obj = NULL;
         if (!PyArg_ParseTupleAndKeywords(args, kw, "iO|f", kwlist, &frame_index, &window_obj, &intent)) return NULL;
         if (!py_parse_box2i(window_obj, &window)) return NULL;
-    } else if (!parse_pull_args(args, kw, &frame_index, &window)) return NULL;
+    } else if (!parse_pull_args(args, kw, &frame_index, &window, &(bool){ false })) return NULL;
     video_source *source = NULL;
     if (!py_video_take_source(self, &source)) return NULL;
     PyObject *bytes = NULL, *result = NULL;

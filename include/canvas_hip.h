@@ -150,6 +150,11 @@ CVS_EXPORT int64_t gettime(void);
 /* src/cprocess/main.c:33-76,105-144 -- vtable dispatch + format conversion; NULL source => empty window */
 CVS_EXPORT void video_get_frame_f16(video_source *source, int frame_index, rgba_frame_f16 *frame);
 CVS_EXPORT void video_get_frame_f32(video_source *source, int frame_index, rgba_frame_f32 *frame);
+/* src/cprocess/main.c:78-103,146-172 -- the forced pull through vtable slot 3 that force_gl=True asks for
+ * (src/process/RgbaFrameF16.c:247-249): here slot 3 is the device slot; a source without one is pulled the
+ * ordinary way instead of yielding an empty window */
+CVS_EXPORT void video_get_frame_f16_gl(video_source *source, int frame_index, rgba_frame_f16 *frame);
+CVS_EXPORT void video_get_frame_f32_gl(video_source *source, int frame_index, rgba_frame_f32 *frame);
 /* device twin: fills a device frame through slot 3 when the source has one, else pulls a host
  * frame and uploads it */
 CVS_EXPORT void video_get_frame_dev(video_source *source, int frame_index, rgba_frame_dev *frame);

@@ -15,7 +15,7 @@
 #define fluggo_pyframework
 
 #include <Python.h>
-#include "canvas_hip.h"
+#include "framework.h"      /* as pyframework.h:25: EXPORT, glib, then canvas_hip.h */
 
 #if defined(__cplusplus)
 extern "C" {

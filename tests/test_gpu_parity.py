@@ -610,6 +610,50 @@ def test_pull_dispatch_converts_between_formats(cvs, orc):
     assert out16.current_window.is_empty()
 
 
+def test_forced_pull_goes_through_the_device_slot(cvs, orc):
+    """video_get_frame_f16_gl / _f32_gl (main.c:78-103,146-172; what force_gl=True calls, RgbaFrameF16.c:247-249): the
+    pull through vtable slot 3 even when the source also fills a host slot.  Slot 3 is the device slot here: a vtable
+    whose host slots would paint junk, with the workspace's device entry in slot 3, must yield the workspace's pixels;
+    a source with no device slot is pulled the ordinary way."""
+    rng = np.random.default_rng(77)
+    full = (0, 0, 23, 11)
+    frames = [rand_f16_frame(rng, full, full, alpha="one"), rand_f16_frame(rng, full, (3, 2, 20, 9))]
+    sources = [_py_source(fill16=_fill_from([fr])) for fr in frames]
+    ws = cvs.workspace_create()
+    for s, z in zip(sources, (0, 1)):
+        cvs.workspace_add_item(ws, C.cast(C.pointer(s[0]), C.c_void_p), 0, 10, 0, z, None)
+    vs = video_source()
+    cvs.workspace_as_video_source(ws, C.byref(vs))
+    assert vs.funcs.contents.flags & 1 and vs.funcs.contents.get_frame_dev          # VIDEO_SOURCE_FLAG_DEVICE
+
+    want16, want32 = HostFrame(full, np.uint16), HostFrame(full, np.float32)
+    cvs.video_get_frame_f16(C.byref(vs), 2, want16.ref())
+    cvs.video_get_frame_f32(C.byref(vs), 2, want32.ref())
+
+    junk = rand_f16_frame(rng, full, (0, 0, 5, 5))
+    junk32 = rand_f32_frame(rng, full, (0, 0, 5, 5))
+    decoy, keep = _py_source(fill16=_fill_from([junk]), fill32=_fill_from([junk32]))
+    keep[2].flags = vs.funcs.contents.flags
+    keep[2].get_frame_dev = vs.funcs.contents.get_frame_dev
+    decoy.obj = vs.obj
+    got16, got32 = HostFrame(full, np.uint16), HostFrame(full, np.float32)
+    cvs.video_get_frame_f16(C.byref(decoy), 2, got16.ref())
+    assert got16.current_window.tuple() == (0, 0, 5, 5)                              # ordinary pull: the host slot
+    cvs.video_get_frame_f16_gl(C.byref(decoy), 2, got16.ref())
+    cvs.video_get_frame_f32_gl(C.byref(decoy), 2, got32.ref())
+    assert same_window(got16.current_window, want16.current_window) and same_window(got32.current_window, want32.current_window)
+    assert_same_f16(got16.window_view(), want16.window_view(), "forced f16")
+    assert_same_f32(got32.window_view(), want32.window_view(), "forced f32")
+
+    plain = HostFrame(full, np.uint16)
+    cvs.video_get_frame_f16_gl(C.byref(sources[1][0]), 0, plain.ref())              # no device slot: ordinary pull
+    assert plain.current_window.tuple() == (3, 2, 20, 9)
+    assert np.array_equal(plain.window_view(), frames[1].window_view())
+    cvs.video_get_frame_f16_gl(None, 0, plain.ref())
+    assert plain.current_window.is_empty()
+    cvs.workspace_free(ws)
+
+
 def test_workspace_stack_host_and_device(cvs, orc):
     rng = np.random.default_rng(31)
     full = (0, 0, 31, 15)

@@ -336,7 +336,12 @@ def test_reference_own_frame_function_tests_run_unmodified(process):
         pytest.skip("reference tree not present")
     spec = importlib.util.spec_from_file_location("reference_frame_func_tests", path)
     mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    import sys
+    keep, sys.dont_write_bytecode = sys.dont_write_bytecode, True     # the reference tree is read-only: leave no __pycache__ in it
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.dont_write_bytecode = keep
     assert mod.process is process                       # it imported fluggo.media.process from this repo
     result = unittest.TextTestRunner(stream=open(os.devnull, "w")).run(unittest.defaultTestLoader.loadTestsFromModule(mod))
     assert result.testsRun >= 3 and result.wasSuccessful(), (result.failures, result.errors)

@@ -12,7 +12,12 @@ REF = "/root/reference/tests"
 def _run_reference_unittest(path, name):
     spec = importlib.util.spec_from_file_location(name, path)
     mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    import sys
+    keep, sys.dont_write_bytecode = sys.dont_write_bytecode, True     # the reference tree is read-only: leave no __pycache__ in it
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.dont_write_bytecode = keep
     result = unittest.TextTestRunner(stream=open(os.devnull, "w")).run(unittest.defaultTestLoader.loadTestsFromModule(mod))
     return mod, result
 
