@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libcanvas_hip.so")
 CHAIN_MAX_LAYERS = 8
 DISPLAY_RGBA8, DISPLAY_ARGB32_PREMUL = 0, 1
 FIR_PATH_AUTO, FIR_PATH_SWEEP, FIR_PATH_TILED, FIR_PATH_TABLES, FIR_PATH_LANES = 0, 1, 2, 4, 8
+FIR_KERNEL_NONE, FIR_KERNEL_WINDOW, FIR_KERNEL_HALVE, FIR_KERNEL_LANES, FIR_KERNEL_VH, FIR_KERNEL_TILED, FIR_KERNEL_STREAM, FIR_KERNEL_TWO_PASS, FIR_KERNEL_PASS = range(9)
 LUT_NONE, LUT_REC709_TO_LINEAR_SCENE, LUT_REC709_TO_LINEAR_DISPLAY, LUT_LINEAR_TO_REC709, LUT_LINEAR_TO_SRGB = -1, 0, 1, 2, 3
 
 
@@ -97,6 +98,7 @@ SIGNATURES = {
     "cvs_device_count": (C.c_int, []),
     "cvs_current_device": (C.c_int, []),
     "cvs_last_error": (C.c_char_p, []),
+    "cvs_clear_last_error": (None, []),
     "cvs_set_log_handler": (None, [C.c_void_p, C.c_void_p]),
     "cvs_device_name": (C.c_char_p, []),
     "cvs_compute_units": (C.c_int, []),
@@ -164,6 +166,7 @@ SIGNATURES = {
     "cvs_chain_color_over_f16_dev": (C.c_int, [P(chain_job), C.c_int, _f32p, C.c_int, C.c_int, _vp]),
     "cvs_chain_last_was_fused": (C.c_int, []),
     "cvs_scale_last_was_fused": (C.c_int, []),
+    "cvs_fir_last_kernel": (C.c_int, []),
     "cvs_chain_last_launch_count": (C.c_int, []),
     "cvs_mix_cross_f16_dev": (C.c_int, [_F16, _F16, _F16, C.c_float, _vp]),
 }

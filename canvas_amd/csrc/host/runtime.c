@@ -45,6 +45,7 @@ void cvs_set_error(const char *fmt, ...) {
 void cvs_clear_error(void) { t_error[0] = 0; }
 
 CVS_EXPORT const char *cvs_last_error(void) { return t_error; }
+CVS_EXPORT void cvs_clear_last_error(void) { t_error[0] = 0; }
 
 CVS_EXPORT int cvs_device_count(void) {
     int n = 0;

@@ -24,6 +24,14 @@
 static _Atomic int g_fir_path = CVS_FIR_PATH_AUTO;
 static _Thread_local int t_scale_fused;         /* the calling thread's last scaler call ran both passes in one launch */
 CVS_EXPORT int cvs_scale_last_was_fused(void) { return t_scale_fused; }
+static _Thread_local int t_fir_kernel;          /* CVS_FIR_KERNEL_*: the kernel the calling thread's last FIR launch went to */
+CVS_EXPORT int cvs_fir_last_kernel(void) { return t_fir_kernel; }
+/* A fused kernel that was chosen for a table pair and then did not launch: the next kernel in line still computes the
+ * same pixels, 3-7x slower -- that must not go unnoticed. */
+static void fir_launch_fell_through(const char *kernel, int rc) {
+    (void)hipGetLastError();
+    cvs_set_error("%s did not launch (%s): falling back to the next FIR kernel", kernel, hipGetErrorString((hipError_t)rc));
+}
 CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_LANES)); }
 
 typedef struct {
@@ -167,6 +175,7 @@ static int triangle_pass(any_frame *target, float tmin, const any_frame *source,
         fp.stride = table.stride;
         fp.in_half = source->half; fp.out_half = target->half;
         rc = cvk_fir_gather(&fp, s);
+        if (rc == 0) t_fir_kernel = CVS_FIR_KERNEL_PASS;
     }
     axis_done(pin, s);
     if (rc != 0) { cvs_set_error("FIR gather launch failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
@@ -206,8 +215,8 @@ static int triangle_fused_vh(any_frame *target, v2f tp, const any_frame *source,
                 const bool covers = lo2 == tf->min.y && hi2 == tf->max.y;
                 hipError_t e = covers || !any_bytes(target) ? hipSuccess : hipMemsetAsync(target->data, 0, any_bytes(target), s);
                 int krc = e == hipSuccess ? cvk_fir_vh(&fp, lo2 - fp.ty0, cvs_cus(), s) : (int)e;
-                if (krc == 0) { box2i_set(&target->cur, hlo, lo2, hhi, hi2); rc = 0; }
-                else { (void)hipGetLastError(); rc = 1; }               /* did not launch: the two passes decide */
+                if (krc == 0) { box2i_set(&target->cur, hlo, lo2, hhi, hi2); t_fir_kernel = CVS_FIR_KERNEL_VH; rc = 0; }
+                else { fir_launch_fell_through("k_fir_vh", krc); rc = 1; }   /* did not launch: the two passes decide */
             }
         }
     }
@@ -243,8 +252,8 @@ static int triangle_fused_hv(any_frame *target, v2f tp, const any_frame *source,
                 const bool covers = fp.tx0 == tf->min.x && hi2 == tf->max.x;
                 hipError_t e = covers || !any_bytes(target) ? hipSuccess : hipMemsetAsync(target->data, 0, any_bytes(target), s);
                 int krc = e == hipSuccess ? cvk_fir_lanes(&fp, cvs_cus(), s) : (int)e;
-                if (krc == 0) { box2i_set(&target->cur, lo2, vlo, hi2, vhi); rc = 0; }
-                else { (void)hipGetLastError(); rc = 1; }
+                if (krc == 0) { box2i_set(&target->cur, lo2, vlo, hi2, vhi); t_fir_kernel = CVS_FIR_KERNEL_LANES; rc = 0; }
+                else { fir_launch_fell_through("k_fir_lanes", krc); rc = 1; }
             }
         }
     }
@@ -257,6 +266,7 @@ static int triangle_fused_hv(any_frame *target, v2f tp, const any_frame *source,
  * 105-144); the frame between the two passes is always f32.  The caller has dealt with the all-identity case. */
 static int scale_core(any_frame *target, v2f tp, const any_frame *source, v2f sp, v2f fac, hipStream_t s) {
     t_scale_fused = 0;
+    t_fir_kernel = CVS_FIR_KERNEL_NONE;
     if (fac.x == 1.0f && tp.x == sp.x) return triangle_pass(target, tp.y, source, sp.y, fac.y, 0, s);
     if (fac.y == 1.0f && tp.y == sp.y) return triangle_pass(target, tp.x, source, sp.x, fac.x, 1, s);
 
@@ -725,6 +735,7 @@ static int fir_two_launches(void *tdata, const box2i *tfull, int out_half, const
     if (rc == 0) rc = gather_pass(tdata, tfull, out_half, mid, &mfull, 0, v, 0, rect->min.y, rect->max.y, rect->min.x, rect->max.x, s);
     cvs_pool_free(mid, s);
     if (rc != 0) { cvs_set_error("FIR gather launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
+    t_fir_kernel = CVS_FIR_KERNEL_TWO_PASS;
     return 0;
 }
 
@@ -751,8 +762,8 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
     if ((force & CVS_FIR_PATH_LANES) || !(force & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED))) {
         if (cvk_fir_lanes_supported(&fp)) {
             int rc = cvk_fir_lanes(&fp, cvs_cus(), s);
-            if (rc == 0) return 0;
-            (void)hipGetLastError();                          /* did not launch: the older kernels decide */
+            if (rc == 0) { t_fir_kernel = CVS_FIR_KERNEL_LANES; return 0; }
+            fir_launch_fell_through("k_fir_lanes", rc);       /* did not launch: the older kernels decide */
         }
     }
     const bool can_stream = v->streamable && h->max_taps >= 1 && v->max_active >= 1 && cvk_fir_stream_supported(h->max_taps, v->max_active);
@@ -762,12 +773,13 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
         sp.max_sw = h->wide_foot > 0 ? h->wide_foot : 1;
         sp.max_sh = 0;
         int rc = cvk_fir_stream(&sp, h->max_taps, v->max_active, cvs_cus(), s);
-        if (rc == 0) return 0;
-        (void)hipGetLastError();                              /* did not fit: the tiled kernel decides */
+        if (rc == 0) { t_fir_kernel = CVS_FIR_KERNEL_STREAM; return 0; }
+        fir_launch_fell_through("k_fir_stream", rc);          /* did not fit: the tiled kernel decides */
     }
     if (cvk_fir2d_lds_bytes(&fp) > 150 * 1024 || h->stride > 64 || v->stride > 64) return 1;
     int rc = cvk_fir2d(&fp, s);
     if (rc != 0) { cvs_set_error("fused FIR launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
+    t_fir_kernel = CVS_FIR_KERNEL_TILED;
     return 0;
 }
 
@@ -795,6 +807,7 @@ static int blur_fused_over(void *tdata, const box2i *tfull, int out_half, const 
         memcpy(bp.taps, taps, sizeof(float) * (size_t)ntaps);
         int rc = cvk_blur(&bp, cvs_cus(), s);
         if (rc != 0) { cvs_set_error("blur launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
+        t_fir_kernel = CVS_FIR_KERNEL_WINDOW;
         return 0;
     }
     if (nover > 0) return 1;        /* the gather kernel has no epilogue: the caller goes node by node */
@@ -838,6 +851,7 @@ static int lanczos_fused(void *tdata, const box2i *tfull, int out_half, const vo
             filter_free(&f);
             int rc = cvk_blur(&bp, cvs_cus(), s);
             if (rc != 0) { cvs_set_error("resample launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
+            t_fir_kernel = CVS_FIR_KERNEL_WINDOW;
             return 0;
         }
         filter_free(&f);
@@ -1000,6 +1014,7 @@ CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame
             int rc = cvk_blur_halve(&bp, cvs_cus(), s);
             if (rc != 0) { cvs_set_error("blur + halving launch failed: %s", hipGetErrorString((hipError_t)rc)); box2i_set_empty(&target->current_window); return -1; }
             target->current_window = target->full_window;
+            t_fir_kernel = CVS_FIR_KERNEL_HALVE;
             return 0;
         }
         filter_free(&f);

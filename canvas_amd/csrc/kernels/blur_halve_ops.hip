@@ -29,6 +29,7 @@
 // source pixel at one pixel per lane) times the halo factor of a strip x segment decomposition, which is larger here
 // because every segment re-blurs the resampler's 10 halo rows; the traffic falls from ~400 MB to ~100 MB.
 #include <type_traits>
+#include <atomic>
 #include <utility>
 #include "kernels.h"
 #include "chain_math.hpp"
@@ -225,9 +226,13 @@ int launch(cvk_blur_halve_params bp, int cus, hipStream_t s) {
     constexpr int OUTW = (W - NT1 - NT2 + 1) / 2 + 1;
     const int cols = bp.tx1 - bp.tx0 + 1, rows = bp.ty1 - bp.ty0 + 1;
     const int strips = (cols + OUTW - 1) / OUTW;
-    static int occ[2] = { 0, 0 };
-    int &mine = occ[bp.in_half ? 1 : 0];
-    if (!mine) mine = bp.in_half ? resident_per_cu(k_blur_halve<NT1, NT2, W, true>, W) : resident_per_cu(k_blur_halve<NT1, NT2, W, false>, W);
+    static std::atomic<int> occ[2];                  // (several threads may launch at once: pull-queue workers)
+    std::atomic<int> &cached = occ[bp.in_half ? 1 : 0];
+    int mine = cached.load(std::memory_order_relaxed);
+    if (!mine) {
+        mine = bp.in_half ? resident_per_cu(k_blur_halve<NT1, NT2, W, true>, W) : resident_per_cu(k_blur_halve<NT1, NT2, W, false>, W);
+        cached.store(mine, std::memory_order_relaxed);
+    }
     if (bp.rows_per_wg <= 0) {
         // one wave of resident workgroups; a segment never shorter than its own halo (NT1 + NT2 - 2 source rows = that many / 2 target rows)
         int segs = (mine * cus) / strips;
@@ -265,8 +270,9 @@ extern "C" int cvk_blur_halve_supported(int ntaps1, int ntaps2) {
 extern "C" int cvk_blur_halve(const cvk_blur_halve_params *bp, int cus, void *stream) {
     if (bp->tx1 < bp->tx0 || bp->ty1 < bp->ty0) return 0;
     if (!cvk_blur_halve_supported(bp->ntaps1, bp->ntaps2)) return (int)hipErrorInvalidValue;
-    static int env_w = -1;
-    if (env_w < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_HALVE_WIDTH"); env_w = e ? atoi(e) : 0; }
+    static std::atomic<int> env_cached{ -1 };
+    int env_w = env_cached.load(std::memory_order_relaxed);
+    if (env_w < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_HALVE_WIDTH"); env_w = e ? atoi(e) : 0; env_cached.store(env_w, std::memory_order_relaxed); }
     const int cols = bp->tx1 - bp->tx0 + 1;
     const int width = env_w == 128 || env_w == 256 ? env_w : (cols <= 60 ? 128 : 256);
     return width == 128 ? pick<128>(*bp, cus, (hipStream_t)stream) : pick<256>(*bp, cus, (hipStream_t)stream);

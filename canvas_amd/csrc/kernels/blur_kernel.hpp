@@ -22,6 +22,7 @@
 // them, so no FMA -- takes longer than the memory traffic (4K, 9 taps: 0.045 ms against 0.024 ms of traffic).
 #pragma once
 #include <cstdlib>
+#include <atomic>
 #include <type_traits>
 #include <utility>
 #include "kernels.h"
@@ -231,8 +232,9 @@ template <class K>
 int resident_per_cu(K kernel, int block) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, 0) != hipSuccess || n < 1) n = 1;
-    static int cap = -1;
-    if (cap < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_WGS_PER_CU"); cap = e ? atoi(e) : 0; }
+    static std::atomic<int> cap_cached{ -1 };       // (several threads may launch at once: pull-queue workers)
+    int cap = cap_cached.load(std::memory_order_relaxed);
+    if (cap < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_WGS_PER_CU"); cap = e ? atoi(e) : 0; cap_cached.store(cap, std::memory_order_relaxed); }
     return cap > 0 ? cap : n;
 }
 
@@ -242,11 +244,13 @@ int launch(cvk_blur_params bp, int cus, hipStream_t s) {
     const int cols = bp.tx1 - bp.tx0 + 1, rows = bp.ty1 - bp.ty0 + 1;
     const int strips = (cols + OUTW - 1) / OUTW;
     const bool epi = STEP == 1 && bp.nover > 0;
-    static int occ[3] = { 0, 0, 0 };               // per instance: [epilogue, f16 in, f32 in]
-    int &mine = occ[epi ? 0 : bp.in_half ? 1 : 2];
+    static std::atomic<int> occ[3];                 // per instance: [epilogue, f16 in, f32 in]
+    std::atomic<int> &cached = occ[epi ? 0 : bp.in_half ? 1 : 2];
+    int mine = cached.load(std::memory_order_relaxed);
     if (!mine) {
         if constexpr (STEP == 1) { if (epi) mine = resident_per_cu(k_blur<NT, W, true, true, 1>, W); }
         if (!mine) mine = bp.in_half ? resident_per_cu(k_blur<NT, W, true, false, STEP>, W) : resident_per_cu(k_blur<NT, W, false, false, STEP>, W);
+        cached.store(mine, std::memory_order_relaxed);
     }
     if (bp.rows_per_wg <= 0) {
         int segs = (mine * cus) / strips;

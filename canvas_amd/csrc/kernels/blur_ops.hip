@@ -3,6 +3,7 @@
 // 17-31 taps and for even counts are compiled in blur_long_ops.hip / blur_even_ops.hip (translation units of their own
 // build in parallel).
 #include "blur_kernel.hpp"
+#include <atomic>
 
 extern "C" int cvk_blur_long(const cvk_blur_params *bp, int cus, void *stream);
 extern "C" int cvk_blur_even(const cvk_blur_params *bp, int cus, void *stream);
@@ -52,9 +53,10 @@ extern "C" int cvk_blur(const cvk_blur_params *bp_in, int cus, void *stream) {
     if (bp.nover < 0 || bp.nover > CVK_BLUR_MAX_OVER || (bp.nover > 0 && !(bp.in_half && bp.out_half && bp.step == 1))) return (int)hipErrorInvalidValue;
     const int cols = bp.tx1 - bp.tx0 + 1;
     // strip width: 256 lanes unless the frame is so narrow that 128 wastes fewer lanes
-    static int env_w = -1, env_rows = -1;
-    if (env_w < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_WIDTH"); env_w = e ? atoi(e) : 0; }
-    if (env_rows < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_ROWS"); env_rows = e ? atoi(e) : 0; }
+    static std::atomic<int> env_w_cached{ -1 }, env_rows_cached{ -1 };      // (several threads may launch at once)
+    int env_w = env_w_cached.load(std::memory_order_relaxed), env_rows = env_rows_cached.load(std::memory_order_relaxed);
+    if (env_w < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_WIDTH"); env_w = e ? atoi(e) : 0; env_w_cached.store(env_w, std::memory_order_relaxed); }
+    if (env_rows < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_ROWS"); env_rows = e ? atoi(e) : 0; env_rows_cached.store(env_rows, std::memory_order_relaxed); }
     const int width = (bp.ntaps > 15 || !(bp.ntaps & 1)) ? 256 : env_w ? env_w : (cols <= 128 ? 128 : 256);      // long and even lists: 256-lane instances only
     if (bp.rows_per_wg <= 0 && env_rows > 0) bp.rows_per_wg = env_rows;
     return width == 128 ? pick<128>(&bp, cus, (hipStream_t)stream) : pick<256>(&bp, cus, (hipStream_t)stream);

@@ -18,6 +18,7 @@
 // Bound: HBM.  Algorithmic bytes: colour = 8 r + 8 w per pixel; lookup = 2 r + 2 w per half;
 // chain = 8 * nlayers r + 8 w per output pixel (config 2: 24 B/px).
 #include <cstdlib>
+#include <atomic>
 #include "lut_common.hpp"
 #include "grade.hpp"
 #include "chain_math.hpp"
@@ -121,11 +122,13 @@ extern "C" int cvk_color_matrix(cvk_view dst, cvk_view src, cvk_rect r, const fl
         uint16_t *d = reinterpret_cast<uint16_t *>(dst.data) + (size_t)(r.y0 - dst.fy0) * (size_t)dst.pitch * 4;
         const uint16_t *q = reinterpret_cast<const uint16_t *>(src.data) + (size_t)(r.y0 - src.fy0) * (size_t)src.pitch * 4;
         if (((((uintptr_t)d) | ((uintptr_t)q)) & 15u) == 0) {
-            static int env_block = -1;
+            static std::atomic<int> env_cached{ -1 };       // (several threads may launch at once)
+            int env_block = env_cached.load(std::memory_order_relaxed);
             if (env_block < 0) {
                 const char *e = CVS_DIAG_ENV("CVS_COLOR_BLOCK");
                 env_block = e ? atoi(e) : 0;
                 if (env_block < 64 || env_block > kWG || (env_block & 63)) env_block = 0;
+                env_cached.store(env_block, std::memory_order_relaxed);
             }
             dim3 grid((unsigned)(cus > 0 ? cus : 256)), block(env_block ? env_block : kWG);
             if (pre && post)  hipLaunchKernelGGL((k_color_flat<true, true>), grid, block, 0, s, d, q, n, mat, pre, post);

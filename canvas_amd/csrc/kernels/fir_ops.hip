@@ -12,6 +12,7 @@
 // written; the tap re-reads (2-11 per output) are served by L1/L2 because neighbouring lanes and
 // neighbouring taps touch neighbouring lines.
 #include "kernels.h"
+#include <atomic>
 #include "pixel_math.hpp"
 
 namespace {
@@ -216,13 +217,13 @@ extern "C" int cvk_fir2d(const cvk_fir2d_params *fp, void *stream) {
     if (fp->tx1 < fp->tx0 || fp->ty1 < fp->ty0) return 0;
     const size_t lds = cvk_fir2d_lds_bytes(fp);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-    static bool raised = false;
-    if (!raised) {      // allow more than the default 64 KiB of dynamic LDS
+    static std::atomic<bool> raised{ false };       // (several threads may launch at once; setting the attribute twice is harmless)
+    if (!raised.load(std::memory_order_acquire)) {      // allow more than the default 64 KiB of dynamic LDS
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir2d<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir2d<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir2d<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir2d<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        raised = true;
+        raised.store(true, std::memory_order_release);
     }
     dim3 grid((unsigned)((fp->tx1 - fp->tx0 + kTX) / kTX), (unsigned)((fp->ty1 - fp->ty0 + kTY) / kTY));
     const int most = fp->h.stride > fp->v.stride ? fp->h.stride : fp->v.stride;

@@ -22,6 +22,7 @@
 // Arithmetic: every sum starts at 0.0f, products and additions separately rounded, ascending order -- bit for bit the
 // two gather passes.  Bound: HBM.  Algorithmic bytes: source pixel once + target pixel once.
 #include <climits>
+#include <atomic>
 #include "kernels.h"
 #include "chain_math.hpp"
 
@@ -198,8 +199,8 @@ int launch(const cvk_fir2d_params &fp, int cus, hipStream_t s) {
     const int strips = (cols + kW - 1) / kW;
     const int lds_px = fp.max_sw;                                   // widest strip footprint, from the host
     auto lds_bytes = [&](int r) { return (size_t)2 * (lds_px + 1) * sizeof(float4) + (size_t)r * fp.v.stride * sizeof(float) + (size_t)r * 2 * sizeof(int); };
-    static bool raised = false;
-    if (!raised) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_stream<MAXT, NACC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised = true; }
+    static std::atomic<bool> raised{ false };       // (several threads may launch at once; setting the attribute twice is harmless)
+    if (!raised.load(std::memory_order_acquire)) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fir_stream<MAXT, NACC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); raised.store(true, std::memory_order_release); }
     // rows per workgroup: about one wave of resident workgroups over the whole frame (as k_blur), at least twice the
     // number of rows a source row feeds, at most what the tables of a segment leave room for
     int per_cu = 0;

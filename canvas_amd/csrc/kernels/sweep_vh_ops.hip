@@ -3,17 +3,27 @@
 // video_scale_bilinear_f32 (video_scale.c:231-286) runs the pass with the smaller factor first and the vertical one when
 // the factors are equal (:252) -- the usual case -- each pass adding its products to a zero-filled f32 frame in ascending
 // source order (:63-122 vertical, :161-226 horizontal).  sweep_ops.hip has the other order (rows filtered horizontally, then
-// accumulated); the order of the two roundings differs, so this is a kernel of its own, on the same tables and records:
-//   * one wave per workgroup owns 32 target columns (one tile of the horizontal table) and the source columns under them
-//     (h.foot: at most 128); a lane owns channel pairs of source pixels: unit u = lane + 64 q is pair (u & 1) of pixel u / 2;
-//   * V: per source row one coalesced load per unit (straight from memory into the multiply, no LDS); every accumulator
-//     slot of the unit takes the row with its weight from the row's record (0 for the slots that do not: cvk_fir_axis.rec,
-//     see sweep_ops.hip), so each vertical sum adds its taps in ascending source order;
-//   * a line that ends on this row: its sums leave their slot through the GPR index, go to ONE LDS row (the wave's own,
-//     LDS runs a wave's accesses in order: no barrier), and each lane gathers the horizontal taps of its target column and
-//     pair from there -- sum from 0.0f in ascending tap order -- and stores.
-// LDS is touched once per TARGET line, not per source row.  Padded horizontal taps read the zero pixel behind the row.
-// Bound: VALU issue / latency at 2-4 waves per SIMD.  Algorithmic bytes: source pixel once + target pixel once.
+// accumulated); the order of the two roundings differs, so this is a kernel of its own, on the same tables.
+//
+// Third form of this kernel.  The second kept one accumulator per target line in flight and walked the SOURCE rows with a
+// record per row (which slots take the row, which lines end on it): 1.7 scalar instructions and 0.4 branches per vector
+// instruction, VALU busy 6 % of the time (profiles/r02).  This one walks the TARGET lines and gathers, which is what the
+// table says literally:
+//   * one wave per workgroup owns 64 target columns (lane = column) and the source columns under them (two tiles of the
+//     horizontal table's footprint list, at most NQ * 64 pixels: lane + 64 q is source pixel q of the lane);
+//   * the source rows a line can reach live WIDENED in a register window win[0 .. W-1] (W = longest vertical list): a line
+//     whose first tap is source row s needs win[k] = row s + k.  First taps never decrease down the table
+//     (cvk_fir_axis.streamable), so the window only ever moves forward: shift by one, take the oldest row of a short ring
+//     of rows requested ahead (pf[0 .. 2], storage format), request the next into the same registers.  Plain loads:
+//     hipcc counts them (a counted vmcnt per row), tools/check_asm_loads.py checks them like every other load;
+//   * V: mid = 0 + win[0] w0 + win[1] w1 ... in ascending source order, exactly the line's n taps (a chain per count: no
+//     padded tap multiplies a row the line does not take, so Inf / NaN spread only where the reference spreads them);
+//     weights, count and first row are scalar loads, requested a line ahead;
+//   * the line's mid row goes to ONE LDS row (the wave's own: LDS runs a wave's accesses in order, no barrier); each lane
+//     gathers the horizontal taps of its column from it -- sum from 0.0f in ascending tap order, padded taps read a zero
+//     pixel with weight 0 -- and stores its pixel.
+// No accumulator slots, no per-row records, no register indexing, no hand-written waits; two uniform branches per line
+// (window moves? which tap count?).  Algorithmic bytes: source pixel once + target pixel once.
 #include <atomic>
 #include <climits>
 #include "kernels.h"
@@ -24,232 +34,200 @@ namespace {
 
 using cvs::f32x2;
 
-constexpr int kCols = 32;        // target columns per workgroup
-constexpr int kLanes = 64;       // one wave
-constexpr int kPFD = 4;          // source rows in flight
-constexpr int kRowPx = 128;      // source pixels under a strip at most (NQ <= 4 units per lane)
-constexpr int kRowFl = (kRowPx + 1) * 4;
+constexpr int kCols = 64;        // target columns per workgroup = lanes of its one wave
+constexpr int kLanes = 64;
+constexpr int kPF = 3;           // source rows requested ahead of the window
+static_assert(kCols == 2 * CVK_FIR2D_TILE_X, "a strip is two tiles of the footprint table");
 
-template <bool INH> struct Unit;
-template <> struct Unit<true> { uint32_t v; };                                           // two halfs
-typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
-template <> struct Unit<false> { u32x2v v; };                                            // two floats
-__device__ __forceinline__ void asm_ld(Unit<true> &dst, const void *row, uint32_t voff) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst.v) : "v"(voff), "s"(row));
+struct Px { f32x2 lo, hi; };                                             // r,g | b,a
+template <bool INH> struct Raw;
+template <> struct Raw<true> { uint2 v; };                               // four halfs
+template <> struct Raw<false> { float4 v; };
+__device__ __forceinline__ Px widen(const Raw<true> &r) {
+    return { f32x2{ cvs::h2f(r.v.x & 0xFFFFu), cvs::h2f(r.v.x >> 16) }, f32x2{ cvs::h2f(r.v.y & 0xFFFFu), cvs::h2f(r.v.y >> 16) } };
 }
-__device__ __forceinline__ void asm_ld(Unit<false> &dst, const void *row, uint32_t voff) {
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst.v) : "v"(voff), "s"(row));
-}
-__device__ __forceinline__ f32x2 widen(const Unit<true> &u) { return f32x2{ cvs::h2f(u.v & 0xFFFFu), cvs::h2f(u.v >> 16) }; }
-__device__ __forceinline__ f32x2 widen(const Unit<false> &u) { return f32x2{ __uint_as_float(u.v.x), __uint_as_float(u.v.y) }; }
+__device__ __forceinline__ Px widen(const Raw<false> &r) { return { f32x2{ r.v.x, r.v.y }, f32x2{ r.v.z, r.v.w } }; }
 
-template <int MAXT, int NACC, int NQ, bool INH>
+// the vertical sum of one line with exactly N taps (video_scale.c:82-85: t += s * coeff, from 0, ascending)
+template <int N, int W>
+__device__ __forceinline__ Px vsum(const Px (&win)[W], const float (&w)[W]) {
+    Px t = { f32x2{ 0.0f, 0.0f }, f32x2{ 0.0f, 0.0f } };
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const f32x2 wk = { w[k], w[k] };
+        const f32x2 plo = win[k].lo * wk, phi = win[k].hi * wk;
+        t.lo = t.lo + plo;
+        t.hi = t.hi + phi;
+    }
+    return t;
+}
+
+template <int W, int MAXTH, int NQ, bool INH>
 __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows_per_wg, int line0) {
-    static_assert(NQ >= 1 && NQ <= 4 && NQ * kLanes <= 2 * kRowPx && (NACC == 8 || NACC == 16), "units per lane; one register vector of slots per unit");
-    __shared__ __align__(16) float lds[kRowFl];     // the vertical sums of one target line, a zero pixel behind them
-    __shared__ int seg[4];                          // first / last source row of the segment, "a line has no taps", first line with taps
-    const int lane = threadIdx.x, pr = lane & 1;
-    const int c0 = fp.tx0 + (int)blockIdx.x * kCols;
-    const int tcol = c0 + (lane >> 1);
+    static_assert(W >= 1 && W <= 8 && MAXTH >= 1 && MAXTH <= 8 && NQ >= 1 && NQ <= 4, "instances");
+    constexpr int kZero = NQ * kLanes;                                   // the zero pixel behind the mid row
+    __shared__ float4 mid[kZero + 1];
+    const int lane = threadIdx.x;
+    const int tcol = fp.tx0 + (int)blockIdx.x * kCols + lane;
     const bool col_live = tcol <= fp.tx1;
     const int nlines = fp.ty1 - fp.ty0 + 1;
     // target lines, counted from the vertical table's first (fp.ty0); the launch covers lines line0 .. nlines - 1
     const int ia = line0 + (int)blockIdx.y * rows_per_wg, ib = min(ia + rows_per_wg - 1, nlines - 1);
+    const konst vn = as_konst(fp.v.ntaps), vs = as_konst(fp.v.src), vw = as_konst(fp.v.taps), foot = as_konst(fp.h.foot);
     const int vstride = fp.v.stride, hstride = fp.h.stride;
 
-    if (lane == 0) { seg[0] = INT_MAX; seg[1] = INT_MIN; seg[2] = 0; seg[3] = INT_MAX; }
-    __syncthreads();
-    for (int i = ia + lane; i <= ib; i += kLanes) {
-        const int n = min(fp.v.ntaps[i], vstride);
-        if (n > 0) {
-            const int a = fp.v.src[(size_t)i * vstride];
-            atomicMin(&seg[0], a);
-            atomicMax(&seg[1], a + n - 1);
-            atomicMin(&seg[3], i);
-        } else seg[2] = 1;
+    // source columns under the strip: its two tiles of the footprint table (first > last: the tile touches nothing)
+    const int ntiles = (fp.tx1 - fp.tx0) / CVK_FIR2D_TILE_X + 1, t0 = 2 * (int)blockIdx.x;
+    int sx_lo = (int)foot[2 * t0], sx_hi = (int)foot[2 * t0 + 1];
+    if (t0 + 1 < ntiles) {
+        const int lo1 = (int)foot[2 * t0 + 2], hi1 = (int)foot[2 * t0 + 3];
+        if (hi1 >= lo1) {
+            if (sx_hi < sx_lo) { sx_lo = lo1; sx_hi = hi1; }
+            else { sx_lo = min(sx_lo, lo1); sx_hi = max(sx_hi, hi1); }
+        }
     }
-    static_assert(kCols == CVK_FIR2D_TILE_X, "a strip is one tile of the footprint table");
-    const konst foot = as_konst(fp.h.foot);
-    int sx_lo = (int)foot[2 * blockIdx.x], sx_hi = (int)foot[2 * blockIdx.x + 1];
-    if (sx_hi < sx_lo) sx_lo = sx_hi = fp.source.fx0;                         // no column of the strip has taps: any pixel will do
-    sx_lo = __builtin_amdgcn_readfirstlane(sx_lo);
-    sx_hi = __builtin_amdgcn_readfirstlane(sx_hi);
-    const int nu = 2 * min(sx_hi - sx_lo + 1, NQ * kLanes / 2);               // units under the strip (the host chose NQ to cover them)
+    if (sx_hi < sx_lo) sx_lo = sx_hi = fp.source.fx0;                    // no column of the strip has taps: any pixel will do
+    const int npx = min(sx_hi - sx_lo + 1, NQ * kLanes);                 // (the host chose NQ to cover them)
+
+    // the horizontal taps of this lane's column: offsets into the mid row, weights; padded taps -> the zero pixel, weight 0
     const int hline = tcol - fp.tx0;
-    const int hn = col_live ? min(fp.h.ntaps[hline], MAXT) : 0;
-    int aoff[MAXT];
-    float wt[MAXT];
+    const int hn = col_live ? min(fp.h.ntaps[hline], MAXTH) : 0;
+    int aoff[MAXTH];
+    float wt[MAXTH];
 #pragma unroll
-    for (int k = 0; k < MAXT; k++) {
+    for (int k = 0; k < MAXTH; k++) {
         const bool live = k < hn;
-        aoff[k] = (live ? fp.h.src[(size_t)hline * hstride + k] - sx_lo : kRowPx) * 4 + 2 * pr;
+        const int a = live ? fp.h.src[(size_t)hline * hstride + k] - sx_lo : kZero;
+        aoff[k] = min(max(a, 0), kZero);
         wt[k] = live ? fp.h.taps[(size_t)hline * hstride + k] : 0.0f;
     }
-    if (lane < 4) lds[kRowPx * 4 + lane] = 0.0f;
-    __syncthreads();
-    const int s_lo = __builtin_amdgcn_readfirstlane(seg[0]), s_hi = __builtin_amdgcn_readfirstlane(seg[1]);
-    const bool some_empty = __builtin_amdgcn_readfirstlane(seg[2]) != 0;
+    if (lane == 0) mid[kZero] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
     const size_t tpx = fp.out_half ? 8 : 16;
-    char *tbase = reinterpret_cast<char *>(fp.target.data) + ((size_t)(tcol - fp.target.fx0)) * tpx + (size_t)pr * (tpx / 2);
+    char *optr = reinterpret_cast<char *>(fp.target.data) + ((size_t)(tcol - fp.target.fx0)) * tpx
+               + (size_t)(fp.ty0 + ia - fp.target.fy0) * (size_t)fp.target.pitch * tpx;
     const size_t trow = (size_t)fp.target.pitch * tpx;
     const bool out_half = fp.out_half != 0;
-    auto store_at = [&](char *o, f32x2 v) __attribute__((always_inline)) {
-        if (!col_live) return;
-        if (out_half) *reinterpret_cast<uint32_t *>(o) = cvs::f2h_rz2(v.x, v.y);
-        else *reinterpret_cast<float2 *>(o) = make_float2(v.x, v.y);
-    };
-    if (some_empty) {                               // lines without taps are zeros (frame edges; rare)
-        for (int i = ia; i <= ib; i++)
-            if (fp.v.ntaps[i] <= 0) store_at(tbase + (size_t)(fp.ty0 + i - fp.target.fy0) * trow, f32x2{ 0.0f, 0.0f });
+
+    // first and last source row the segment's lines reach (first taps and last taps never decrease down the table)
+    int s_lo = INT_MAX, s_hi = INT_MIN;
+    for (int i = ia; i <= ib; i++) {                                     // uniform, scalar loads; segments are short
+        const int n = (int)vn[i];
+        if (n > 0) { s_lo = (int)vs[(size_t)i * vstride]; break; }
     }
-    if (s_lo > s_hi) return;                        // uniform
-    // the lines with taps are one run and end in ascending order: the stores go to consecutive target rows
-    char *optr = tbase + (size_t)(fp.ty0 + __builtin_amdgcn_readfirstlane(seg[3]) - fp.target.fy0) * trow;
+    for (int i = ib; i >= ia; i--) {
+        const int n = (int)vn[i];
+        if (n > 0) { s_hi = (int)vs[(size_t)i * vstride] + min(n, W) - 1; break; }
+    }
+    const bool any_taps = s_lo <= s_hi;                                  // (uniform) else every line of the segment is zeros
 
-    typedef float accvec __attribute__((ext_vector_type(2 * NACC)));
-    // one register vector per unit, as NAMED variables: an array of three or more is merged by hipcc into one vector wider
-    // than the widest register tuple, and lands in scratch
-    accvec acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;
-#define CVK_ACC(q) ((q) == 0 ? acc0 : (q) == 1 ? acc1 : (q) == 2 ? acc2 : acc3)      /* q: a constant after unrolling */
-
-    // source units lane + 64 q of the strip's footprint (clamped to its last unit: every load unconditional), fetched a group
-    // of four rows ahead by asm loads and a hand-written vmcnt(0) (see sweep_ops.hip)
-    constexpr int UB = INH ? 4 : 8;
+    // rows are requested through a uniform row pointer + one 32-bit lane offset per unit (clamped: every load unconditional)
+    constexpr int PXB = INH ? 8 : 16;
     uint32_t uoff[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; q++) uoff[q] = (uint32_t)(min(lane + q * kLanes, nu - 1) * UB);
-    const uint32_t rowb = __builtin_amdgcn_readfirstlane((uint32_t)fp.source.pitch * (2 * UB));
-    const char *rp;
-    {
-        const uint64_t a = reinterpret_cast<uint64_t>(fp.source.data) + (uint64_t)(sx_lo - fp.source.fx0) * (2 * UB) + (uint64_t)(s_lo - fp.source.fy0) * (uint64_t)rowb;
-        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-        rp = reinterpret_cast<const char *>(((uint64_t)hi << 32) | lo);
-    }
-    int s_next = s_lo;
-    typedef Unit<INH> Group[kPFD][NQ];
-    auto issue_group = [&](Group &g) __attribute__((always_inline)) {
+    for (int q = 0; q < NQ; q++) uoff[q] = (uint32_t)(min(lane + q * kLanes, npx - 1) * PXB);
+    const uint32_t rowb = (uint32_t)fp.source.pitch * PXB;
+    const char *rp = reinterpret_cast<const char *>(fp.source.data) + (size_t)(sx_lo - fp.source.fx0) * PXB
+                   + (size_t)((any_taps ? s_lo : fp.source.fy0) - fp.source.fy0) * (size_t)rowb;
+    int s_next = any_taps ? s_lo : 0;                                    // the row `rp` points at
+    const int s_last = any_taps ? s_hi : 0;
+
+    Raw<INH> pf[kPF][NQ];
+    Px win[W][NQ];
+    auto request = [&](Raw<INH> (&dst)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int d = 0; d < kPFD; d++) {
-#pragma unroll
-            for (int q = 0; q < NQ; q++) asm_ld(g[d][q], rp, uoff[q]);
-            const bool more = s_next < s_hi;                       // uniform; past the segment's last row the pointer stays
-            rp += more ? rowb : 0u;
-            s_next += more ? 1 : 0;
-        }
+        for (int q = 0; q < NQ; q++) dst[q].v = *reinterpret_cast<const decltype(dst[q].v) *>(rp + uoff[q]);
+        const bool more = s_next < s_last;                               // uniform; past the segment's last row the pointer stays
+        rp += more ? rowb : 0u;
+        s_next += more ? 1 : 0;
     };
-    auto wait_group = [&](Group &g) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 #pragma unroll
-        for (int d = 0; d < kPFD; d++) {
+    for (int d = 0; d < kPF; d++) request(pf[d]);
 #pragma unroll
-            for (int q = 0; q < NQ; q++) asm volatile("" : "+v"(g[d][q].v));
+    for (int j = 0; j < W; j++) {
+#pragma unroll
+        for (int q = 0; q < NQ; q++) win[j][q] = Px{ f32x2{ 0.0f, 0.0f }, f32x2{ 0.0f, 0.0f } };
+    }
+    int win0 = s_lo - W;                                                 // source row of win[0] (rows before s_lo: never a tap)
+    // The queue of requested rows is a ring whose position is a RUNTIME phase with one copy of the step per phase: moving
+    // a requested row from one register to another would have to wait for it to land (that was the first form: vmcnt(0)
+    // in front of every request), while a phase only ever names the registers the row was requested into.
+    int phase = 0;                                                       // pf[phase] is the oldest request
+    auto advance_from = [&](Raw<INH> (&oldest)[NQ]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j + 1 < W; j++) {
+#pragma unroll
+            for (int q = 0; q < NQ; q++) win[j][q] = win[j + 1][q];
         }
+#pragma unroll
+        for (int q = 0; q < NQ; q++) win[W - 1][q] = widen(oldest[q]);
+        request(oldest);
+        win0++;
+    };
+    static_assert(kPF == 3, "three phases written out");
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (phase == 0) { advance_from(pf[0]); phase = 1; }
+        else if (phase == 1) { advance_from(pf[1]); phase = 2; }
+        else { advance_from(pf[2]); phase = 0; }
     };
 
-    struct Rec { uint32_t ends; int first_end; f32x2 w[NACC]; };
-    konst rec_next = as_konst(fp.v.rec) + (ptrdiff_t)(s_lo - fp.v.rec_s0) * (2 * NACC + 4);
-    auto load_rec = [&]() __attribute__((always_inline)) {
-        Rec r;
-        r.ends = rec_next[1]; r.first_end = (int)rec_next[2];
+    // the line's scalars, requested a line ahead
+    struct Line { int n, first; float w[W]; };
+    auto load_line = [&](int i) __attribute__((always_inline)) {
+        Line l;
+        const int ii = min(i, ib);
+        l.n = min((int)vn[ii], W);
+        l.first = (int)vs[(size_t)ii * vstride];
 #pragma unroll
-        for (int j = 0; j < NACC; j++) r.w[j] = f32x2{ __uint_as_float(rec_next[4 + 2 * j]), __uint_as_float(rec_next[5 + 2 * j]) };
-        rec_next += 2 * NACC + 4;
-        return r;
+        for (int k = 0; k < W; k++) l.w[k] = k < vstride ? __uint_as_float(vw[(size_t)ii * vstride + k]) : 0.0f;
+        return l;
     };
-    // one source row: every slot of every unit takes it; then the lines that end on it go through the horizontal pass
-    auto step = [&](const Unit<INH> (&px)[NQ], const Rec &rec, Rec &rec_after) __attribute__((always_inline)) {
-        f32x2 x[NQ];
-        bool odd = false;
+    Line cur = load_line(ia);
+    for (int i = ia; i <= ib; i++) {
+        const Line nxt = load_line(i + 1);
+        Px m[NQ];
+        if (cur.n > 0) {
+            while (win0 < cur.first) advance();                          // uniform
+            // exactly the line's taps: the usual count first
+#define CVK_VSUM(N) { _Pragma("unroll") for (int q = 0; q < NQ; q++) { Px col[W]; _Pragma("unroll") for (int j = 0; j < W; j++) col[j] = win[j][q]; m[q] = vsum<N, W>(col, cur.w); } }
+            if (cur.n == W) CVK_VSUM(W)
+            else if (W > 1 && cur.n == W - 1) CVK_VSUM((W > 1 ? W - 1 : 1))
+            else if (W > 2 && cur.n == W - 2) CVK_VSUM((W > 2 ? W - 2 : 1))
+            else if (W > 3 && cur.n == W - 3) CVK_VSUM((W > 3 ? W - 3 : 1))
+            else if (W > 4 && cur.n == W - 4) CVK_VSUM((W > 4 ? W - 4 : 1))
+            else if (W > 5 && cur.n == W - 5) CVK_VSUM((W > 5 ? W - 5 : 1))
+            else if (W > 6 && cur.n == W - 6) CVK_VSUM((W > 6 ? W - 6 : 1))
+            else CVK_VSUM(1)
+#undef CVK_VSUM
+        } else {
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            x[q] = widen(px[q]);
-            odd = odd || __builtin_amdgcn_class(x[q].x, 0x207) || __builtin_amdgcn_class(x[q].y, 0x207);     // NaN, -Inf, +Inf
+            for (int q = 0; q < NQ; q++) m[q] = Px{ f32x2{ 0.0f, 0.0f }, f32x2{ 0.0f, 0.0f } };     // a line without taps is zeros
         }
-        rec_after = load_rec();
-        // (weight 0 for the slots that do not take the row; Inf and NaN pixels through a pass of their own: sweep_ops.hip)
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
-            const bool mine = __builtin_amdgcn_class(x[q].x, 0x207) || __builtin_amdgcn_class(x[q].y, 0x207);
-            const f32x2 xp = mine ? f32x2{ 0.0f, 0.0f } : x[q];
-            // all products, then all sums: a packed add right behind the packed multiply it depends on costs a hazard slot
-            // (an s_nop per slot, and this kernel is short of scalar issue, not of registers)
-            f32x2 p[NACC];
+        for (int q = 0; q < NQ; q++) mid[lane + q * kLanes] = make_float4(m[q].lo.x, m[q].lo.y, m[q].hi.x, m[q].hi.y);
+        __builtin_amdgcn_wave_barrier();                                 // (compiler fence; the hardware keeps a wave's LDS accesses in order)
+        float4 t[MAXTH];
 #pragma unroll
-            for (int j = 0; j < NACC; j++) p[j] = xp * rec.w[j];
-            __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < MAXTH; k++) t[k] = mid[aoff[k]];
+        f32x2 hlo = { 0.0f, 0.0f }, hhi = { 0.0f, 0.0f };
 #pragma unroll
-            for (int j = 0; j < NACC; j++) {
-                const f32x2 t = f32x2{ CVK_ACC(q)[2 * j], CVK_ACC(q)[2 * j + 1] } + p[j];
-                CVK_ACC(q)[2 * j] = t.x; CVK_ACC(q)[2 * j + 1] = t.y;
-            }
+        for (int k = 0; k < MAXTH; k++) {
+            const f32x2 wk = { wt[k], wt[k] };
+            const f32x2 plo = f32x2{ t[k].x, t[k].y } * wk, phi = f32x2{ t[k].z, t[k].w } * wk;
+            hlo = hlo + plo;
+            hhi = hhi + phi;
         }
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0, 0)) {
-            cvs::rare_path();
-#pragma unroll
-            for (int q = 0; q < NQ; q++) {
-                const bool mine = __builtin_amdgcn_class(x[q].x, 0x207) || __builtin_amdgcn_class(x[q].y, 0x207);
-                const f32x2 xo = mine ? x[q] : f32x2{ 0.0f, 0.0f };
-#pragma unroll
-                for (int j = 0; j < NACC; j++) {
-                    const f32x2 t = f32x2{ CVK_ACC(q)[2 * j], CVK_ACC(q)[2 * j + 1] } + f32x2{ mul_zero_wins(xo.x, rec.w[j].x), mul_zero_wins(xo.y, rec.w[j].x) };
-                    CVK_ACC(q)[2 * j] = t.x; CVK_ACC(q)[2 * j + 1] = t.y;
-                }
-            }
+        __builtin_amdgcn_wave_barrier();
+        if (col_live) {
+            if (out_half) *reinterpret_cast<uint2 *>(optr) = make_uint2(cvs::f2h_rz2(hlo.x, hlo.y), cvs::f2h_rz2(hhi.x, hhi.y));
+            else *reinterpret_cast<float4 *>(optr) = make_float4(hlo.x, hlo.y, hhi.x, hhi.y);
         }
-        if (rec.ends) {                                            // uniform
-            int n_end = __builtin_popcount(rec.ends);
-            int i = rec.first_end;
-            do {
-                const int e = 2 * (i & (NACC - 1));
-#pragma unroll
-                for (int q = 0; q < NQ; q++) {
-                    const f32x2 v = { CVK_ACC(q)[e], CVK_ACC(q)[e + 1] };
-                    CVK_ACC(q)[e] = 0.0f; CVK_ACC(q)[e + 1] = 0.0f;
-                    *reinterpret_cast<f32x2 *>(lds + 2 * (lane + q * kLanes)) = v;
-                }
-                __builtin_amdgcn_wave_barrier();                   // (compiler fence; the hardware keeps a wave's LDS accesses in order)
-                if (i >= ia && i <= ib) {                          // uniform
-                    f32x2 t[MAXT], h = { 0.0f, 0.0f };
-#pragma unroll
-                    for (int k = 0; k < MAXT; k++) t[k] = *reinterpret_cast<const f32x2 *>(lds + aoff[k]);
-#pragma unroll
-                    for (int k = 0; k < MAXT; k++) t[k] = t[k] * wt[k];
-#pragma unroll
-                    for (int k = 0; k < MAXT; k++) h = h + t[k];
-                    store_at(optr, h);
-                    optr += trow;
-                }
-                __builtin_amdgcn_wave_barrier();
-                i++;
-            } while (--n_end);
-        }
-    };
-    static_assert(kPFD == 4, "four steps written out: the records alternate");
-    Rec ra = load_rec(), rb;
-    int s = s_lo;
-    Group ga, gb;
-    auto four_rows = [&](Group &cur, Group &nxt) __attribute__((always_inline)) -> bool {
-        step(cur[0], ra, rb);
-        if (++s > s_hi) return false;
-        step(cur[1], rb, ra);
-        if (++s > s_hi) return false;
-        step(cur[2], ra, rb);
-        if (++s > s_hi) return false;
-        wait_group(nxt);
-        step(cur[3], rb, ra);
-        issue_group(cur);
-        return ++s <= s_hi;
-    };
-    issue_group(ga);
-    wait_group(ga);
-    issue_group(gb);
-    while (four_rows(ga, gb) && four_rows(gb, ga)) {}
-    asm volatile("s_waitcnt vmcnt(0)" : : : "memory");             // nothing of this wave is in flight when it ends
-#undef CVK_ACC
+        optr += trow;
+        cur = nxt;
+    }
 }
 
-template <int MAXT, int NACC, int NQ, bool INH>
+template <int W, int MAXTH, int NQ, bool INH>
 int launch(const cvk_fir2d_params &fp, int line0, int cus, hipStream_t s) {
     const int cols = fp.tx1 - fp.tx0 + 1, rows = fp.ty1 - fp.ty0 + 1 - line0;
     const int strips = (cols + kCols - 1) / kCols;
@@ -257,45 +235,46 @@ int launch(const cvk_fir2d_params &fp, int line0, int cus, hipStream_t s) {
     int per_cu = cached.load(std::memory_order_relaxed);
     if (!per_cu) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fir_vh<MAXT, NACC, NQ, INH>, kLanes, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fir_vh<W, MAXTH, NQ, INH>, kLanes, 0) != hipSuccess || n < 1) n = 1;
         per_cu = n;
         cached.store(n, std::memory_order_relaxed);
     }
-    // one round of resident workgroups over the frame; a segment re-reads (but does not re-filter horizontally) the source
-    // rows its first lines reach back to
+    // one round of resident workgroups over the frame; a segment re-reads the W - 1 source rows its first line reaches back to
     int segs = (per_cu * (cus > 0 ? cus : 256)) / strips;
     if (segs < 1) segs = 1;
     int r = (rows + segs - 1) / segs;
-    if (r < 3 * fp.v.max_active) r = 3 * fp.v.max_active;
+    if (r < 8) r = 8;
     if (r > 256) r = 256;
     if (r > rows) r = rows;
     dim3 grid((unsigned)strips, (unsigned)((rows + r - 1) / r));
-    hipLaunchKernelGGL((k_fir_vh<MAXT, NACC, NQ, INH>), grid, dim3(kLanes), 0, s, fp, r, line0);
+    hipLaunchKernelGGL((k_fir_vh<W, MAXTH, NQ, INH>), grid, dim3(kLanes), 0, s, fp, r, line0);
     return (int)hipGetLastError();
 }
 
-// (longest horizontal list, accumulator slots, units a lane holds per row); a call gets the first that covers it
-struct Instance { int maxt, nacc, nq; int (*f16)(const cvk_fir2d_params &, int, int, hipStream_t); int (*f32)(const cvk_fir2d_params &, int, int, hipStream_t); };
-#define CVK_VH_INSTANCE(T, A, Q) { T, A, Q, launch<T, A, Q, true>, launch<T, A, Q, false> }
+// (longest vertical list = window rows, longest horizontal list, source pixels a lane holds per row); a call gets the first that covers it
+struct Instance { int w, maxth, nq; int (*f16)(const cvk_fir2d_params &, int, int, hipStream_t); int (*f32)(const cvk_fir2d_params &, int, int, hipStream_t); };
+#define CVK_VH_INSTANCE(W, T, Q) { W, T, Q, launch<W, T, Q, true>, launch<W, T, Q, false> }
 const Instance kInstances[] = {
-    CVK_VH_INSTANCE(4, 8, 1),  CVK_VH_INSTANCE(4, 16, 1),          // the triangle scaler enlarging up to 2x (and 1 : 1 shifts)
-    CVK_VH_INSTANCE(8, 8, 2),  CVK_VH_INSTANCE(8, 16, 1),          // reducing down to ~0.55x; enlarging up to 4x
-    CVK_VH_INSTANCE(4, 8, 3),  CVK_VH_INSTANCE(8, 8, 3),           // down to ~0.4x (0.5x: three taps, 67 source columns)
-    CVK_VH_INSTANCE(8, 8, 4),                                      // down to ~0.3x; below, the two launches
+    CVK_VH_INSTANCE(2, 2, 1), CVK_VH_INSTANCE(3, 4, 1),            // the triangle scaler enlarging (and 1 : 1 shifts)
+    CVK_VH_INSTANCE(3, 4, 2), CVK_VH_INSTANCE(4, 4, 2),            // reducing down to ~0.6x
+    CVK_VH_INSTANCE(3, 4, 3), CVK_VH_INSTANCE(4, 4, 3),            // 0.5x: three taps, 130 source columns under 64
+    CVK_VH_INSTANCE(6, 8, 3), CVK_VH_INSTANCE(8, 8, 4),            // down to ~0.3x; below, the two launches
 };
 
+// source pixels under a 64-column strip: at most two tiles' footprints
+int strip_foot(const cvk_fir2d_params *fp) { return 2 * fp->max_sw; }
+
 const Instance *pick(const cvk_fir2d_params *fp) {
-    const int nq = (2 * fp->max_sw + kLanes - 1) / kLanes;
+    const int nq = (strip_foot(fp) + kLanes - 1) / kLanes;
     for (const Instance &in : kInstances)
-        if (fp->h.max_taps <= in.maxt && fp->v.nacc == in.nacc && nq <= in.nq) return &in;
+        if (fp->v.max_taps <= in.w && fp->h.max_taps <= in.maxth && nq <= in.nq) return &in;
     return NULL;
 }
 
 }  // namespace
 
 extern "C" int cvk_fir_vh_supported(const cvk_fir2d_params *fp) {
-    return fp->v.rec != NULL && !fp->v.rec_zero_weight && (fp->v.nacc == 8 || fp->v.nacc == 16) &&
-           fp->v.max_active >= 1 && fp->v.max_active <= fp->v.nacc && fp->h.max_taps >= 1 && fp->max_sw >= 1 && fp->max_sw <= kRowPx && pick(fp) != NULL;
+    return fp->v.streamable && fp->v.max_taps >= 1 && fp->h.max_taps >= 1 && fp->max_sw >= 1 && pick(fp) != NULL;
 }
 
 // fp->ty0 is the vertical table's first line; lines fp->ty0 + line0 .. fp->ty1 are produced

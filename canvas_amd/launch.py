@@ -14,6 +14,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 
@@ -54,12 +55,19 @@ def spawn_ranks(n, argv, env=None, timeout=None, relay=True):
     base = dict(os.environ if env is None else env)
     base.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(n),
                 HSA_ENABLE_IPC_MODE_LEGACY=base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    procs = []
+    procs, chunks, readers = [], [[] for _ in range(n)], []
+
+    def drain(pipe, into):                              # a rank may print more than a pipe holds (64 KiB): read as it writes
+        for line in pipe:
+            into.append(line)
+        pipe.close()
+
     for r in range(n):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen(list(argv), env=e, stdout=subprocess.PIPE, stderr=None, text=True))
+        readers.append(threading.Thread(target=drain, args=(procs[r].stdout, chunks[r]), daemon=True))
+        readers[r].start()
     deadline = None if timeout is None else time.monotonic() + timeout
-    outs = [None] * n
     worst = 0
     pending = set(range(n))
     while pending:
@@ -67,7 +75,6 @@ def spawn_ranks(n, argv, env=None, timeout=None, relay=True):
             rc = procs[r].poll()
             if rc is None:
                 continue
-            outs[r] = procs[r].stdout.read()
             pending.discard(r)
             if rc != 0:
                 worst = worst or rc
@@ -75,11 +82,15 @@ def spawn_ranks(n, argv, env=None, timeout=None, relay=True):
                     procs[q].terminate()
         if pending:
             if deadline is not None and time.monotonic() > deadline:
+                sys.stderr.write("ranks %s still running after %.0f s: killed\n" % (sorted(pending), timeout))
                 for q in pending:
                     procs[q].kill()
                 worst = worst or 124
                 deadline = None
             time.sleep(0.05)
+    for t in readers:
+        t.join(10)
+    outs = ["".join(c) for c in chunks]
     if relay:
         for r in range(n):
             if outs[r]:
@@ -88,9 +99,10 @@ def spawn_ranks(n, argv, env=None, timeout=None, relay=True):
     return worst, outs
 
 
-def ensure_ranks(gpus, argv=None, need_devices=True):
+def ensure_ranks(gpus, argv=None, need_devices=True, timeout=3000):
     """Call first thing in main(), before any GPU call.  Returns normally inside a rank (or when one rank is
-    all that was asked for); otherwise spawns the ranks, waits, and exits the process."""
+    all that was asked for); otherwise spawns the ranks, waits (at most `timeout` seconds: a hung rendezvous ends with
+    a message and exit code 124 instead of hanging the caller), and exits the process."""
     if gpus <= 1 or "WORLD_SIZE" in os.environ:
         return
     if need_devices:
@@ -98,5 +110,5 @@ def ensure_ranks(gpus, argv=None, need_devices=True):
         if have < gpus:
             sys.stderr.write("%d ranks wanted, %d devices visible: not starting\n" % (gpus, have))
             sys.exit(2)
-    rc, _ = spawn_ranks(gpus, [sys.executable] + (list(sys.argv) if argv is None else list(argv)))
+    rc, _ = spawn_ranks(gpus, [sys.executable] + (list(sys.argv) if argv is None else list(argv)), timeout=timeout)
     sys.exit(rc)

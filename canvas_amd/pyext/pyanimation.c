@@ -210,7 +210,7 @@ static PyObject *anim_remove(py_anim *self, PyObject *args) {
 
 static void anim_values(py_anim *self, ssize_t count, double *frames, double (*out)[4]) {
     if (!self->lock_ready) { for (ssize_t i = 0; i < count; i++) out[i][0] = out[i][1] = out[i][2] = out[i][3] = 0.0; return; }
-    pthread_rwlock_rdlock(&self->lock);
+    py_rdlock(&self->lock);
     for (ssize_t i = 0; i < count; i++) {
         const double f = frames[i];
         const Py_ssize_t r = upper_bound(self, f);

@@ -13,14 +13,30 @@
 #include "pyframework.h"
 #include <pthread.h>
 
-/* Writer side of a node's rwlock, taken from a Python-called method (GIL held).  Worker threads hold the reader side
- * across pulls, and a pull may need the GIL (a source written in Python): a writer that blocks WITH the GIL would then
- * wait for a reader that waits for the GIL.  So: try first, and if the lock is busy, wait for it without the GIL. */
+/* Node locks and the GIL.  Worker threads (pull queue, playback) hold the reader side of a node's rwlock across a pull,
+ * and a pull may need the GIL (a source or a frame function written in Python).  Python-called methods take either side
+ * with the GIL held.  The one rule that keeps the pair (lock, GIL) free of cycles: NOBODY BLOCKS ON A NODE LOCK WHILE
+ * HOLDING THE GIL.  Both sides try first and, if the lock is busy, wait for it with the GIL released.  A thread may then
+ * wait for the GIL while it holds the lock (the writer coming back from its wait, a worker's reader calling into
+ * Python): whoever has the GIL at that moment either runs on or gives it up before it blocks on the lock, so the wait ends.
+ * (The first form released the GIL only on the writer side: a writer coming back for the GIL with the lock in hand met
+ * a reader that had blocked on the lock with the GIL in hand -- anim.add() against get_values() from a callback.) */
 static inline void py_wrlock_nogil(pthread_rwlock_t *lock) {
     if (pthread_rwlock_trywrlock(lock) == 0) return;
     Py_BEGIN_ALLOW_THREADS
     pthread_rwlock_wrlock(lock);
     Py_END_ALLOW_THREADS
+}
+/* reader side: called from worker threads without the GIL and from Python-called code with it */
+static inline void py_rdlock(pthread_rwlock_t *lock) {
+    if (pthread_rwlock_tryrdlock(lock) == 0) return;
+    if (PyGILState_Check()) {
+        Py_BEGIN_ALLOW_THREADS
+        pthread_rwlock_rdlock(lock);
+        Py_END_ALLOW_THREADS
+    } else {
+        pthread_rwlock_rdlock(lock);
+    }
 }
 
 /* a node's native render: fill `frame` (device, of the node's native format) for frame_index */

@@ -371,7 +371,7 @@ static void ffpass_dealloc(py_ffpass *self) {
     Py_TYPE(self)->tp_free((PyObject *)self);
 }
 static void ffpass_values(py_ffpass *self, ssize_t count, double *frames, double (*out)[4]) {
-    pthread_rwlock_rdlock(&self->lock);
+    py_rdlock(&self->lock);
     if (self->source.funcs && self->source.funcs->get_values) {
         double *shifted = NULL;
         if (self->offset != 0.0 && count > 0) {

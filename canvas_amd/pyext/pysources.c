@@ -143,7 +143,7 @@ static void gain_render(PyObject *o, int frame_index, rgba_frame_dev *f) {      
     py_gain *self = (py_gain *)o;
     rgba_frame_dev in = scratch_like(f, CVS_FORMAT_F16, &f->full_window);
     if (!in.data) { box2i_set_empty(&f->current_window); return; }
-    pthread_rwlock_rdlock(&self->n.lock);
+    py_rdlock(&self->n.lock);
     pull_dev(self->n.source, frame_index, &in);
     float gain = framefunc_get_f32(&self->gain, frame_index), offset = framefunc_get_f32(&self->offset, frame_index);
     pthread_rwlock_unlock(&self->n.lock);
@@ -276,7 +276,7 @@ static void scaler_dealloc(py_scaler *self) {
  * wants f16 and the input is half-native (widen on load, truncate on store inside the scaler's own passes) */
 static void scaler_render_fmt(PyObject *o, int frame_index, rgba_frame_dev *f, int fmt) {
     py_scaler *self = (py_scaler *)o;
-    pthread_rwlock_rdlock(&self->n.lock);                 /* released on every path (the reference leaks it at VideoScaler.c:64-69) */
+    py_rdlock(&self->n.lock);                 /* released on every path (the reference leaks it at VideoScaler.c:64-69) */
     if (!self->n.source) { pthread_rwlock_unlock(&self->n.lock); box2i_set_empty(&f->current_window); return; }
     v2f sp, tp, fac; box2i rect;
     framefunc_get_v2f(&sp, &self->source_point, frame_index);
@@ -316,7 +316,7 @@ static void scaler_render_fmt(PyObject *o, int frame_index, rgba_frame_dev *f, i
 static void scaler_render(PyObject *o, int frame_index, rgba_frame_dev *f) { scaler_render_fmt(o, frame_index, f, CVS_FORMAT_F32); }     /* native: f32 */
 static void scaler_slot_dev(PyObject *self, int i, rgba_frame_dev *f) {
     py_scaler *sc = (py_scaler *)self;
-    pthread_rwlock_rdlock(&sc->n.lock);
+    py_rdlock(&sc->n.lock);
     const bool half = f->format == CVS_FORMAT_F16 && half_native(sc->n.source);
     pthread_rwlock_unlock(&sc->n.lock);
     if (half) scaler_render_fmt(self, i, f, CVS_FORMAT_F16);
@@ -364,7 +364,7 @@ static void pass_dealloc(py_pass *self) {
 }
 /* forwards in the caller's format: no native format of its own (VideoPassThroughFilter.c:70-119) */
 static void pass_slot_dev(py_pass *self, int frame_index, rgba_frame_dev *f) {
-    pthread_rwlock_rdlock(&self->n.lock);
+    py_rdlock(&self->n.lock);
     if ((self->has_start && frame_index < self->start_frame) || (self->has_end && frame_index >= self->end_frame)) box2i_set_empty(&f->current_window);
     else pull_dev(self->n.source, frame_index + self->offset, f);
     pthread_rwlock_unlock(&self->n.lock);
@@ -440,7 +440,7 @@ static seq_elem *seq_pick(py_seq *self, int frame_index) {
     return &self->e[lo];
 }
 static void seq_slot_dev(py_seq *self, int frame_index, rgba_frame_dev *f) {
-    pthread_rwlock_rdlock(&self->lock);
+    py_rdlock(&self->lock);
     seq_elem *el = seq_pick(self, frame_index);
     if (!el) box2i_set_empty(&f->current_window);
     else pull_dev(el->source, frame_index - el->start_frame + el->offset, f);
@@ -555,7 +555,7 @@ static void pulldown_dealloc(py_pulldown *self) {
 }
 static void pulldown_render(PyObject *o, int frame_index, rgba_frame_dev *f) {      /* native: f16 */
     py_pulldown *self = (py_pulldown *)o;
-    pthread_rwlock_rdlock(&self->n.lock);
+    py_rdlock(&self->n.lock);
     if (!self->n.source) { box2i_set_empty(&f->current_window); pthread_rwlock_unlock(&self->n.lock); return; }
     int first, second;
     const int mixed = cvs_pulldown23_frames(self->offset, frame_index, &first, &second);

@@ -47,12 +47,12 @@ static void ws_dealloc(py_workspace *self) {
 
 /* slots forward to the library's workspace vtable under the reader lock (VideoWorkspace.c:325-330) */
 static void ws_slot_32(py_workspace *self, int frame_index, rgba_frame_f32 *f) {
-    pthread_rwlock_rdlock(&self->lock);
+    py_rdlock(&self->lock);
     video_get_frame_f32(&self->source, frame_index, f);
     pthread_rwlock_unlock(&self->lock);
 }
 static void ws_slot_dev(py_workspace *self, int frame_index, rgba_frame_dev *f) {
-    pthread_rwlock_rdlock(&self->lock);
+    py_rdlock(&self->lock);
     video_get_frame_dev(&self->source, frame_index, f);
     pthread_rwlock_unlock(&self->lock);
 }

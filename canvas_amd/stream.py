@@ -66,6 +66,9 @@ class GraphStream:
             refs = (C.POINTER(_lib.rgba_frame_f16_t) * overlays)(*[C.pointer(o.c) for o in over])
             self.slots.append({"src": src, "over": over, "over_refs": refs, "graded": DeviceFrame(self.full, np.uint16),
                                "out": DeviceFrame(self.full, np.uint16)})
+        # the donor copies ran on this thread's own stream; the slots are rendered on whatever streams the caller
+        # passes to render(): finish the copies before anyone reads them
+        _lib.check(self.lib.cvs_stream_sync(None), "donor copies")
         self._m = self.matrix.ctypes.data_as(C.POINTER(C.c_float))
         self._t = self.taps.ctypes.data_as(C.POINTER(C.c_float))
 

@@ -229,6 +229,7 @@ CVS_EXPORT int cvs_init(int device);                   /* 0 on success; idempote
 CVS_EXPORT int cvs_device_count(void);
 CVS_EXPORT int cvs_current_device(void);
 CVS_EXPORT const char *cvs_last_error(void);
+CVS_EXPORT void cvs_clear_last_error(void);                                           /* forget the calling thread's message */
 /* Diagnostics: every failure message (the text of cvs_last_error) is also handed to the installed handler, or written to
  * stderr when there is none.  The handler may be called from any thread that calls into the library.  The reference
  * logs through g_log in per-file domains (e.g. src/cprocess/video_reconstruct.c:23-24); here the domain is always
@@ -373,6 +374,19 @@ CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame
 enum { CVS_FIR_PATH_AUTO = 0, CVS_FIR_PATH_SWEEP = 1 /* lane per pixel */, CVS_FIR_PATH_TILED = 2, CVS_FIR_PATH_TABLES = 4 /* skip the register-window kernel */,
        CVS_FIR_PATH_LANES = 8 /* lane per channel */ };
 CVS_EXPORT void cvs_fir_path_override(int mode);
+/* Which kernel the calling thread's last FIR launch (scaler, blur, Lanczos resample, blur + resample) went to -- what a
+ * test pinned to one kernel asserts, and what tells a silent fallback from the intended kernel.  A fused kernel that was
+ * chosen and then failed to launch is reported through cvs_last_error() / the log handler before the next one is tried. */
+enum { CVS_FIR_KERNEL_NONE = 0,
+       CVS_FIR_KERNEL_WINDOW = 1,      /* k_blur: one tap list for every line, vertical window in registers */
+       CVS_FIR_KERNEL_HALVE = 2,       /* k_blur_halve: blur + Lanczos halving in one sweep */
+       CVS_FIR_KERNEL_LANES = 3,       /* k_fir_lanes: per-line tables, horizontal pass first */
+       CVS_FIR_KERNEL_VH = 4,          /* k_fir_vh: the triangle scaler with the vertical pass first */
+       CVS_FIR_KERNEL_TILED = 5,       /* k_fir2d: LDS tiles */
+       CVS_FIR_KERNEL_STREAM = 6,      /* k_fir_stream: lane-per-pixel sweep */
+       CVS_FIR_KERNEL_TWO_PASS = 7,    /* two k_fir launches through an f32 frame (cached tables) */
+       CVS_FIR_KERNEL_PASS = 8 };      /* k_fir: one pass of the triangle scaler (both passes: two of these) */
+CVS_EXPORT int cvs_fir_last_kernel(void);
 
 /* ------------------------------------------------------------------ (3) fused chain: BASELINE config 2
  * out = f16( over-stack_{k=0..n-1}( f32( colour(layer_k) ) ) ), i.e. what the reference computes with

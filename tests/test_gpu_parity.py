@@ -5,6 +5,7 @@ tests/util.py) -- tighter than the 1-ulp-in-half bar BASELINE.md allows.
 Run on the GPU box with `pytest -m gpu`.  Nothing here reads /root/reference.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -830,6 +831,39 @@ def force_fir(request):
         lib.cvs_fir_path_override(mode)
     yield pin
     pin(None)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if _FIR_SEEN and os.path.isdir(out):                       # which kernel every pinned case went to, for the record
+        import json
+        with open(os.path.join(out, "fir_kernels_seen.json"), "w") as f:
+            json.dump(_FIR_SEEN, f, indent=0, sort_keys=True)
+
+
+_KERNEL_NAMES = {_lib.FIR_KERNEL_NONE: "none", _lib.FIR_KERNEL_WINDOW: "window", _lib.FIR_KERNEL_HALVE: "halve", _lib.FIR_KERNEL_LANES: "lanes",
+                 _lib.FIR_KERNEL_VH: "vh", _lib.FIR_KERNEL_TILED: "tiled", _lib.FIR_KERNEL_STREAM: "stream",
+                 _lib.FIR_KERNEL_TWO_PASS: "two-pass", _lib.FIR_KERNEL_PASS: "pass"}
+_FIR_SEEN = {}
+
+
+def ran_on(cvs, forced, fallback=None, note=None):
+    """cvs_fir_last_kernel() after a launch pinned with force_fir(forced): the pinned kernel, or -- for a table pair that
+    kernel does not take -- the documented fallback named by the caller (host/scale.c fir2d_launch: lanes -> stream when
+    the tiles would need more than 64 KiB of LDS and the vertical table streams -> tiled -> two passes)."""
+    got = _KERNEL_NAMES[cvs.cvs_fir_last_kernel()]
+    if note is not None:
+        _FIR_SEEN[note] = got
+    want = fallback or forced
+    assert got == want, "pinned to %r (expected to run on %r), ran on %r" % (forced, want, got)
+    assert _lib.last_error() == "", _lib.last_error()      # a fused kernel that failed to launch says so (fir_launch_fell_through)
+    return got
+
+
+# cases of the tests below that the pinned kernel does NOT take, and where they go instead
+_FALLBACK = {
+    ("lanes", (0.3, 3.0)): "tiled",        # 3x enlargement: 39 accumulator slots, the sweep has 32; small footprint -> tiles
+    # the lane-per-pixel sweep keeps one accumulator per active target row and has instances up to 16 of them
+    # (cvk_fir_stream_supported): a 2x enlargement has 26 active rows, 2.1x and 3x more -> tiles
+    ("stream", (2.0, 2.0)): "tiled", ("stream", (1.5625, 2.1)): "tiled", ("stream", (0.3, 3.0)): "tiled",
+}
 
 
 @pytest.mark.parametrize("kernel", ["lanes", "stream", "tiled"])
@@ -854,7 +888,9 @@ def test_lanczos_resample_both_kernels(cvs, orc, force_fir, kernel, ssize, scur,
     orc.lib().orc_resample_lanczos_f32(want.ref(), src.ref(), C.c_float(fx), C.c_float(fy), 3)
     force_fir(kernel)
     d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(tfull, np.float32)
+    cvs.cvs_clear_last_error()
     _lib.check(cvs.cvs_resample_lanczos_f32_dev(d_out.ref(), d_src.ref(), C.c_float(fx), C.c_float(fy), 3, None))
+    ran_on(cvs, kernel, _FALLBACK.get((kernel, (fx, fy))), note="lanczos %s %r" % (kernel, (ssize, scur, fx, fy)))
     got = d_out.download()
     assert same_window(got.current_window, want.current_window)
     assert_same_f32(got.array, want.array, "lanczos (%s)" % kernel)
@@ -863,6 +899,7 @@ def test_lanczos_resample_both_kernels(cvs, orc, force_fir, kernel, ssize, scur,
     want16 = _oracle_config3(orc, src16, tsize, np.array([1.0], np.float32), fx, fy)
     d16, o16 = DeviceFrame.from_host(src16), DeviceFrame(tfull, np.uint16)
     _lib.check(cvs.cvs_blur_lanczos_f16_dev(o16.ref(), d16.ref(), f32p(np.array([1.0], np.float32)), 1, C.c_float(fx), C.c_float(fy), 3, None))
+    ran_on(cvs, kernel, _FALLBACK.get((kernel, (fx, fy))))
     assert_same_f16(o16.download().array, want16.array, "lanczos f16 (%s)" % kernel)
 
 
@@ -886,7 +923,9 @@ def test_lanczos_resample_with_inf_and_nan_pixels(cvs, orc, force_fir, kernel, s
     assert 0 < np.count_nonzero(~np.isfinite(want.array)) < want.array.size // 4
     force_fir(kernel)
     d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(tfull, np.float32)
+    cvs.cvs_clear_last_error()
     _lib.check(cvs.cvs_resample_lanczos_f32_dev(d_out.ref(), d_src.ref(), C.c_float(fx), C.c_float(fy), 3, None))
+    ran_on(cvs, kernel, _FALLBACK.get((kernel, (fx, fy))), note="lanczos non-finite %s %r" % (kernel, (fx, fy)))
     got = d_out.download()
     assert same_window(got.current_window, want.current_window)
     assert_same_f32(got.array, want.array, "lanczos with non-finite pixels (%s)" % kernel)
@@ -903,7 +942,9 @@ def test_even_and_short_blurs_both_kernels(cvs, orc, force_fir, kernel, ntaps):
     orc.lib().orc_fir_blur_f32(want.ref(), src.ref(), f32p(taps), ntaps)
     force_fir(kernel)
     d_src, d_out = DeviceFrame.from_host(src), DeviceFrame(full, np.float32)
+    cvs.cvs_clear_last_error()
     _lib.check(cvs.cvs_fir_blur_f32_dev(d_out.ref(), d_src.ref(), f32p(taps), ntaps, None))
+    ran_on(cvs, kernel, _FALLBACK.get((kernel, ntaps)), note="blur %s %d" % (kernel, ntaps))
     got = d_out.download()
     assert same_window(got.current_window, want.current_window)
     assert_same_f32(got.window_view(), want.window_view(), "blur %d taps (%s)" % (ntaps, kernel))
@@ -926,6 +967,7 @@ def test_full_size_resample_agrees_between_the_kernels(cvs, force_fir, f, fmt):
         from tests.models import h2f_ieee
         d_src, dtype = DeviceFrame.from_host(HostFrame(src16.full_window, np.float32, h2f_ieee(src16.array).astype(np.float32))), np.float32
     outs = []
+    cvs.cvs_clear_last_error()
     for kernel in (None, "tiled", "lanes"):
         force_fir(kernel)
         d_out = DeviceFrame((0, 0, tw - 1, th - 1), dtype)
@@ -933,6 +975,7 @@ def test_full_size_resample_agrees_between_the_kernels(cvs, force_fir, f, fmt):
             _lib.check(cvs.cvs_resample_lanczos_f16_dev(d_out.ref(), d_src.ref(), C.c_float(f), C.c_float(f), 3, None))
         else:
             _lib.check(cvs.cvs_resample_lanczos_f32_dev(d_out.ref(), d_src.ref(), C.c_float(f), C.c_float(f), 3, None))
+        ran_on(cvs, kernel or "lanes", note="full size %s %r %s" % (kernel, f, fmt))       # the automatic choice at these factors is the channel-pair sweep
         got = d_out.download()
         assert got.current_window.tuple() == (0, 0, tw - 1, th - 1)
         outs.append(got.array.copy())
@@ -1267,7 +1310,9 @@ def test_blur_over_node_by_node_through_the_table_kernels(cvs, orc, force_fir, k
     taps = synth.gaussian_taps(ntaps | 1, 1.5)[:ntaps].copy()
     want = oracle_blur_over(orc, src, taps, overlays)
     force_fir(kernel)
+    cvs.cvs_clear_last_error()
     got = _blur_over(cvs, full, src, taps, overlays)
+    ran_on(cvs, kernel, _FALLBACK.get((kernel, ntaps)), note="blur over %s %d" % (kernel, ntaps))
     assert same_window(got.current_window, want.current_window)
     assert_same_f16(got.window_view(), want.window_view(), "blur+over node by node (%s)" % kernel)
 
@@ -1859,6 +1904,8 @@ def test_scaler_in_one_launch_agrees_with_the_two_passes(cvs, force_fir, fac, fm
             d_out = DeviceFrame((0, 0, tw - 1, th - 1), np.float32)
             _lib.check(cvs.cvs_scale_bilinear_f32_dev(d_out.ref(), v2f(0, 0), d_src.ref(), v2f(0, 0), v2f(*fac), None))
         fused.append(cvs.cvs_scale_last_was_fused())
+        # video_scale.c:252: the smaller factor's pass first -- horizontal first is the channel-pair sweep, else k_fir_vh
+        assert _KERNEL_NAMES[cvs.cvs_fir_last_kernel()] == ("pass" if kernel else "lanes" if fac[0] < fac[1] else "vh")
         got = d_out.download()
         outs.append((got.current_window.tuple(), got.array.copy()))
         d_src.free(); d_out.free()

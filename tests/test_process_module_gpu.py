@@ -313,6 +313,51 @@ def test_pull_queue_may_lose_its_last_reference_on_its_own_worker(process, bt):
     assert done.wait(30)
 
 
+def test_writer_worker_and_callback_on_one_animation_do_not_deadlock(process, bt):
+    """Three parties on one AnimationFunc's lock: the main thread keeps adding and removing points (writer, called with
+    the GIL), pull-queue workers read it through a solid's colour (readers without the GIL), and the queue's callbacks
+    call get_values() on it (readers WITH the GIL, on the worker thread).  A writer that came back from its wait holding
+    the lock and wanting the GIL used to meet a callback holding the GIL and wanting the lock."""
+    anim = process.AnimationFunc()
+    anim.add(process.POINT_LINEAR, 0.0, (0.0, 0.0, 0.0, 1.0))
+    anim.add(process.POINT_LINEAR, 1000.0, (1000.0, 0.0, 0.0, 1.0))
+    solid = process.SolidColorVideoSource(anim, bt.box2i(0, 0, 63, 63))
+    passing = process.FrameFuncPassThroughFilter(anim, offset=1.0)
+    q = process.VideoPullQueue(workers=3)
+    stop, total, got, errors = threading.Event(), 600, [], []
+    all_done = threading.Event()
+
+    def callback(frame_index, frame, user_data):
+        try:
+            v = anim.get_values(float(frame_index))[0]
+            w = passing.get_values([float(frame_index)])[0]
+            got.append((frame_index, frame.pixel(1, 1), v, w))
+        except Exception as e:                              # noqa: BLE001
+            errors.append(e)
+        if len(got) + len(errors) == total:
+            all_done.set()
+
+    def feeder():
+        for i in range(total):
+            q.enqueue(solid, i % 900, bt.box2i(0, 0, 63, 63), callback, None)
+
+    t = threading.Thread(target=feeder, daemon=True)
+    t.start()
+    writes = 0
+    while not all_done.is_set() and writes < 200000:
+        p = anim.add(process.POINT_LINEAR, 2000.0 + writes % 7, (0.0, 0.0, 0.0, 1.0))      # beyond every frame pulled
+        p.frame = 3000.0 + writes % 5
+        anim.remove(p)
+        passing.set_source(anim)
+        writes += 1
+    assert all_done.wait(60), "deadlock: %d of %d callbacks after %d writes" % (len(got), total, writes)
+    stop.set()
+    t.join(30)
+    assert not errors, errors[:3]
+    for i, px, v, w in got[::37]:
+        assert abs(px.r - i) <= max(1.0, i) * 2e-3 and abs(v[0] - i) < 1e-9 and abs(w[0] - (i + 1)) < 1e-9, (i, px, v, w)
+
+
 def test_preview_pulls_convert_on_the_device(process, bt, orc):
     """get_frame_argb32 equals get_frame_f16(...).to_argb32_bytes() (RgbaFrameF16.c:114-149 against the oracle);
     get_frame_rgba8 is the software widget's sRGB bytes (widget_gl.c:291-307)."""

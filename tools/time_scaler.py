@@ -1,0 +1,83 @@
+"""The reference's own scaler (video_scale_bilinear_f32 and its f16 twin) at the factors the editor uses, per call:
+ms, TB/s of source + target bytes, and which kernel took it (cvs_fir_last_kernel).  Sources rotate over enough frames to
+stay out of the Infinity Cache.   usage: python3 tools/time_scaler.py [--reps 40]"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from canvas_amd import _lib, synth                      # noqa: E402
+from canvas_amd.abi import v2f                          # noqa: E402
+from canvas_amd.device import DeviceFrame               # noqa: E402
+
+NAMES = ["none", "window", "halve", "lanes", "vh", "tiled", "stream", "two-pass", "pass"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=40)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    lib = _lib.load()
+    assert lib.cvs_init(0) == 0
+    lib.init_half()
+    cases = [("1080p->4K", (1920, 1080), (2.0, 2.0)), ("4K->1080p", (3840, 2160), (0.5, 0.5)), ("4K->0.75", (3840, 2160), (0.75, 0.75)),
+             ("4K->1.5", (3840, 2160), (1.5, 1.5)), ("4K->2x", (3840, 2160), (2.0, 2.0)), ("4K->0.4", (3840, 2160), (0.4, 0.4)),
+             ("4K->0.3", (3840, 2160), (0.3, 0.3)), ("4K->0.75x1.5", (3840, 2160), (0.75, 1.5)), ("4K->1.25x1.125", (3840, 2160), (1.25, 1.125))]
+    for name, (w, h), fac in cases:
+        if args.only and args.only not in name:
+            continue
+        tw, th = int(w * fac[0]), int(h * fac[1])
+        for fmt in ("f16", "f32"):
+            bpp = 8 if fmt == "f16" else 16
+            nsrc = max(2, int(600e6 // (w * h * bpp)) + 1)
+            nsrc = min(nsrc, 24)
+            host = synth.layer_frame(w, h, 1, 0)
+            srcs = []
+            for k in range(nsrc):
+                d16 = DeviceFrame.from_host(host) if k == 0 else None
+                if fmt == "f16":
+                    if k == 0:
+                        srcs.append(d16)
+                    else:
+                        d = DeviceFrame((0, 0, w - 1, h - 1), np.uint16)
+                        _lib.check(lib.cvs_memcpy_d2d(d.ptr, srcs[0].ptr, d.nbytes, None))
+                        srcs.append(d)
+                else:
+                    d = DeviceFrame((0, 0, w - 1, h - 1), np.float32)
+                    if k == 0:
+                        _lib.check(lib.cvs_frame_f16_to_f32_dev(d.ref(), d16.ref(), None))
+                        lib.cvs_stream_sync(None)
+                        d16.free()
+                    else:
+                        _lib.check(lib.cvs_memcpy_d2d(d.ptr, srcs[0].ptr, d.nbytes, None))
+                    srcs.append(d)
+            outs = [DeviceFrame((0, 0, tw - 1, th - 1), np.uint16 if fmt == "f16" else np.float32) for _ in range(2)]
+            lib.cvs_stream_sync(None)
+            call = lib.cvs_scale_bilinear_f16_dev if fmt == "f16" else lib.cvs_scale_bilinear_f32_dev
+
+            def run(i):
+                _lib.check(call(outs[i & 1].ref(), v2f(0, 0), srcs[i % nsrc].ref(), v2f(0, 0), v2f(*fac), None))
+            for i in range(3):
+                run(i)
+            lib.cvs_stream_sync(None)
+            best = 1e9
+            for rep in range(3):
+                t0 = time.perf_counter()
+                for i in range(args.reps):
+                    run(i)
+                lib.cvs_stream_sync(None)
+                best = min(best, (time.perf_counter() - t0) / args.reps)
+            nbytes = (w * h + tw * th) * bpp
+            print("%-16s %s  %.4f ms  %.2f TB/s (%.3f of 8)  kernel=%s fused=%d" % (
+                name, fmt, best * 1e3, nbytes / best / 1e12, nbytes / best / 8e12, NAMES[lib.cvs_fir_last_kernel()], lib.cvs_scale_last_was_fused()), flush=True)
+            for d in srcs + outs:
+                d.free()
+
+
+if __name__ == "__main__":
+    main()
