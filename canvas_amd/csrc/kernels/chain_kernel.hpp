@@ -117,9 +117,20 @@ struct Walk {
 
 // NL in 1..4, the same for every job of the batch; every job has 2 <= npixels and npixels * 8 < 4 GiB;
 // blockDim.x == 1 << lshift
+// Whether an instance fetches through the asm pipeline above.  The property it needs -- no instruction touches a register
+// between the load into it and the wait -- is checked on the machine code of every instance at build time
+// (tools/check_asm_loads.py, run by the Makefile): an instance that hipcc compiles with a copy of an in-flight register in
+// front of the wait is listed here and takes plain loads, waits left to the compiler (slower, never wrong).
+//   <6, GRADE, PRE, !POST>: ROCm 7.2's hipcc turns the two register sets of six layers into one set + sixteen v_mov_b64
+//   on a loop edge, placed before the wait.
+constexpr bool chain_hand_pipelined(int nl, int mode, bool pre, bool post) {
+    return !(nl == 6 && mode == CHAIN_GRADE && pre && !post);
+}
+
 template <int NL, int MODE, bool PRE, bool POST, int DIAG>
 __global__ __launch_bounds__(NL <= 4 ? kWG : 512) void k_chain(BatchT<(NL <= 4 ? 4 : 8)> batch, int njobs_, Mat kmat, int lshift,
                                                const uint16_t *__restrict__ pre, const uint16_t *__restrict__ post) {
+    constexpr bool HAND = chain_hand_pipelined(NL, MODE, PRE, POST);
     const MatR mat = CVS_MAT_REGS(kmat);
     __shared__ uint16_t lut[(PRE || POST) ? kLutHalfs : 1];
     const unsigned L = 1u << lshift, G = gridDim.x, tid = threadIdx.x, njobs = (unsigned)njobs_;
@@ -147,7 +158,11 @@ __global__ __launch_bounds__(NL <= 4 ? kWG : 512) void k_chain(BatchT<(NL <= 4 ?
         const unsigned valid = valid_of(w);
         const uint32_t voff = (tid < valid ? tid : valid - 1) << 4;
 #pragma unroll
-        for (int k = 0; k < NL; k++) asm_ld4s(dst[k], w.layer[k] + ((size_t)w.chunk << (lshift + 4)), voff);
+        for (int k = 0; k < NL; k++) {
+            const char *base = w.layer[k] + ((size_t)w.chunk << (lshift + 4));
+            if constexpr (HAND) asm_ld4s(dst[k], base, voff);
+            else dst[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(base + voff));
+        }
     };
 
     Walk<NL> cur;
@@ -163,7 +178,7 @@ __global__ __launch_bounds__(NL <= 4 ? kWG : 512) void k_chain(BatchT<(NL <= 4 ?
     issue(A, cur);                              // the first trip goes out before the table is staged
     if (PRE) stage_lut_any(lut, pre);
     else if (POST) stage_lut_any(lut, post);
-    wait_vm0(A);
+    if constexpr (HAND) wait_vm0(A);
     if (next.job < njobs) issue(B, next);
 
     // One trip.  On entry `now` holds chunk `cur` and the loads of chunk `next` are in flight into `nxt`.
@@ -185,7 +200,7 @@ __global__ __launch_bounds__(NL <= 4 ? kWG : 512) void k_chain(BatchT<(NL <= 4 ?
         const bool store_it = tid < valid_of(cur);
         g_u4 out = (g_u4)(cur.out + ((size_t)cur.chunk << (lshift + 4)));
         __builtin_amdgcn_sched_barrier(0);
-        wait_vm0(nxt);
+        if constexpr (HAND) wait_vm0(nxt);
         __builtin_amdgcn_sched_barrier(0);
         if (DIAG == DIAG_COMPUTE_ONLY) diag_acc ^= res;
         else if (store_it) __builtin_nontemporal_store(res, out + tid);

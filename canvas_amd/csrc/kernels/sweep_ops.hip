@@ -341,17 +341,25 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
     Taps xa, xb;
     // Four rows out of the group `cur` (AHEAD: its first row is in LDS and gathered already).
     // false: the segment's last row has been filtered (uniform)
+    // Leaving in the middle of a group: the other group's loads are still in flight.  Wait for them HERE, before the exit
+    // path joins anything else -- hipcc lays a loop's exits through blocks it shares with the loop body, and a
+    // path-insensitive reading of the machine code (tools/check_asm_loads.py) must not find a way from "loads in flight"
+    // to an instruction that touches their registers.
+    auto leave = [&]() __attribute__((always_inline)) -> bool {
+        if constexpr (HAND) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        return false;
+    };
     auto four_rows = [&](Group &cur, Group &nxt) __attribute__((always_inline)) -> bool {
         if constexpr (AHEAD) {
             filter(xa, xb, lds + kRowFl, cur[1], ra, rb);
             finish(ra);
-            if (++s > s_hi) return false;
+            if (++s > s_hi) return leave();
             filter(xb, xa, lds, cur[2], rb, ra);
             finish(rb);
-            if (++s > s_hi) return false;
+            if (++s > s_hi) return leave();
             filter(xa, xb, lds + kRowFl, cur[3], ra, rb);
             finish(ra);
-            if (++s > s_hi) return false;
+            if (++s > s_hi) return leave();
             wait_group(nxt);                                       // the row after this group's last is the next group's first
             issue_group(cur);                                      // (cur[3] went to LDS a step ago)
             filter(xb, xa, lds, nxt[0], rb, ra);
@@ -359,13 +367,13 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
         } else {
             filter(xa, xa, lds, cur[0], ra, rb);
             finish(ra);
-            if (++s > s_hi) return false;
+            if (++s > s_hi) return leave();
             filter(xa, xa, lds + kRowFl, cur[1], rb, ra);
             finish(rb);
-            if (++s > s_hi) return false;
+            if (++s > s_hi) return leave();
             filter(xa, xa, lds, cur[2], ra, rb);
             finish(ra);
-            if (++s > s_hi) return false;
+            if (++s > s_hi) return leave();
             filter(xa, xa, lds + kRowFl, cur[3], rb, ra);
             // the wait for the next group (vmcnt(0): it waits for this wave's stores too) between the halves of the last row:
             // the youngest store outstanding is then a row old (an enlargement stores on every row)
@@ -373,7 +381,8 @@ __global__ __launch_bounds__(kLanes) void k_fir_lanes(cvk_fir2d_params fp, int r
             issue_group(cur);
             finish(rb);
         }
-        return ++s <= s_hi;
+        if (++s > s_hi) return leave();
+        return true;
     };
     issue_group(ga);
     wait_group(ga);

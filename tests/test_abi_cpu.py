@@ -218,16 +218,101 @@ def test_hot_kernels_keep_their_state_in_registers():
                                             # kernel for the last pixel of odd-sized frames
                     assert int(scratch) == 0 and int(spills) == 0, (name, scratch, spills)
                     checked += 1
-                # sweep_ops.hip: an instance that fetches its rows through hand-written asm loads (last template argument
-                # true) must have registers to spare -- under pressure hipcc moves values about, and a register with a load
-                # in flight into it must not be touched before the hand-written wait
-                for agprs, name, vgprs in re.findall(r"\.agpr_count:\s+(\d+)(?:(?!\.agpr_count).)*?\.name:\s+(\S*k_fir_lanes\S+)(?:(?!\.agpr_count).)*?\.vgpr_count:\s+(\d+)", notes, re.S):
-                    if name.endswith("Lb1EEEv16cvk_fir2d_paramsi"):
-                        assert int(agprs) == 0 and int(vgprs) <= 224, (name, agprs, vgprs)
-                        hand += 1
-                # sweep_vh_ops.hip: every instance fetches that way
-                for agprs, name, vgprs in re.findall(r"\.agpr_count:\s+(\d+)(?:(?!\.agpr_count).)*?\.name:\s+(\S*k_fir_vh\S+)(?:(?!\.agpr_count).)*?\.vgpr_count:\s+(\d+)", notes, re.S):
-                    assert int(agprs) == 0 and int(vgprs) <= 224, (name, agprs, vgprs)
-                    hand += 1
     assert checked >= 20, checked
-    assert hand >= 20, hand
+
+
+def _asm_checker():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_asm_loads", os.path.join(ROOT, "tools", "check_asm_loads.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_no_kernel_touches_a_register_with_a_load_in_flight():
+    """The hand-pipelined kernels (k_chain, k_fir_lanes) issue loads from inline asm and wait by hand; hipcc believes the
+    loaded value exists when the asm statement ends and may copy or reuse its register before the wait (round 2: wrong
+    pixels, then a fault; round 3: the checker found sixteen such copies in k_chain<6 layers, pre-LUT>).  The rule is
+    checked on the disassembly of EVERY kernel of the library -- the same check the Makefile runs as a build step."""
+    chk = _asm_checker()
+    build = os.path.join(ROOT, "canvas_amd", "csrc", "build")
+    import glob
+    objs = sorted(glob.glob(os.path.join(build, "*.hip.o")))
+    if not os.path.exists(chk.OBJDUMP):
+        pytest.skip("no ROCm LLVM tools")
+    assert len(objs) >= 15, "no kernel objects in tree: build first (python -c 'import __graft_entry__ as g; g.build()')"
+    checked, problems = chk.check_paths(objs)
+    assert checked >= 250, checked
+    assert not problems, "\n".join(problems[:10])
+    # the hand-pipelined ones were among them
+    hand, _ = chk.check_paths([o for o in objs if os.path.basename(o) in ("chain_ops.hip.o", "sweep_ops.hip.o")], only=r"k_chainILi2ELi0ELb1ELb0|k_fir_lanesILi8ELi8ELi1ELb1ELb1")
+    assert hand >= 2
+
+
+_BROKEN = """
+0000000000001000 <k_broken>:
+\ts_load_dwordx2 s[0:1], s[4:5], 0x0                         // 000000001000: C0060002 00000000
+\ts_waitcnt lgkmcnt(0)                                       // 000000001008: BF8CC07F
+\tglobal_load_dwordx4 v[4:7], v1, s[0:1]                     // 00000000100C: DC5C8000 04000001
+\tv_mov_b32_e32 v10, 0                                       // 000000001014: 7E140280
+\tv_mov_b64_e32 v[8:9], v[4:5]                               // 000000001018: 7E107104
+\ts_waitcnt vmcnt(0)                                         // 00000000101C: BF8C0F70
+\tv_add_f32_e32 v10, v8, v6                                  // 000000001020: 02140D08
+\ts_endpgm                                                   // 000000001024: BF810000
+"""
+
+
+def test_the_checker_finds_a_copy_in_front_of_the_wait():
+    """The shape of the fault: a register pair copied between the load into it and the wait.  And the shapes that are
+    fine: a counted wait that retires the older of two loads, a second load into the same registers (in order), a loop
+    that waits at its top for what it requested at its bottom, a structurizer flag that sends the exit path round the body."""
+    chk = _asm_checker()
+    bad = chk.parse(_BROKEN)
+    problems = chk.check_function("k_broken", bad["k_broken"])
+    assert len(problems) == 1 and "v_mov_b64_e32 v[8:9], v[4:5]" in problems[0] and "0x100c" in problems[0], problems
+
+    fine = """
+0000000000002000 <k_fine>:
+\tglobal_load_dwordx2 v[2:3], v0, s[0:1]                     // 000000002000: DC548000 02000000
+\tglobal_load_dwordx2 v[4:5], v0, s[2:3]                     // 000000002008: DC548000 04020000
+\ts_waitcnt vmcnt(1)                                         // 000000002010: BF8C0F71
+\tv_add_f32_e32 v6, v2, v3                                   // 000000002014: 020C0702
+\tglobal_load_dwordx2 v[4:5], v0, s[4:5]                     // 000000002018: DC548000 04040000
+\ts_mov_b64 s[10:11], 0                                      // 000000002020: BE8A0180
+\ts_cmp_lt_i32 s6, s7                                        // 000000002024: BF040706
+\ts_cbranch_scc1 2                                           // 000000002028: BF850002 <k_fine+0x34>
+\ts_mov_b64 s[10:11], -1                                     // 00000000202C: BE8A01C1
+\ts_branch 3                                                 // 000000002030: BF820003 <k_fine+0x40>
+\ts_waitcnt vmcnt(0)                                         // 000000002034: BF8C0F70
+\tv_add_f32_e32 v6, v4, v5                                   // 000000002038: 020C0B04
+\tglobal_load_dwordx2 v[4:5], v0, s[4:5]                     // 00000000203C: DC548000 04040000
+\ts_and_b64 vcc, exec, s[10:11]                              // 000000002040: 86EA0A7E
+\ts_cbranch_vccnz 2                                          // 000000002044: BF870002 <k_fine+0x50>
+\ts_branch 65531                                             // 000000002048: BF82FFFB <k_fine+0x34>
+\ts_nop 0                                                    // 00000000204C: BF800000
+\ts_endpgm                                                   // 000000002050: BF810000
+"""
+    ok = chk.parse(fine)
+    assert chk.check_function("k_fine", ok["k_fine"]) == []
+
+    # hipcc's structurizer: the exit path (loads still in flight) and the loop path (waited) meet in a shared block that
+    # tests a flag; only with the flag known does the exit path not run on into the body
+    flagged = """
+0000000000003000 <k_flag>:
+\tglobal_load_dwordx2 v[4:5], v0, s[0:1]                     // 000000003000: DC548000 04000000
+\ts_cmp_lt_i32 s6, s7                                        // 000000003008: BF040706
+\ts_cbranch_scc1 2                                           // 00000000300C: BF850002 <k_flag+0x18>
+\ts_mov_b64 s[10:11], -1                                     // 000000003010: BE8A01C1
+\ts_branch 2                                                 // 000000003014: BF820002 <k_flag+0x20>
+\ts_waitcnt vmcnt(0)                                         // 000000003018: BF8C0F70
+\ts_mov_b64 s[10:11], 0                                      // 00000000301C: BE8A0180
+\ts_and_b64 vcc, exec, s[10:11]                              // 000000003020: 86EA0A7E
+\ts_cbranch_vccnz 2                                          // 000000003024: BF870002 <k_flag+0x30>
+\tv_add_f32_e32 v6, v4, v5                                   // 000000003028: 020C0B04
+\ts_nop 0                                                    // 00000000302C: BF800000
+\ts_endpgm                                                   // 000000003030: BF810000
+"""
+    assert chk.check_function("k_flag", chk.parse(flagged)["k_flag"]) == []
+    leaky = flagged.replace("s_and_b64 vcc, exec, s[10:11]", "s_and_b64 vcc, exec, s[12:13]").replace("k_flag", "k_leaky")
+    problems = chk.check_function("k_leaky", chk.parse(leaky)["k_leaky"])
+    assert len(problems) == 1 and "v_add_f32_e32 v6, v4, v5" in problems[0], problems

@@ -512,7 +512,7 @@ def test_chain_batch_and_lut_variants(cvs, orc):
             assert_same_f16(out.download().array, want.array, "batch pre=%d post=%d" % (pre, post))
 
 
-@pytest.mark.parametrize("nlayers,plain", [(1, False), (2, False), (3, True), (4, False), (5, True), (7, False), (8, True)])
+@pytest.mark.parametrize("nlayers,plain", [(1, False), (2, False), (3, True), (4, False), (5, True), (6, False), (7, False), (8, True)])
 def test_chain_batch_of_frames_of_different_sizes(cvs, orc, nlayers, plain):
     """One call, frames of very different sizes, odd and even pixel counts, some smaller than one 8 KiB chunk: the
     workgroups walk the whole batch as one run of chunks, crossing from frame to frame with partial last chunks, and the

@@ -31,6 +31,12 @@ import tempfile
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 IDX_SPAN = 32           # registers a GPR-indexed operand may reach from its base (the longest register vector in the kernels)
+# Kernels that issue loads from inline asm.  A jump table (s_setpc_b64, hipcc's code for a dense switch) cannot be
+# followed; in a kernel of this list that is an error, elsewhere the blocks behind it are simply not walked (every load
+# there is the compiler's own, waited for by the compiler).
+HAND_PIPELINED = re.compile(r"k_chainILi|k_fir_lanesILi")
+# kernels whose indexed register vector is shorter: k_fir_lanes<MAXT, NACC, ...> indexes ONE vector of 2 * NACC floats
+IDX_SPAN_OF = [(re.compile(r"k_fir_lanesILi\d+ELi(\d+)E"), lambda m: 2 * int(m.group(1)))]
 VMCNT_MAX = 63
 
 _reg_re = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
@@ -99,7 +105,7 @@ def split_operands(ops):
     return out
 
 
-def check_function(name, body, verbose=False):
+def _analyse(name, body, use_flags):
     """-> list of violation strings.
     Forward may-analysis over the kernel's control-flow graph.  State at an instruction: for every register with a load
     possibly in flight into it, the SMALLEST number of vector-memory instructions issued after that load on any path
@@ -110,8 +116,10 @@ def check_function(name, body, verbose=False):
     succs, touched, kind = [None] * n, [None] * n, [None] * n
     for i, ins in enumerate(body):
         mnem, ops = ins.mnem, ins.ops
-        if mnem == "s_endpgm" or mnem in ("s_setpc_b64", "s_swappc_b64", "s_call_b64"):
+        if mnem == "s_endpgm":
             succs[i] = ()
+        elif mnem in ("s_setpc_b64", "s_swappc_b64", "s_call_b64"):
+            succs[i] = "indirect"                       # a jump table (hipcc's own, from a switch): not followed, see below
         elif mnem == "s_branch" and ins.target is not None:
             succs[i] = (index[ins.target],) if ins.target in index else ()
         elif mnem.startswith("s_cbranch") and ins.target is not None:
@@ -145,8 +153,14 @@ def check_function(name, body, verbose=False):
             kind[i] = ("vmem", dst)
         elif mnem == "s_endpgm":
             kind[i] = ("end",)
-        elif mnem in ("s_setpc_b64", "s_swappc_b64", "s_call_b64"):
-            kind[i] = ("indirect",)
+
+    indirect = any(x == "indirect" for x in succs)
+    succs = [() if x == "indirect" else x for x in succs]
+    span = IDX_SPAN
+    for pat, fn in IDX_SPAN_OF:
+        m_ = pat.search(name)
+        if m_:
+            span = min(IDX_SPAN, fn(m_))
 
     def indexed_touch(i, idx_mode):
         out = set()
@@ -154,7 +168,7 @@ def check_function(name, body, verbose=False):
             if idx_mode & (8 if pos == 0 else (1 << (pos - 1))):
                 for k_, r in regs_of(op):
                     if k_ == "v":
-                        out.update(("v", r + k) for k in range(IDX_SPAN))
+                        out.update(("v", r + k) for k in range(span))
         return out
 
     # Scalar flags.  hipcc's structurizer routes a loop's exits through shared blocks: "s_mov_b64 s[a:b], -1" on the way
@@ -177,11 +191,20 @@ def check_function(name, body, verbose=False):
         return out
 
     flag_op = [None] * n
+    tested = set()
+    for ins in body:
+        ops = split_operands(ins.ops)
+        if ins.mnem in ("s_and_b64", "s_andn2_b64") and len(ops) == 3 and ops[0] == "vcc" and ops[1] == "exec":
+            m = re.fullmatch(r"s\[(\d+):(\d+)\]", ops[2])
+            if m:
+                tested.add(int(m.group(1)))
     for i, ins in enumerate(body):
+        if not use_flags:
+            break
         ops = split_operands(ins.ops)
         if ins.mnem == "s_mov_b64" and len(ops) == 2 and ops[1] in ("-1", "0"):
             m = re.fullmatch(r"s\[(\d+):(\d+)\]", ops[0])
-            if m:
+            if m and int(m.group(1)) in tested:
                 flag_op[i] = ("set", int(m.group(1)), -1 if ops[1] == "-1" else 0)
             elif ops[0] == "vcc":
                 flag_op[i] = ("setvcc", "nz" if ops[1] == "-1" else "z")
@@ -236,9 +259,6 @@ def check_function(name, body, verbose=False):
                 out = {r: (min(v[0] + 1, VMCNT_MAX + 1), v[1]) for r, v in regs.items()}
                 for r in k[1]:
                     out[r] = (0, frozenset([ins.addr]))
-            elif k[0] == "indirect" and ("ind", i) not in reported:
-                reported.add(("ind", i))
-                problems.append("%s: %s -- indirect control flow, not followed" % (name, ins.mnem))
         nexts = succs[i]
         f = flag_op[i]
         if f is not None:
@@ -284,9 +304,20 @@ def check_function(name, body, verbose=False):
             if changed and (s_, facts_out) not in queued:
                 queued.add((s_, facts_out))
                 work.append((s_, facts_out))
+    if indirect and HAND_PIPELINED.search(name) and not any("indirect" in p_ for p_ in problems):
+        problems.append("%s: indirect control flow (s_setpc_b64) in a kernel with hand-written loads: cannot be verified" % name)
+    return problems, visits
+
+
+def check_function(name, body, verbose=False):
+    """-> list of violation strings.  First without any knowledge of scalar flags (every branch both ways: cheap, and
+    enough for kernels whose loads hipcc placed itself); a kernel that fails that way is walked again with the flags."""
+    problems, visits = _analyse(name, body, False)
+    if problems:
+        problems, visits = _analyse(name, body, True)
     if verbose:
-        loads = sum(1 for k in kind if k is not None and k[0] == "vmem" and k[1])
-        print("  %-92s %5d instructions, %3d loads, %6d visits: %s" % (name[:92], n, loads, visits, "ok" if not problems else "BROKEN"))
+        loads = sum(1 for ins in body if _VMEM.match(ins.mnem) and "_load" in ins.mnem)
+        print("  %-92s %5d instructions, %3d loads, %6d visits: %s" % (name[:92], len(body), loads, visits, "ok" if not problems else "BROKEN"))
     return problems
 
 
