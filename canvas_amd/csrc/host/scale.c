@@ -557,13 +557,28 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
             }
         }
     }
+    /* the table by TARGET line in one record each (kernels.h cvk_fir_axis.lrec): one scalar load per line */
+    uint32_t *lrec = NULL;
+    if (streamable && max_taps >= 1 && max_taps <= CVK_FIR_LREC - 2) {
+        lrec = calloc(((size_t)lines + 1) * CVK_FIR_LREC, sizeof *lrec);      /* + one spare record: the kernel loads a line ahead */
+        if (!lrec) { free(foot); free(ntaps); free(rec); return -1; }
+        for (int i = 0; i <= lines; i++) {
+            uint32_t *r = lrec + (size_t)i * CVK_FIR_LREC;
+            const int n = i < lines ? ntaps[i] : 0;
+            r[0] = (uint32_t)n;
+            r[1] = n ? (uint32_t)tb->tap_src[(size_t)i * tb->stride] : (uint32_t)INT_MIN;     /* no taps: never moves the window */
+            for (int k = 0; k < n; k++) memcpy(&r[2 + k], &tb->taps[(size_t)i * tb->stride + k], 4);
+        }
+    }
     const size_t n_l = (size_t)(lines ? lines : 1), n_t = n_l * (size_t)tb->stride;
     const size_t off_src = (n_l * sizeof(int) + 255) & ~(size_t)255;
     const size_t off_tap = off_src + ((n_t * sizeof(int) + 255) & ~(size_t)255);
     const size_t off_foot = off_tap + ((n_t * sizeof(float) + 255) & ~(size_t)255);
     const size_t off_rec = off_foot + ((sizeof(int) * 2 * (size_t)(tiles ? tiles : 1) + 255) & ~(size_t)255);
     const size_t rec_bytes = rec ? ((size_t)rec_n + 1) * (2 * (size_t)nacc + 4) * sizeof *rec : 0;
-    const size_t total = off_rec + (rec_bytes ? rec_bytes : 4);
+    const size_t off_lrec = off_rec + (((rec_bytes ? rec_bytes : 4) + 255) & ~(size_t)255);
+    const size_t lrec_bytes = lrec ? ((size_t)lines + 1) * CVK_FIR_LREC * sizeof *lrec : 0;
+    const size_t total = off_lrec + (lrec_bytes ? lrec_bytes : 4);
     char *dev = NULL;
     hipError_t err = hipMalloc((void **)&dev, total);
     if (err == hipSuccess) err = hipMemcpy(dev, ntaps, n_l * sizeof(int), hipMemcpyHostToDevice);
@@ -571,7 +586,8 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     if (err == hipSuccess) err = hipMemcpy(dev + off_tap, tb->taps, n_t * sizeof(float), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(dev + off_foot, foot, sizeof(int) * 2 * (size_t)(tiles ? tiles : 1), hipMemcpyHostToDevice);
     if (err == hipSuccess && rec_bytes) err = hipMemcpy(dev + off_rec, rec, rec_bytes, hipMemcpyHostToDevice);
-    free(foot); free(ntaps); free(rec);
+    if (err == hipSuccess && lrec_bytes) err = hipMemcpy(dev + off_lrec, lrec, lrec_bytes, hipMemcpyHostToDevice);
+    free(foot); free(ntaps); free(rec); free(lrec);
     if (err != hipSuccess) { if (dev) hipFree(dev); cvs_set_error("FIR table upload: %s", hipGetErrorString(err)); return -1; }
     e->dev = dev;
     e->axis.ntaps = (const int *)dev;
@@ -583,6 +599,7 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     e->axis.rec = rec_bytes ? (const uint32_t *)(dev + off_rec) : NULL;
     e->axis.rec_s0 = rec_s0; e->axis.rec_n = rec_bytes ? rec_n : 0; e->axis.nacc = nacc;
     e->axis.rec_zero_weight = rec_zero_weight;
+    e->axis.lrec = lrec_bytes ? (const uint32_t *)(dev + off_lrec) : NULL;
     e->max_foot = max_foot;
     return 0;
 }

@@ -127,7 +127,12 @@ typedef struct {
     const uint32_t *rec;
     int rec_s0, rec_n, nacc;
     int rec_zero_weight;       /* some tap of the table has weight +-0 (the sweep tells "no tap" by weight 0: not for this table) */
+    /* the table by TARGET line, one record of CVK_FIR_LREC dwords per line (present when streamable and no list is longer
+     * than CVK_FIR_LREC - 2): [0] tap count, [1] first source line (INT_MIN for a line without taps), [2 + k] weight of
+     * tap k; unused entries 0.  One spare all-zero record (count 0) follows the last.  sweep_vh_ops.hip reads one per line. */
+    const uint32_t *lrec;
 } cvk_fir_axis;
+#define CVK_FIR_LREC 16
 typedef struct {
     cvk_view target, source;
     int in_half, out_half;     /* 0: rgba_f32 pixels, 1: rgba_f16 pixels */

@@ -9,8 +9,9 @@
 // record per row (which slots take the row, which lines end on it): 1.7 scalar instructions and 0.4 branches per vector
 // instruction, VALU busy 6 % of the time (profiles/r02).  This one walks the TARGET lines and gathers, which is what the
 // table says literally:
-//   * one wave per workgroup owns 64 target columns (lane = column) and the source columns under them (two tiles of the
-//     horizontal table's footprint list, at most NQ * 64 pixels: lane + 64 q is source pixel q of the lane);
+//   * one wave per workgroup owns 64 target columns (lane = column) or, for large targets, 128 (lane = two columns, PXL)
+//     and the source columns under them (two or four tiles of the horizontal table's footprint list, at most NQ * 64
+//     pixels: lane + 64 q is source pixel q of the lane);
 //   * the source rows a line can reach live WIDENED in a register window win[0 .. W-1] (W = longest vertical list): a line
 //     whose first tap is source row s needs win[k] = row s + k.  First taps never decrease down the table
 //     (cvk_fir_axis.streamable), so the window only ever moves forward: shift by one, take the oldest row of a short ring
@@ -18,12 +19,13 @@
 //     hipcc counts them (a counted vmcnt per row), tools/check_asm_loads.py checks them like every other load;
 //   * V: mid = 0 + win[0] w0 + win[1] w1 ... in ascending source order, exactly the line's n taps (a chain per count: no
 //     padded tap multiplies a row the line does not take, so Inf / NaN spread only where the reference spreads them);
-//     weights, count and first row are scalar loads, requested a line ahead;
+//     weights, count and first row are ONE scalar load per line (cvk_fir_axis.lrec, built by the host), requested a line ahead;
 //   * the line's mid row goes to ONE LDS row (the wave's own: LDS runs a wave's accesses in order, no barrier); each lane
 //     gathers the horizontal taps of its column from it -- sum from 0.0f in ascending tap order, padded taps read a zero
 //     pixel with weight 0 -- and stores its pixel.
-// No accumulator slots, no per-row records, no register indexing, no hand-written waits; two uniform branches per line
-// (window moves? which tap count?).  Algorithmic bytes: source pixel once + target pixel once.
+// No accumulator slots, no per-row records, no register indexing, no hand-written waits.  Per line of 128 pixels the second
+// form executed 455 scalar instructions and 105 branches; this one 47 and 14 (profiles/r03).
+// Algorithmic bytes: source pixel once + target pixel once.
 #include <atomic>
 #include <climits>
 #include "kernels.h"
@@ -34,10 +36,9 @@ namespace {
 
 using cvs::f32x2;
 
-constexpr int kCols = 64;        // target columns per workgroup = lanes of its one wave
-constexpr int kLanes = 64;
+constexpr int kLanes = 64;       // one wave per workgroup; a lane owns one or two target columns
 constexpr int kPF = 3;           // source rows requested ahead of the window
-static_assert(kCols == 2 * CVK_FIR2D_TILE_X, "a strip is two tiles of the footprint table");
+static_assert(kLanes == 2 * CVK_FIR2D_TILE_X, "a strip is two or four tiles of the footprint table");
 
 struct Px { f32x2 lo, hi; };                                             // r,g | b,a
 template <bool INH> struct Raw;
@@ -62,62 +63,88 @@ __device__ __forceinline__ Px vsum(const Px (&win)[W], const float (&w)[W]) {
     return t;
 }
 
-template <int W, int MAXTH, int NQ, bool INH>
+// PXL: target pixels per lane (1: a strip of 64 columns; 2: 128 columns, the lane owns the adjacent pair 2 lane, 2 lane + 1
+// and stores 16 bytes of halfs at once -- half the waves, half the scalar work per pixel; for large targets)
+template <int W, int MAXTH, int NQ, bool INH, int PXL>
 __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows_per_wg, int line0) {
-    static_assert(W >= 1 && W <= 8 && MAXTH >= 1 && MAXTH <= 8 && NQ >= 1 && NQ <= 4, "instances");
+    static_assert(W >= 1 && W <= 8 && MAXTH >= 1 && MAXTH <= 8 && NQ >= 1 && NQ <= 5 && (PXL == 1 || PXL == 2), "instances");
     constexpr int kZero = NQ * kLanes;                                   // the zero pixel behind the mid row
+    constexpr int kStrip = kLanes * PXL;                                 // target columns per workgroup
     __shared__ float4 mid[kZero + 1];
     const int lane = threadIdx.x;
-    const int tcol = fp.tx0 + (int)blockIdx.x * kCols + lane;
-    const bool col_live = tcol <= fp.tx1;
+    // the lane's columns: halfs out -> the adjacent pair 2 lane, 2 lane + 1 (one 16-byte store); floats out -> lane and
+    // lane + 64 (two 16-byte stores, each contiguous across the wave)
+    constexpr bool out_half = INH;                                       // (both frames of a scaler call have the caller's format)
+    constexpr int cstep = PXL == 2 && !out_half ? kLanes : 1;            // from the lane's first column to its second
+    const int tcol = fp.tx0 + (int)blockIdx.x * kStrip + (PXL == 2 && out_half ? 2 * lane : lane);
     const int nlines = fp.ty1 - fp.ty0 + 1;
     // target lines, counted from the vertical table's first (fp.ty0); the launch covers lines line0 .. nlines - 1
     const int ia = line0 + (int)blockIdx.y * rows_per_wg, ib = min(ia + rows_per_wg - 1, nlines - 1);
-    const konst vn = as_konst(fp.v.ntaps), vs = as_konst(fp.v.src), vw = as_konst(fp.v.taps), foot = as_konst(fp.h.foot);
-    const int vstride = fp.v.stride, hstride = fp.h.stride;
+    const konst foot = as_konst(fp.h.foot);
+    const int hstride = fp.h.stride;
 
-    // source columns under the strip: its two tiles of the footprint table (first > last: the tile touches nothing)
-    const int ntiles = (fp.tx1 - fp.tx0) / CVK_FIR2D_TILE_X + 1, t0 = 2 * (int)blockIdx.x;
-    int sx_lo = (int)foot[2 * t0], sx_hi = (int)foot[2 * t0 + 1];
-    if (t0 + 1 < ntiles) {
-        const int lo1 = (int)foot[2 * t0 + 2], hi1 = (int)foot[2 * t0 + 3];
-        if (hi1 >= lo1) {
-            if (sx_hi < sx_lo) { sx_lo = lo1; sx_hi = hi1; }
-            else { sx_lo = min(sx_lo, lo1); sx_hi = max(sx_hi, hi1); }
+    // source columns under the strip: its tiles of the footprint table (first > last: the tile touches nothing)
+    constexpr int kTiles = kStrip / CVK_FIR2D_TILE_X;
+    const int ntiles = (fp.tx1 - fp.tx0) / CVK_FIR2D_TILE_X + 1, t0 = kTiles * (int)blockIdx.x;
+    int sx_lo = INT_MAX, sx_hi = INT_MIN;
+#pragma unroll
+    for (int t = 0; t < kTiles; t++) {
+        if (t0 + t < ntiles) {
+            const int lo1 = (int)foot[2 * (t0 + t)], hi1 = (int)foot[2 * (t0 + t) + 1];
+            if (hi1 >= lo1) { sx_lo = min(sx_lo, lo1); sx_hi = max(sx_hi, hi1); }
         }
     }
     if (sx_hi < sx_lo) sx_lo = sx_hi = fp.source.fx0;                    // no column of the strip has taps: any pixel will do
     const int npx = min(sx_hi - sx_lo + 1, NQ * kLanes);                 // (the host chose NQ to cover them)
 
-    // the horizontal taps of this lane's column: offsets into the mid row, weights; padded taps -> the zero pixel, weight 0
-    const int hline = tcol - fp.tx0;
-    const int hn = col_live ? min(fp.h.ntaps[hline], MAXTH) : 0;
-    int aoff[MAXTH];
-    float wt[MAXTH];
+    // the horizontal taps of this lane's columns: offsets into the mid row, weights; padded taps -> the zero pixel, weight 0
+    bool col_live[PXL];
+    int aoff[PXL][MAXTH];
+    float wt[PXL][MAXTH];
 #pragma unroll
-    for (int k = 0; k < MAXTH; k++) {
-        const bool live = k < hn;
-        const int a = live ? fp.h.src[(size_t)hline * hstride + k] - sx_lo : kZero;
-        aoff[k] = min(max(a, 0), kZero);
-        wt[k] = live ? fp.h.taps[(size_t)hline * hstride + k] : 0.0f;
+    for (int p = 0; p < PXL; p++) {
+        col_live[p] = tcol + p * cstep <= fp.tx1;
+        const int hline = tcol + p * cstep - fp.tx0;
+        const int hn = col_live[p] ? min(fp.h.ntaps[hline], MAXTH) : 0;
+#pragma unroll
+        for (int k = 0; k < MAXTH; k++) {
+            const bool live = k < hn;
+            const int a = live ? fp.h.src[(size_t)hline * hstride + k] - sx_lo : kZero;
+            aoff[p][k] = min(max(a, 0), kZero);
+            wt[p][k] = live ? fp.h.taps[(size_t)hline * hstride + k] : 0.0f;
+        }
     }
     if (lane == 0) mid[kZero] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const bool all_live = fp.tx0 + ((int)blockIdx.x + 1) * kStrip - 1 <= fp.tx1;      // (uniform) every lane's columns exist
 
-    const size_t tpx = fp.out_half ? 8 : 16;
+    constexpr uint32_t tpx = out_half ? 8 : 16;
     char *optr = reinterpret_cast<char *>(fp.target.data) + ((size_t)(tcol - fp.target.fx0)) * tpx
                + (size_t)(fp.ty0 + ia - fp.target.fy0) * (size_t)fp.target.pitch * tpx;
     const size_t trow = (size_t)fp.target.pitch * tpx;
-    const bool out_half = fp.out_half != 0;
+
+    // one record per line (cvk_fir_axis.lrec): count, first source row, weights -- one scalar load, requested a line ahead
+    constexpr int LR = CVK_FIR_LREC;
+    konst lrec = as_konst(fp.v.lrec) + (size_t)ia * LR;
+    struct Line { int n, first; float w[W]; };
+    auto load_line = [&]() __attribute__((always_inline)) {              // the record `lrec` points at; then on to the next
+        Line l;
+        l.n = (int)lrec[0];                                              // (<= W: the host picked the instance by the longest list)
+        l.first = (int)lrec[1];
+#pragma unroll
+        for (int k = 0; k < W; k++) l.w[k] = __uint_as_float(lrec[2 + k]);
+        lrec += LR;                                                      // (a spare record follows the table's last)
+        return l;
+    };
 
     // first and last source row the segment's lines reach (first taps and last taps never decrease down the table)
     int s_lo = INT_MAX, s_hi = INT_MIN;
-    for (int i = ia; i <= ib; i++) {                                     // uniform, scalar loads; segments are short
-        const int n = (int)vn[i];
-        if (n > 0) { s_lo = (int)vs[(size_t)i * vstride]; break; }
-    }
-    for (int i = ib; i >= ia; i--) {
-        const int n = (int)vn[i];
-        if (n > 0) { s_hi = (int)vs[(size_t)i * vstride] + min(n, W) - 1; break; }
+    {
+        konst r = lrec;
+        for (int i = ia; i <= ib; i++, r += LR)                          // uniform, scalar loads; segments are short
+            if ((int)r[0] > 0) { s_lo = (int)r[1]; break; }
+        r = lrec + (size_t)(ib - ia) * LR;
+        for (int i = ib; i >= ia; i--, r -= LR)
+            if ((int)r[0] > 0) { s_hi = (int)r[1] + min((int)r[0], W) - 1; break; }
     }
     const bool any_taps = s_lo <= s_hi;                                  // (uniform) else every line of the segment is zeros
 
@@ -129,17 +156,16 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
     const uint32_t rowb = (uint32_t)fp.source.pitch * PXB;
     const char *rp = reinterpret_cast<const char *>(fp.source.data) + (size_t)(sx_lo - fp.source.fx0) * PXB
                    + (size_t)((any_taps ? s_lo : fp.source.fy0) - fp.source.fy0) * (size_t)rowb;
-    int s_next = any_taps ? s_lo : 0;                                    // the row `rp` points at
-    const int s_last = any_taps ? s_hi : 0;
+    int s_left = any_taps ? s_hi - s_lo : 0;                             // rows after the one `rp` points at
 
     Raw<INH> pf[kPF][NQ];
     Px win[W][NQ];
     auto request = [&](Raw<INH> (&dst)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < NQ; q++) dst[q].v = *reinterpret_cast<const decltype(dst[q].v) *>(rp + uoff[q]);
-        const bool more = s_next < s_last;                               // uniform; past the segment's last row the pointer stays
+        const bool more = s_left > 0;                                    // uniform; past the segment's last row the pointer stays
         rp += more ? rowb : 0u;
-        s_next += more ? 1 : 0;
+        s_left -= more ? 1 : 0;
     };
 #pragma unroll
     for (int d = 0; d < kPF; d++) request(pf[d]);
@@ -148,11 +174,11 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
 #pragma unroll
         for (int q = 0; q < NQ; q++) win[j][q] = Px{ f32x2{ 0.0f, 0.0f }, f32x2{ 0.0f, 0.0f } };
     }
-    int win0 = s_lo - W;                                                 // source row of win[0] (rows before s_lo: never a tap)
-    // The queue of requested rows is a ring whose position is a RUNTIME phase with one copy of the step per phase: moving
-    // a requested row from one register to another would have to wait for it to land (that was the first form: vmcnt(0)
-    // in front of every request), while a phase only ever names the registers the row was requested into.
-    int phase = 0;                                                       // pf[phase] is the oldest request
+    int win0 = any_taps ? s_lo - W : 0;                                  // source row of win[0] (rows before s_lo: never a tap)
+    // The queue of requested rows is a ring, and the ring position is a place in the PROGRAM: the line loop below is
+    // written out once per position, each copy naming the registers its row was requested into.  (Moving a requested row
+    // from one register to another would have to wait for it to land -- the first form: vmcnt(0) in front of every request;
+    // a position kept in a variable came back from hipcc as exactly those moves.)
     auto advance_from = [&](Raw<INH> (&oldest)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j + 1 < W; j++) {
@@ -164,30 +190,15 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
         request(oldest);
         win0++;
     };
-    static_assert(kPF == 3, "three phases written out");
-    auto advance = [&]() __attribute__((always_inline)) {
-        if (phase == 0) { advance_from(pf[0]); phase = 1; }
-        else if (phase == 1) { advance_from(pf[1]); phase = 2; }
-        else { advance_from(pf[2]); phase = 0; }
-    };
 
-    // the line's scalars, requested a line ahead
-    struct Line { int n, first; float w[W]; };
-    auto load_line = [&](int i) __attribute__((always_inline)) {
-        Line l;
-        const int ii = min(i, ib);
-        l.n = min((int)vn[ii], W);
-        l.first = (int)vs[(size_t)ii * vstride];
-#pragma unroll
-        for (int k = 0; k < W; k++) l.w[k] = k < vstride ? __uint_as_float(vw[(size_t)ii * vstride + k]) : 0.0f;
-        return l;
-    };
-    Line cur = load_line(ia);
-    for (int i = ia; i <= ib; i++) {
-        const Line nxt = load_line(i + 1);
-        Px m[NQ];
-        if (cur.n > 0) {
-            while (win0 < cur.first) advance();                          // uniform
+    Line cur = load_line();
+    int left = ib - ia + 1;                                              // lines still to produce
+    // lines until one needs the window moved (true) or the segment is done (false)
+    auto run_lines = [&]() __attribute__((always_inline)) -> bool {
+        for (;;) {
+            if (win0 < cur.first) return true;                           // (a line without taps has first = INT_MIN)
+            const Line nxt = load_line();
+            Px m[NQ];
             // exactly the line's taps: the usual count first
 #define CVK_VSUM(N) { _Pragma("unroll") for (int q = 0; q < NQ; q++) { Px col[W]; _Pragma("unroll") for (int j = 0; j < W; j++) col[j] = win[j][q]; m[q] = vsum<N, W>(col, cur.w); } }
             if (cur.n == W) CVK_VSUM(W)
@@ -197,45 +208,77 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
             else if (W > 4 && cur.n == W - 4) CVK_VSUM((W > 4 ? W - 4 : 1))
             else if (W > 5 && cur.n == W - 5) CVK_VSUM((W > 5 ? W - 5 : 1))
             else if (W > 6 && cur.n == W - 6) CVK_VSUM((W > 6 ? W - 6 : 1))
-            else CVK_VSUM(1)
+            else if (cur.n == 1) CVK_VSUM(1)
+            else {
+#pragma unroll
+                for (int q = 0; q < NQ; q++) m[q] = Px{ f32x2{ 0.0f, 0.0f }, f32x2{ 0.0f, 0.0f } };     // a line without taps is zeros
+            }
 #undef CVK_VSUM
-        } else {
 #pragma unroll
-            for (int q = 0; q < NQ; q++) m[q] = Px{ f32x2{ 0.0f, 0.0f }, f32x2{ 0.0f, 0.0f } };     // a line without taps is zeros
+            for (int q = 0; q < NQ; q++) mid[lane + q * kLanes] = make_float4(m[q].lo.x, m[q].lo.y, m[q].hi.x, m[q].hi.y);
+            __builtin_amdgcn_wave_barrier();                             // (compiler fence; the hardware keeps a wave's LDS accesses in order)
+            float4 t[PXL][MAXTH];
+#pragma unroll
+            for (int p = 0; p < PXL; p++) {
+#pragma unroll
+                for (int k = 0; k < MAXTH; k++) t[p][k] = mid[aoff[p][k]];
+            }
+            f32x2 hlo[PXL], hhi[PXL];
+#pragma unroll
+            for (int p = 0; p < PXL; p++) {
+                hlo[p] = f32x2{ 0.0f, 0.0f }; hhi[p] = f32x2{ 0.0f, 0.0f };
+#pragma unroll
+                for (int k = 0; k < MAXTH; k++) {
+                    const f32x2 wk = { wt[p][k], wt[p][k] };
+                    const f32x2 plo = f32x2{ t[p][k].x, t[p][k].y } * wk, phi = f32x2{ t[p][k].z, t[p][k].w } * wk;
+                    hlo[p] = hlo[p] + plo;
+                    hhi[p] = hhi[p] + phi;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (out_half) {
+                uint32_t h[PXL][2];
+#pragma unroll
+                for (int p = 0; p < PXL; p++) { h[p][0] = cvs::f2h_rz2(hlo[p].x, hlo[p].y); h[p][1] = cvs::f2h_rz2(hhi[p].x, hhi[p].y); }
+                if constexpr (PXL == 2) {
+                    if (all_live || col_live[1]) *reinterpret_cast<uint4 *>(optr) = make_uint4(h[0][0], h[0][1], h[1][0], h[1][1]);
+                    else if (col_live[0]) *reinterpret_cast<uint2 *>(optr) = make_uint2(h[0][0], h[0][1]);
+                } else {
+                    if (all_live || col_live[0]) *reinterpret_cast<uint2 *>(optr) = make_uint2(h[0][0], h[0][1]);
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < PXL; p++)
+                    if (all_live || col_live[p]) *reinterpret_cast<float4 *>(optr + 16 * kLanes * p) = make_float4(hlo[p].x, hlo[p].y, hhi[p].x, hhi[p].y);
+            }
+            optr += trow;
+            cur = nxt;
+            if (--left == 0) return false;
         }
-#pragma unroll
-        for (int q = 0; q < NQ; q++) mid[lane + q * kLanes] = make_float4(m[q].lo.x, m[q].lo.y, m[q].hi.x, m[q].hi.y);
-        __builtin_amdgcn_wave_barrier();                                 // (compiler fence; the hardware keeps a wave's LDS accesses in order)
-        float4 t[MAXTH];
-#pragma unroll
-        for (int k = 0; k < MAXTH; k++) t[k] = mid[aoff[k]];
-        f32x2 hlo = { 0.0f, 0.0f }, hhi = { 0.0f, 0.0f };
-#pragma unroll
-        for (int k = 0; k < MAXTH; k++) {
-            const f32x2 wk = { wt[k], wt[k] };
-            const f32x2 plo = f32x2{ t[k].x, t[k].y } * wk, phi = f32x2{ t[k].z, t[k].w } * wk;
-            hlo = hlo + plo;
-            hhi = hhi + phi;
+    };
+    static_assert(kPF == 3, "three positions written out");
+    if (left > 0) {
+        for (;;) {
+            if (!run_lines()) break;
+            advance_from(pf[0]);
+            if (!run_lines()) break;
+            advance_from(pf[1]);
+            if (!run_lines()) break;
+            advance_from(pf[2]);
         }
-        __builtin_amdgcn_wave_barrier();
-        if (col_live) {
-            if (out_half) *reinterpret_cast<uint2 *>(optr) = make_uint2(cvs::f2h_rz2(hlo.x, hlo.y), cvs::f2h_rz2(hhi.x, hhi.y));
-            else *reinterpret_cast<float4 *>(optr) = make_float4(hlo.x, hlo.y, hhi.x, hhi.y);
-        }
-        optr += trow;
-        cur = nxt;
     }
 }
 
-template <int W, int MAXTH, int NQ, bool INH>
+template <int W, int MAXTH, int NQ, bool INH, int PXL>
 int launch(const cvk_fir2d_params &fp, int line0, int cus, hipStream_t s) {
+    constexpr int kStrip = kLanes * PXL;
     const int cols = fp.tx1 - fp.tx0 + 1, rows = fp.ty1 - fp.ty0 + 1 - line0;
-    const int strips = (cols + kCols - 1) / kCols;
+    const int strips = (cols + kStrip - 1) / kStrip;
     static std::atomic<int> cached{ 0 };            // (several threads may launch at once: pull-queue workers)
     int per_cu = cached.load(std::memory_order_relaxed);
     if (!per_cu) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fir_vh<W, MAXTH, NQ, INH>, kLanes, 0) != hipSuccess || n < 1) n = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_fir_vh<W, MAXTH, NQ, INH, PXL>, kLanes, 0) != hipSuccess || n < 1) n = 1;
         per_cu = n;
         cached.store(n, std::memory_order_relaxed);
     }
@@ -243,38 +286,45 @@ int launch(const cvk_fir2d_params &fp, int line0, int cus, hipStream_t s) {
     int segs = (per_cu * (cus > 0 ? cus : 256)) / strips;
     if (segs < 1) segs = 1;
     int r = (rows + segs - 1) / segs;
-    if (r < 8) r = 8;
+    // measured (1080p -> 4K and 4K -> 1080p, profiles/r03): the wide strips want 16 lines, the narrow ones as many waves as the chip holds
+    if (r < (PXL == 2 ? 16 : 8)) r = PXL == 2 ? 16 : 8;
     if (r > 256) r = 256;
     if (r > rows) r = rows;
     dim3 grid((unsigned)strips, (unsigned)((rows + r - 1) / r));
-    hipLaunchKernelGGL((k_fir_vh<W, MAXTH, NQ, INH>), grid, dim3(kLanes), 0, s, fp, r, line0);
+    hipLaunchKernelGGL((k_fir_vh<W, MAXTH, NQ, INH, PXL>), grid, dim3(kLanes), 0, s, fp, r, line0);
     return (int)hipGetLastError();
 }
 
-// (longest vertical list = window rows, longest horizontal list, source pixels a lane holds per row); a call gets the first that covers it
-struct Instance { int w, maxth, nq; int (*f16)(const cvk_fir2d_params &, int, int, hipStream_t); int (*f32)(const cvk_fir2d_params &, int, int, hipStream_t); };
-#define CVK_VH_INSTANCE(W, T, Q) { W, T, Q, launch<W, T, Q, true>, launch<W, T, Q, false> }
+// (longest vertical list = window rows, longest horizontal list, source pixels a lane holds per row, target pixels per lane);
+// a call gets the first that covers it
+typedef int (*launch_fn)(const cvk_fir2d_params &, int, int, hipStream_t);
+struct Instance { int w, maxth, nq, pxl; launch_fn f16, f32; };
+#define CVK_VH_INSTANCE(W, T, Q, P) { W, T, Q, P, launch<W, T, Q, true, P>, launch<W, T, Q, false, P> }
 const Instance kInstances[] = {
-    CVK_VH_INSTANCE(2, 2, 1), CVK_VH_INSTANCE(3, 4, 1),            // the triangle scaler enlarging (and 1 : 1 shifts)
-    CVK_VH_INSTANCE(3, 4, 2), CVK_VH_INSTANCE(4, 4, 2),            // reducing down to ~0.6x
-    CVK_VH_INSTANCE(3, 4, 3), CVK_VH_INSTANCE(4, 4, 3),            // 0.5x: three taps, 130 source columns under 64
-    CVK_VH_INSTANCE(6, 8, 3), CVK_VH_INSTANCE(8, 8, 4),            // down to ~0.3x; below, the two launches
+    // enlarging (and 1 : 1 shifts): 128 columns per wave, at most ~66 (2x) .. 130 (1x) source pixels under them
+    CVK_VH_INSTANCE(2, 2, 2, 2), CVK_VH_INSTANCE(3, 4, 2, 2), CVK_VH_INSTANCE(3, 4, 3, 2),
+    // reducing: 64 columns per wave (smaller targets: more waves)
+    CVK_VH_INSTANCE(3, 4, 2, 1), CVK_VH_INSTANCE(4, 4, 2, 1),      // down to ~0.6x
+    CVK_VH_INSTANCE(3, 4, 3, 1), CVK_VH_INSTANCE(4, 4, 3, 1),      // 0.5x: three taps, 130 source columns under 64
+    CVK_VH_INSTANCE(6, 8, 3, 1), CVK_VH_INSTANCE(8, 8, 4, 1),      // down to ~0.3x; below, the two launches
 };
 
-// source pixels under a 64-column strip: at most two tiles' footprints
-int strip_foot(const cvk_fir2d_params *fp) { return 2 * fp->max_sw; }
-
+// source pixels under a strip of `tiles` tiles: at most the sum of their footprints
 const Instance *pick(const cvk_fir2d_params *fp) {
-    const int nq = (strip_foot(fp) + kLanes - 1) / kLanes;
-    for (const Instance &in : kInstances)
+    const int cols = fp->tx1 - fp->tx0 + 1;
+    for (const Instance &in : kInstances) {
+        const int tiles = kLanes * in.pxl / CVK_FIR2D_TILE_X;
+        const int nq = (tiles * fp->max_sw + kLanes - 1) / kLanes;
+        if (in.pxl == 2 && cols < 1024) continue;                  // small targets: more, narrower strips
         if (fp->v.max_taps <= in.w && fp->h.max_taps <= in.maxth && nq <= in.nq) return &in;
+    }
     return NULL;
 }
 
 }  // namespace
 
 extern "C" int cvk_fir_vh_supported(const cvk_fir2d_params *fp) {
-    return fp->v.streamable && fp->v.max_taps >= 1 && fp->h.max_taps >= 1 && fp->max_sw >= 1 && pick(fp) != NULL;
+    return fp->in_half == fp->out_half && fp->v.streamable && fp->v.lrec != NULL && fp->v.max_taps >= 1 && fp->h.max_taps >= 1 && fp->max_sw >= 1 && pick(fp) != NULL;
 }
 
 // fp->ty0 is the vertical table's first line; lines fp->ty0 + line0 .. fp->ty1 are produced
