@@ -41,8 +41,8 @@ BYTES_PER_PIXEL_PER_LAYER = 8  # one rgba_f16 read per layer pixel + one written
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU (one C-ABI call)")
     ap.add_argument("--ring", type=int, default=8, help="distinct frame sets resident per GPU")
     ap.add_argument("--width", type=int, default=3840)
@@ -53,17 +53,27 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-extra", action="store_true", help="skip the config 3 / 4 / 5 sub-records")
-    ap.add_argument("--extra-seconds", type=float, default=0.25, help="timed region of each extra config, per rank")
+    ap.add_argument("--extra-seconds", type=float, default=1.5, help="timed region of each extra config, per rank (long enough for a 5 s SMI sampler to see the GPU busy)")
     return ap.parse_args()
 
 
-def cpu_baseline(args, seconds):
+def build_cpu_baseline():
+    """The checker rebuilt for this host's cores (gcc fork + exec): called first thing in main(), BEFORE the process
+    touches the GPU (a process that has initialised the GPU must not fork-and-exec on this pool)."""
+    import oracle
+    try:
+        return oracle.build(force=True, arch="-march=native -mtune=native", out="/tmp/canvas_oracle_native_%d.so" % os.getpid())
+    except Exception:
+        return None
+
+
+def cpu_baseline(args, seconds, so):
     """The oracle (a scalar C port of the reference path) on the host cores, same workload, bounded."""
     import oracle
     from canvas_amd import REC709_RGB_TO_YPBPR, synth
-    so = None
     try:
-        so = oracle.build(force=True, arch="-march=native -mtune=native", out="/tmp/canvas_oracle_native_%d.so" % os.getpid())
+        if so is None:
+            raise RuntimeError("no native build")
         olib = oracle.lib(so)
         flags = "gcc -std=c99 -O3 -march=native -fno-math-errno -ffp-contract=off"
     except Exception:
@@ -157,6 +167,9 @@ def main():
     args = parse()
     from canvas_amd import launch
     launch.ensure_ranks(args.gpus)          # --gpus N without a launcher: become N ranks (never returns in the parent)
+    native_oracle = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        native_oracle = build_cpu_baseline()                           # (the checker, built before the first GPU call)
 
     # stdout carries exactly ONE line, the JSON result: libraries that write banners there (RCCL prints its version,
     # host name and library path on communicator creation) are sent to stderr until the result is ready
@@ -334,7 +347,7 @@ def main():
             res["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             try:
-                res["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+                res["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds, native_oracle)
             except Exception as e:
                 res["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %s" % e}
         sys.stdout.flush()

@@ -40,7 +40,10 @@ def _timed_passes(lib, _lib, streams, one_pass, seconds):
     return n, time.perf_counter() - t0
 
 
-def _record(dist, gather_stats, checksum52, name, workload, frames, px_per_frame, seconds, digest, want, bytes_per_px, note, rank, extra_fields=None):
+def _record(dist, gather_stats, checksum52, name, workload, frames, px_per_frame, seconds, digest, want, bytes_per_px, note, rank, extra_fields=None,
+            moved_bytes_per_px=None, kernels=None):
+    """bytes_per_px: the per-node denominator; moved_bytes_per_px: what the launches actually read and write
+    per pixel by construction (inputs once + outputs once of every LAUNCH; default: the same) -- both fractions are reported."""
     verified = -1 if want is None else int(digest == want)
     stats = gather_stats(dist, frames, checksum52(digest), seconds, extra=(verified,))
     if rank != 0:
@@ -54,6 +57,15 @@ def _record(dist, gather_stats, checksum52, name, workload, frames, px_per_frame
            "bytes_per_px": bytes_per_px,
            "frac_of_8TBps_per_gpu": round(px_per_frame * bytes_per_px / (per_gpu_frame_ms * 1e-3) / HBM_PEAK_BPS, 4),
            "ranks_verified": sum(1 for s in stats if int(s[3]) == 1), "timing": "wall clock around the enqueue + stream syncs", "note": note}
+    moved = bytes_per_px if moved_bytes_per_px is None else moved_bytes_per_px
+    gbs = lambda b: px_per_frame * b / (per_gpu_frame_ms * 1e-3) / 1e9          # noqa: E731
+    rec["roofline"] = {"bound": "hbm", "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s",
+                       "achieved": round(gbs(bytes_per_px), 1), "frac": round(gbs(bytes_per_px) / (HBM_PEAK_BPS / 1e9), 4),
+                       "bytes_per_px": bytes_per_px,
+                       "achieved_moved": round(gbs(moved), 1), "frac_moved": round(gbs(moved) / (HBM_PEAK_BPS / 1e9), 4),
+                       "moved_bytes_per_px": moved, "kernels": kernels,
+                       "note": "frac: on SURVEY 8(d)'s per-node denominator; frac_moved: on the bytes the launches of this implementation "
+                               "read and write by construction (each launch's inputs once + outputs once); wall clock per frame on this rank"}
     if extra_fields:
         rec.update(extra_fields)
     return rec
@@ -84,7 +96,8 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
     rec = _record(dist, gather_stats, checksum52, "config3", "3840x2160 f16 -> 9-tap Gaussian -> Lanczos3 -> 1920x1080 f16",
                   n * len(sources), w * h, dt, digest, verify.stream_fixture("config3_3840x2160_to_1920x1080", g0), 26,
                   "Mpixels/s and bytes are per INPUT pixel; 26 B/px is BASELINE's per-node denominator (blur 8 r + 8 w, scale 8 r + 2 w); "
-                  "a fused form needs 10 B/px (8 r + 2 w)", rank, {"fused_lower_bound_bytes_per_px": 10})
+                  "a fused form needs 10 B/px (8 r + 2 w)", rank, {"fused_lower_bound_bytes_per_px": 10},
+                  moved_bytes_per_px=10, kernels=["k_blur_halve<9, 11, 256, f16> (one launch: VALU-issue bound, DESIGN 4.2)"])
     if rec:
         out.append(rec)
     for d in smalls:
@@ -107,7 +120,7 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
         in_bytes, out_bytes = 8, 8 * (tw * th) / (w * h)
         rec = _record(dist, gather_stats, checksum52, "lanczos3_x" + tag, "3840x2160 f16 -> Lanczos3 -> %dx%d f16 (per-line tap tables)" % (tw, th),
                       n * len(sources), w * h, dt, digest, verify.stream_fixture("lanczos3_3840x2160_x" + tag, g0), round(in_bytes + out_bytes, 2),
-                      "Mpixels/s and bytes are per INPUT pixel: source read once + target written once", rank)
+                      "Mpixels/s and bytes are per INPUT pixel: source read once + target written once", rank, kernels=["k_fir_lanes (one launch)"])
         if rec:
             out.append(rec)
         for d in outs:
@@ -134,7 +147,8 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
     digest = verify.canon_sha256(bigs[0].download(stream).array)
     rec = _record(dist, gather_stats, checksum52, "scaler_x2.00", "1920x1080 f16 -> video_scale_bilinear (triangle) x2 -> 3840x2160 f16",
                   n * len(srcs), w * h, dt, digest, verify.stream_fixture("scaler_1920x1080_x2.00", g0), 10,
-                  "Mpixels/s and bytes are per OUTPUT pixel: source read once (2 B per output px) + target written once; both passes in one launch", rank)
+                  "Mpixels/s and bytes are per OUTPUT pixel: source read once (2 B per output px) + target written once; both passes in one launch", rank,
+                  kernels=["k_fir_vh<2, 2, 2, f16, 2 px per lane> (one launch)"])
     if rec:
         out.append(rec)
     for d in srcs + bigs:
@@ -167,7 +181,7 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
     digest = verify.canon_sha256(slots[0][0].download(stream).array)
     rec = _record(dist, gather_stats, checksum52, "config4", "7680x4320 f16 RGBA 3-layer alpha-over stack, f16 out",
                   n * len(slots), w8 * h8, dt, digest, verify.stream_fixture("config4_7680x4320", g0), 8 * (nl + 1),
-                  "fused chain kernel, plain stack (no colour stage); 2 frame sets of 1.06 GB rotate", rank)
+                  "fused chain kernel, plain stack (no colour stage); 2 frame sets of 1.06 GB rotate", rank, kernels=["k_chain<3 layers, plain> (one launch per frame)"])
     if rec:
         out.append(rec)
     for o, ls in slots:
@@ -190,7 +204,8 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
     rec = _record(dist, gather_stats, checksum52, "config5", "3840x2160 10-node graph (4 sources, colour -> blur -> 4-step composite), frame stream",
                   n * g.ring, w * h, dt, digest, verify.stream_fixture("config5_3840x2160", g0), NODE_BYTES_PER_PIXEL,
                   "72 B/px is BASELINE's per-node denominator; the two launches per frame move %d B/px; frames alternate over two HIP streams" % BYTES_PER_PIXEL,
-                  rank, {"moved_bytes_per_px": BYTES_PER_PIXEL})
+                  rank, {"moved_bytes_per_px": BYTES_PER_PIXEL}, moved_bytes_per_px=BYTES_PER_PIXEL,
+                  kernels=["k_color_flat (8 r + 8 w)", "k_blur<9, 256, f16, over epilogue> (8 r + 3 x 8 r + 8 w)"])
     if rec:
         out.append(rec)
     lib.cvs_stream_destroy(streams[1])

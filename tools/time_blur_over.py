@@ -11,6 +11,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from canvas_amd import _lib, synth  # noqa: E402
 from canvas_amd.device import DeviceFrame  # noqa: E402
 
+if os.environ.get("CANVAS_DIAG") == "1":                   # the diagnostic build: CVS_BLUR_WIDTH / CVS_BLUR_ROWS / CVS_BLUR_WGS_PER_CU are read there only
+    from tools._diag import use_diag_library
+    use_diag_library()
 lib = _lib.load()
 _lib.check(lib.cvs_init(0))
 lib.init_half()
