@@ -139,23 +139,16 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
             const int t = ta + (i - (NT - 1)) / STEP;         // the target row this step completes
             // two rows ahead goes out now; this row's data was requested two steps ago
             const Row far = fetch_row(ys + 2, i + 2 < steps);
-            // the upper layers of the NEXT step's output pixel go out now; this step's were requested a step ago.  Every lane
-            // loads (lanes past the strip's last column read the strip's first: a valid pixel, never used); the layer count
-            // is wave-uniform, one copy of the loads per count instead of a test per layer.
+            // the upper layers of the NEXT step's output pixel go out now; this step's were requested a step ago
             uint2 ov[CVK_BLUR_MAX_OVER];
             if constexpr (EPI) {
+                const bool next_emits = i + 1 >= NT - 1 && i + 1 < steps;
+                const size_t o = (size_t)(t + 1 - bp.target.fy0) * (size_t)bp.target.pitch + (size_t)(tcol - bp.target.fx0);
 #pragma unroll
-                for (int l = 0; l < CVK_BLUR_MAX_OVER; l++) ov[l] = ov_next[l];
-                if (i + 1 >= NT - 1 && i + 1 < steps) {                 // the next step emits (uniform)
-                    const size_t o = (size_t)(t + 1 - bp.target.fy0) * (size_t)bp.target.pitch + (size_t)((out_live ? tcol : xo) - bp.target.fx0);
-                    auto request = [&](auto nc) __attribute__((always_inline)) {
-#pragma unroll
-                        for (int l = 0; l < decltype(nc)::value; l++) ov_next[l] = reinterpret_cast<const uint2 *>(bp.over[l])[o];
-                    };
-                    if (bp.nover == 3) request(std::integral_constant<int, 3>{});
-                    else if (bp.nover == 1) request(std::integral_constant<int, 1>{});
-                    else if (bp.nover == 2) request(std::integral_constant<int, 2>{});
-                    else request(std::integral_constant<int, 4>{});
+                for (int l = 0; l < CVK_BLUR_MAX_OVER; l++) {
+                    ov[l] = ov_next[l];
+                    ov_next[l] = make_uint2(0u, 0u);
+                    if (l < bp.nover && next_emits && out_live) ov_next[l] = reinterpret_cast<const uint2 *>(bp.over[l])[o];
                 }
             }
             float4 (*buf)[PITCH] = rowbuf[i & 1];
@@ -212,17 +205,12 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
                 }
                 if constexpr (EPI) {
                     cvs::px1 acc = { org, oba.x, oba.y };
-                    auto blend = [&](auto nc) __attribute__((always_inline)) {
 #pragma unroll
-                        for (int l = 0; l < decltype(nc)::value; l++) {
+                    for (int l = 0; l < CVK_BLUR_MAX_OVER; l++)
+                        if (l < bp.nover) {
                             const cvs::px1 up = { f32x2{ cvs::h2f(ov[l].x & 0xFFFFu), cvs::h2f(ov[l].x >> 16) }, cvs::h2f(ov[l].y & 0xFFFFu), cvs::h2f(ov[l].y >> 16) };
-                            acc = cvs::over_px_uniform(acc, up);
+                            acc = cvs::over_px(acc, up);
                         }
-                    };
-                    if (bp.nover == 3) blend(std::integral_constant<int, 3>{});
-                    else if (bp.nover == 1) blend(std::integral_constant<int, 1>{});
-                    else if (bp.nover == 2) blend(std::integral_constant<int, 2>{});
-                    else blend(std::integral_constant<int, 4>{});
                     org = acc.rg;
                     oba = f32x2{ acc.b, acc.a };
                 }

@@ -57,9 +57,7 @@ extern "C" int cvk_blur(const cvk_blur_params *bp_in, int cus, void *stream) {
     int env_w = env_w_cached.load(std::memory_order_relaxed), env_rows = env_rows_cached.load(std::memory_order_relaxed);
     if (env_w < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_WIDTH"); env_w = e ? atoi(e) : 0; env_w_cached.store(env_w, std::memory_order_relaxed); }
     if (env_rows < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_ROWS"); env_rows = e ? atoi(e) : 0; env_rows_cached.store(env_rows, std::memory_order_relaxed); }
-    // with the over epilogue two waves per workgroup (eight workgroups per CU instead of four: more barrier groups to switch
-    // between) beat four by 4 % at 4K (0.0948 -> 0.0907 ms with three layers, profiles/r03); the plain blur does not care
-    const int width = (bp.ntaps > 15 || !(bp.ntaps & 1)) ? 256 : env_w ? env_w : (cols <= 128 || bp.nover > 0 ? 128 : 256);      // long and even lists: 256-lane instances only
+    const int width = (bp.ntaps > 15 || !(bp.ntaps & 1)) ? 256 : env_w ? env_w : (cols <= 128 ? 128 : 256);      // long and even lists: 256-lane instances only
     if (bp.rows_per_wg <= 0 && env_rows > 0) bp.rows_per_wg = env_rows;
     return width == 128 ? pick<128>(&bp, cus, (hipStream_t)stream) : pick<256>(&bp, cus, (hipStream_t)stream);
 }

@@ -179,40 +179,6 @@ __device__ __forceinline__ px1 over_px(px1 lo, px1 up) {
     return o;
 }
 
-// The same blend with wave-uniform branches only (the FIR epilogue runs it up to four times per pixel row: the per-lane
-// form cost three exec-mask branches per layer).  x / 1.0f == x on both divide paths, so lanes whose alpha sum is 1 may
-// go through the divide with the others; a whole wave of opaque pixels still skips it.  a == 0: the quotients are
-// Inf / NaN and are replaced by zeros (video_mix.c:333-337), as the per-lane form does.
-__device__ __forceinline__ px1 over_px_uniform(px1 lo, px1 up) {
-    const float alpha_b = up.a;                      // up.a * 1.0f
-    const float alpha_a = lo.a * (1.0f - up.a);
-    const float a = alpha_a + alpha_b;
-    f32x2 nrg = lo.rg * alpha_a + up.rg * alpha_b;
-    float nb = lo.b * alpha_a + up.b * alpha_b;
-    if (wave_any(a != 1.0f)) {
-        const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(nrg.x), __builtin_fabsf(nrg.y)), __builtin_fmaxf(__builtin_fabsf(nb), __builtin_fabsf(a)));
-        const float lw = __builtin_fminf(__builtin_fminf(__builtin_fabsf(nrg.x), __builtin_fabsf(nrg.y)), __builtin_fminf(__builtin_fabsf(nb), __builtin_fabsf(a)));
-        if (!wave_any(!(lw >= 0x1p-60f && hi < 0x1p60f))) {
-            float r = __builtin_amdgcn_rcpf(a);
-            r = __builtin_fmaf(__builtin_fmaf(-a, r, 1.0f), r, r);
-            const f32x2 nd = { -a, -a }, rr = { r, r };
-            f32x2 q = nrg * rr;
-            q = fma2(fma2(nd, q, nrg), rr, q);
-            nrg = fma2(fma2(nd, q, nrg), rr, q);
-            float qb = nb * r;
-            qb = __builtin_fmaf(__builtin_fmaf(-a, qb, nb), r, qb);
-            nb = __builtin_fmaf(__builtin_fmaf(-a, qb, nb), r, qb);
-        } else {
-            rare_path();
-            nrg = f32x2{ nrg.x / a, nrg.y / a };
-            nb = nb / a;
-        }
-    }
-    const bool zero = a == 0.0f;
-    px1 o = { f32x2{ zero ? 0.0f : nrg.x, zero ? 0.0f : nrg.y }, zero ? 0.0f : nb, a };
-    return o;
-}
-
 // main.c:43-71: the stack's f32 result, truncated
 __device__ __forceinline__ u32x4 narrow_pair(px32x2 v) {
     const float big = __builtin_fmaxf(

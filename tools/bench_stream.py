@@ -43,6 +43,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from canvas_amd import _lib, shard
     from canvas_amd.stream import BYTES_PER_PIXEL, NODE_BYTES_PER_PIXEL, GraphStream
+    if os.environ.get("CANVAS_LIB"):                      # A/B runs of tools/: another build of the library (never set by the package)
+        _lib.LIB_PATH = os.environ["CANVAS_LIB"]
     lib = _lib.load()
     if lib.cvs_init(local) != 0:
         raise SystemExit("no HIP device: " + _lib.last_error())
