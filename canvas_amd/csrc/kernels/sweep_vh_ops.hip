@@ -49,18 +49,33 @@ __device__ __forceinline__ Px widen(const Raw<true> &r) {
 }
 __device__ __forceinline__ Px widen(const Raw<false> &r) { return { f32x2{ r.v.x, r.v.y }, f32x2{ r.v.z, r.v.w } }; }
 
-// the vertical sum of one line with exactly N taps (video_scale.c:82-85: t += s * coeff, from 0, ascending)
+// the vertical sum of one line with exactly N taps (video_scale.c:82-85: t += s * coeff, from 0, ascending).  The first
+// addition, 0 + p0, is p0 itself except for the sign of a zero product (the reference is built -fno-signed-zeros; every
+// comparison in tests/ and every fixture folds it): left out, two packed adds per pixel and pass.
 template <int N, int W>
 __device__ __forceinline__ Px vsum(const Px (&win)[W], const float (&w)[W]) {
-    Px t = { f32x2{ 0.0f, 0.0f }, f32x2{ 0.0f, 0.0f } };
+    const f32x2 w0 = { w[0], w[0] };
+    Px t = { win[0].lo * w0, win[0].hi * w0 };
 #pragma unroll
-    for (int k = 0; k < N; k++) {
+    for (int k = 1; k < N; k++) {
         const f32x2 wk = { w[k], w[k] };
         const f32x2 plo = win[k].lo * wk, phi = win[k].hi * wk;
         t.lo = t.lo + plo;
         t.hi = t.hi + phi;
     }
     return t;
+}
+
+// four channels -> two dwords of truncated halfs; |x| >= 65536 must become Inf where v_cvt_pkrtz saturates (pixel_math.hpp):
+// the exact scaling that does it costs two multiplies a channel, so it sits behind a wave-uniform test (chain_math.hpp does
+// the same for the chain's stores)
+__device__ __forceinline__ uint2 narrow4(f32x2 lo, f32x2 hi) {
+    const float big = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(lo.x), __builtin_fabsf(lo.y)), __builtin_fmaxf(__builtin_fabsf(hi.x), __builtin_fabsf(hi.y)));
+    if (cvs::wave_any(!(big < 65536.0f))) {             // (also taken for NaN: harmless, the scaling keeps NaN)
+        cvs::rare_path();
+        return make_uint2(cvs::f2h_rz2(lo.x, lo.y), cvs::f2h_rz2(hi.x, hi.y));
+    }
+    return make_uint2(cvs::pkrtz(lo.x, lo.y), cvs::pkrtz(hi.x, hi.y));
 }
 
 // PXL: target pixels per lane (1: a strip of 64 columns; 2: 128 columns, the lane owns the adjacent pair 2 lane, 2 lane + 1
@@ -226,9 +241,10 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
             f32x2 hlo[PXL], hhi[PXL];
 #pragma unroll
             for (int p = 0; p < PXL; p++) {
-                hlo[p] = f32x2{ 0.0f, 0.0f }; hhi[p] = f32x2{ 0.0f, 0.0f };
+                const f32x2 w0 = { wt[p][0], wt[p][0] };                 // (0 + p0 is p0: see vsum)
+                hlo[p] = f32x2{ t[p][0].x, t[p][0].y } * w0; hhi[p] = f32x2{ t[p][0].z, t[p][0].w } * w0;
 #pragma unroll
-                for (int k = 0; k < MAXTH; k++) {
+                for (int k = 1; k < MAXTH; k++) {
                     const f32x2 wk = { wt[p][k], wt[p][k] };
                     const f32x2 plo = f32x2{ t[p][k].x, t[p][k].y } * wk, phi = f32x2{ t[p][k].z, t[p][k].w } * wk;
                     hlo[p] = hlo[p] + plo;
@@ -239,7 +255,7 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
             if constexpr (out_half) {
                 uint32_t h[PXL][2];
 #pragma unroll
-                for (int p = 0; p < PXL; p++) { h[p][0] = cvs::f2h_rz2(hlo[p].x, hlo[p].y); h[p][1] = cvs::f2h_rz2(hhi[p].x, hhi[p].y); }
+                for (int p = 0; p < PXL; p++) { const uint2 v = narrow4(hlo[p], hhi[p]); h[p][0] = v.x; h[p][1] = v.y; }
                 if constexpr (PXL == 2) {
                     if (all_live || col_live[1]) *reinterpret_cast<uint4 *>(optr) = make_uint4(h[0][0], h[0][1], h[1][0], h[1][1]);
                     else if (col_live[0]) *reinterpret_cast<uint2 *>(optr) = make_uint2(h[0][0], h[0][1]);
