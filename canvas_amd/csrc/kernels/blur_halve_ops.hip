@@ -61,6 +61,9 @@ __device__ __forceinline__ float4 fetch_px(const char *p, bool live) {
 // packed add right behind the packed multiply it depends on costs a hazard slot); the groups keep the products of a long
 // list from occupying 4 x NT registers at once.  Same rounding and order as mul/add in sequence.
 constexpr int CH = 6;
+// (The first addition of a sum, 0 + p0, is p0 itself except for the sign of a zero product -- the reference is built
+// -fno-signed-zeros and every comparison and fixture folds that sign -- so a sum starts with its first product: one packed
+// add per channel pair and pass less, four passes per pixel.)
 template <int NT, class At>
 __device__ __forceinline__ Px fir(const float (&w)[NT], At at) {
     Px o = { f32x2{ 0.0f, 0.0f }, f32x2{ 0.0f, 0.0f } };
@@ -76,8 +79,8 @@ __device__ __forceinline__ Px fir(const float (&w)[NT], At at) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < CH; c++) if (k0 + c < NT) {
-            o.rg = o.rg + prg[c];
-            o.ba = o.ba + pba[c];
+            if (k0 + c == 0) { o.rg = prg[c]; o.ba = pba[c]; }
+            else { o.rg = o.rg + prg[c]; o.ba = o.ba + pba[c]; }
         }
     }
     return o;
@@ -94,7 +97,7 @@ __device__ __forceinline__ f32x2 fir1(const float (&w)[NT], At at) {
         for (int c = 0; c < 2 * CH; c++) if (k0 + c < NT) p[c] = at(k0 + c) * w[k0 + c];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < 2 * CH; c++) if (k0 + c < NT) o = o + p[c];
+        for (int c = 0; c < 2 * CH; c++) if (k0 + c < NT) o = (k0 + c == 0) ? p[c] : o + p[c];
     }
     return o;
 }

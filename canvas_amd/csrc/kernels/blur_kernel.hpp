@@ -178,8 +178,9 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int c = 0; c < CH; c++) if (k0 + c < NT) {
-                    rg = rg + prg[c];
-                    ba = ba + pba[c];
+                    // (0 + p0 is p0 except for the sign of a zero, which the reference's -fno-signed-zeros build leaves open)
+                    if (k0 + c == 0) { rg = prg[c]; ba = pba[c]; }
+                    else { rg = rg + prg[c]; ba = ba + pba[c]; }
                 }
             }
             ring[j].rg = rg;
@@ -199,8 +200,8 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int c = 0; c < CH; c++) if (k0 + c < NT) {
-                        org = org + qrg[c];
-                        oba = oba + qba[c];
+                        if (k0 + c == 0) { org = qrg[c]; oba = qba[c]; }
+                        else { org = org + qrg[c]; oba = oba + qba[c]; }
                     }
                 }
                 if constexpr (EPI) {
