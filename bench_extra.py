@@ -71,6 +71,19 @@ def _record(dist, gather_stats, checksum52, name, workload, frames, px_per_frame
     return rec
 
 
+class GraphStreamView:
+    """A fixed group of a GraphStream's slots rendered with one batch call (its pointer tables are built once)."""
+
+    def __init__(self, graph, slots):
+        import copy
+        self.g = copy.copy(graph)           # shares the frames; own cache of pointer tables
+        self.g._batch_key = None
+        self.slots = slots
+
+    def render(self, stream):
+        return self.g.render_batch(self.slots, stream)
+
+
 def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds):
     from canvas_amd import _lib, synth, verify
     from canvas_amd.device import DeviceFrame, chain_color_over
@@ -87,17 +100,31 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
     sources = [ring[0][1][1]] + [l for i, (_o, ls) in enumerate(ring) for k, l in enumerate(ls) if not (i == 0 and k == 1)]
     smalls = [DeviceFrame((0, 0, w // 2 - 1, h // 2 - 1), np.uint16) for _ in sources]      # 16 x (66 + 17) MB = 1.3 GB + the f32 scratch frame
 
-    def pass3():
-        for src, dst in zip(sources, smalls):
-            _lib.check(lib.cvs_blur_lanczos_f16_dev(dst.ref(), src.ref(), f32p(taps), 9, C.c_float(0.5), C.c_float(0.5), 3, stream), "config 3")
+    # the frames of a pass are independent: they go to the library four at a time (cvs_blur_lanczos_f16_batch_dev: one
+    # launch per batch, row segments sized for all four frames), the batches alternating over two HIP streams -- frames in
+    # flight, as a pull queue with two workers keeps them (profiles/r03/config3_batches.txt: 1 frame per call on 1 stream
+    # 0.084 ms, 4 per call 0.071, 4 per call on 2 streams 0.063)
+    fp16 = C.POINTER(_lib.rgba_frame_f16_t)
+    per = 4
+    streams3 = [stream, lib.cvs_stream_create()]
+    b3 = [((fp16 * per)(*[C.pointer(d.c) for d in smalls[a:a + per]]), (fp16 * per)(*[C.pointer(d.c) for d in sources[a:a + per]]))
+          for a in range(0, len(sources) - per + 1, per)]
+    assert len(b3) * per == len(sources)
 
-    n, dt = _timed_passes(lib, _lib, [stream], pass3, seconds)
+    def pass3():
+        for k, (dst, src) in enumerate(b3):
+            _lib.check(lib.cvs_blur_lanczos_f16_batch_dev(dst, src, per, f32p(taps), 9, C.c_float(0.5), C.c_float(0.5), 3, streams3[k % 2]), "config 3")
+
+    n, dt = _timed_passes(lib, _lib, streams3, pass3, seconds)
     digest = verify.canon_sha256(smalls[0].download(stream).array)
+    lib.cvs_stream_destroy(streams3[1])
     rec = _record(dist, gather_stats, checksum52, "config3", "3840x2160 f16 -> 9-tap Gaussian -> Lanczos3 -> 1920x1080 f16",
                   n * len(sources), w * h, dt, digest, verify.stream_fixture("config3_3840x2160_to_1920x1080", g0), 26,
                   "Mpixels/s and bytes are per INPUT pixel; 26 B/px is BASELINE's per-node denominator (blur 8 r + 8 w, scale 8 r + 2 w); "
-                  "a fused form needs 10 B/px (8 r + 2 w)", rank, {"fused_lower_bound_bytes_per_px": 10},
-                  moved_bytes_per_px=10, kernels=["k_blur_halve<9, 11, 256, f16> (one launch: VALU-issue bound, DESIGN 4.2)"])
+                  "a fused form needs 10 B/px (8 r + 2 w); the 16 independent frames of a pass go to the library four at a time "
+                  "(cvs_blur_lanczos_f16_batch_dev: one launch per batch), the batches alternating over two HIP streams", rank,
+                  {"fused_lower_bound_bytes_per_px": 10, "frames_per_launch": 4, "streams": 2},
+                  moved_bytes_per_px=10, kernels=["k_blur_halve<9, 11, 256, f16> (four frames per launch: latency / VALU-issue bound, DESIGN 4.2)"])
     if rec:
         out.append(rec)
     for d in smalls:
@@ -191,21 +218,28 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
 
     # ---------------------------------------------------------------- config 5
     donors = [d for pair in zip(donors0, donors1) for d in pair]
-    g = GraphStream(w, h, ring=4, matrix=matrix, first_frame=g0, exact_slots=1, donors=donors)      # 4 x 6 x 66 MB = 1.6 GB
+    g = GraphStream(w, h, ring=8, matrix=matrix, first_frame=g0, exact_slots=1, donors=donors)      # 8 x 6 x 66 MB = 3.2 GB
     streams = [stream, lib.cvs_stream_create()]
     assert g.ring % len(streams) == 0          # slot i always on stream i % 2: no two streams ever share a slot's buffers
 
+    # the ring's frames are independent: their blur + over launches go as ONE batch (cvs_blur_over_f16_batch_dev); two
+    # batches alternate over two streams
+    half = g.ring // 2
+    groups = [list(range(0, half)), list(range(half, g.ring))]
+    gs = [GraphStreamView(g, grp) for grp in groups]
+
     def pass5():
-        for i in range(g.ring):
-            g.render(i, streams[i % len(streams)])
+        for k, view in enumerate(gs):
+            view.render(streams[k % len(streams)])
 
     n, dt = _timed_passes(lib, _lib, streams, pass5, seconds)
     digest = verify.canon_sha256(g.slots[0]["out"].download(streams[0]).array)
     rec = _record(dist, gather_stats, checksum52, "config5", "3840x2160 10-node graph (4 sources, colour -> blur -> 4-step composite), frame stream",
                   n * g.ring, w * h, dt, digest, verify.stream_fixture("config5_3840x2160", g0), NODE_BYTES_PER_PIXEL,
-                  "72 B/px is BASELINE's per-node denominator; the two launches per frame move %d B/px; frames alternate over two HIP streams" % BYTES_PER_PIXEL,
+                  "72 B/px is BASELINE's per-node denominator; the launches move %d B/px; eight frames in two groups of four on two HIP streams: "
+                  "a colour launch per frame, one blur + over launch per group (cvs_blur_over_f16_batch_dev)" % BYTES_PER_PIXEL,
                   rank, {"moved_bytes_per_px": BYTES_PER_PIXEL}, moved_bytes_per_px=BYTES_PER_PIXEL,
-                  kernels=["k_color_flat (8 r + 8 w)", "k_blur<9, 256, f16, over epilogue> (8 r + 3 x 8 r + 8 w)"])
+                  kernels=["k_color_flat (8 r + 8 w)", "k_blur<9, 256, f16, over epilogue> (8 r + 3 x 8 r + 8 w; four frames per launch)"])
     if rec:
         out.append(rec)
     lib.cvs_stream_destroy(streams[1])

@@ -161,6 +161,8 @@ SIGNATURES = {
     "cvs_resample_lanczos_f32_dev": (C.c_int, [_F32, _F32, C.c_float, C.c_float, C.c_int, _vp]),
     "cvs_resample_lanczos_f16_dev": (C.c_int, [_F16, _F16, C.c_float, C.c_float, C.c_int, _vp]),
     "cvs_blur_lanczos_f16_dev": (C.c_int, [_F16, _F16, _f32p, C.c_int, C.c_float, C.c_float, C.c_int, _vp]),
+    "cvs_blur_over_f16_batch_dev": (C.c_int, [P(_F16), P(_F16), _f32p, C.c_int, P(_F16), C.c_int, C.c_int, _vp]),
+    "cvs_blur_lanczos_f16_batch_dev": (C.c_int, [P(_F16), P(_F16), C.c_int, _f32p, C.c_int, C.c_float, C.c_float, C.c_int, _vp]),
     "cvs_fir_path_override": (None, [C.c_int]),
     # (3) fused chain
     "cvs_chain_color_over_f16_dev": (C.c_int, [P(chain_job), C.c_int, _f32p, C.c_int, C.c_int, _vp]),

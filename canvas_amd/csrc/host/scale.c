@@ -807,8 +807,9 @@ static bool blur_has_fast_kernel(const float *taps, int ntaps) {
 }
 
 /* `over`: nover f16 buffers with the target's layout, blended over the blur result before the store (f16 in/out only) */
-static int blur_fused_over(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
-                           const box2i *win, const float *taps, int ntaps, const void *const *over, int nover, hipStream_t s) {
+static int blur_fused_over_batch(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
+                                 const box2i *win, const float *taps, int ntaps, const void *const *over, int nover,
+                                 const cvk_frame_batch *batch, hipStream_t s) {
     /* one tap list for every line: the register-window kernel, when it has an instance for this length */
     if (blur_has_fast_kernel(taps, ntaps)) {
         cvk_blur_params bp;
@@ -822,12 +823,16 @@ static int blur_fused_over(void *tdata, const box2i *tfull, int out_half, const 
         bp.sx0 = sw->min.x; bp.sy0 = sw->min.y; bp.sx1 = sw->max.x; bp.sy1 = sw->max.y;
         bp.ntaps = ntaps;
         memcpy(bp.taps, taps, sizeof(float) * (size_t)ntaps);
+        if (batch) {
+            if (!(ntaps & 1) || ntaps > 31) return 1;                 /* the batched form exists for the odd lists of blur_kernel.hpp */
+            bp.batch = *batch;
+        }
         int rc = cvk_blur(&bp, cvs_cus(), s);
         if (rc != 0) { cvs_set_error("blur launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
         t_fir_kernel = CVS_FIR_KERNEL_WINDOW;
         return 0;
     }
-    if (nover > 0) return 1;        /* the gather kernel has no epilogue: the caller goes node by node */
+    if (nover > 0 || batch) return 1;   /* the gather kernel has no epilogue and takes one frame: the caller goes node by node / frame by frame */
     const uint64_t th = fnv1a(taps, sizeof(float) * (size_t)ntaps);
     axis_key kh = make_key(1, 0, ntaps, th, win->min.x, win->max.x, sw->min.x, sw->max.x, CVK_FIR2D_TILE_X);
     axis_key kv = make_key(1, 0, ntaps, th, win->min.y, win->max.y, sw->min.y, sw->max.y, CVK_FIR2D_TILE_Y);
@@ -840,9 +845,26 @@ static int blur_fused_over(void *tdata, const box2i *tfull, int out_half, const 
     return rc;
 }
 
+static int blur_fused_over(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
+                           const box2i *win, const float *taps, int ntaps, const void *const *over, int nover, hipStream_t s) {
+    return blur_fused_over_batch(tdata, tfull, out_half, sdata, sfull, sw, in_half, win, taps, ntaps, over, nover, NULL, s);
+}
+
 static int blur_fused(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
                       const box2i *win, const float *taps, int ntaps, hipStream_t s) {
     return blur_fused_over(tdata, tfull, out_half, sdata, sfull, sw, in_half, win, taps, ntaps, NULL, 0, s);
+}
+
+/* ---- batches of frames of one geometry (kernels.h cvk_frame_batch) ---- */
+static bool same_box(const box2i *a, const box2i *b) { return memcmp(a, b, sizeof *a) == 0; }
+/* does any output of the run overlap any input of the run (another frame's, or its own at a shifted address)? */
+static bool batch_has_hazard(void *const *outs, size_t out_bytes, const void *const *ins, size_t in_bytes, int nouts, int nins) {
+    for (int i = 0; i < nouts; i++) {
+        const char *o = outs[i];
+        for (int j = 0; j < nins; j++) { const char *q = ins[j]; if (q && o < q + in_bytes && q < o + out_bytes) return true; }
+        for (int j = 0; j < i; j++) { const char *q = outs[j]; if (o < q + out_bytes && q < o + out_bytes) return true; }
+    }
+    return false;
 }
 
 static int lanczos_fused(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
@@ -1044,5 +1066,104 @@ CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame
     if (rc == 0) target->current_window = target->full_window;
     cvs_pool_free(mid.data, s);
     if (rc != 0) box2i_set_empty(&target->current_window);
+    return rc;
+}
+
+/* cvs_blur_over_f16_dev for `count` independent frames in as few launches as possible: frames that share one geometry
+ * (every window equal to the first frame's, whole-frame layers) and do not feed each other go CVK_FRAME_BATCH at a time
+ * into ONE launch whose segments are sized for the whole batch (fewer halo rows re-filtered per frame); anything else is
+ * carried out frame by frame, exactly as `count` single calls would.  overlays: count x noverlays pointers, frame-major. */
+CVS_EXPORT int cvs_blur_over_f16_batch_dev(rgba_frame_f16 *const *outs, const rgba_frame_f16 *const *sources, const float *taps, int ntaps,
+                                           const rgba_frame_f16 *const *overlays, int noverlays, int count, cvs_stream_t stream) {
+    if (count <= 0) return 0;
+    if (!outs || !sources || ntaps < 1 || !taps || noverlays < 0 || (noverlays > 0 && !overlays)) { cvs_set_error("blur+over batch: bad arguments"); return -1; }
+    if (cvs_enter() != 0) { for (int i = 0; i < count; i++) box2i_set_empty(&outs[i]->current_window); return -1; }
+    hipStream_t s = cvs_pick_stream(stream);
+    const box2i *full = &outs[0]->full_window;
+    bool uniform = count > 1 && noverlays >= 1 && noverlays <= CVK_BLUR_MAX_OVER && !box2i_is_empty(full) && blur_has_fast_kernel(taps, ntaps) && (ntaps & 1);
+    for (int i = 0; uniform && i < count; i++) {
+        uniform = same_box(&outs[i]->full_window, full) && same_box(&sources[i]->full_window, &sources[0]->full_window) &&
+                  same_box(&sources[i]->current_window, full) && same_box(&sources[0]->full_window, full);
+        for (int l = 0; uniform && l < noverlays; l++) {
+            const rgba_frame_f16 *ov = overlays[(size_t)i * noverlays + l];
+            uniform = same_box(&ov->full_window, full) && same_box(&ov->current_window, full);
+        }
+    }
+    int rc = 0, done = 0;
+    if (uniform) {
+        const size_t bytes = cvs_box_pixels(full) * sizeof(rgba_f16);
+        while (rc == 0 && done < count) {
+            const int n = count - done < CVK_FRAME_BATCH ? count - done : CVK_FRAME_BATCH;
+            cvk_frame_batch b;
+            memset(&b, 0, sizeof b);
+            void *o[CVK_FRAME_BATCH]; const void *in[CVK_FRAME_BATCH * (1 + CVK_BLUR_MAX_OVER)]; int nin = 0;
+            b.n = n;
+            for (int i = 0; i < n; i++) {
+                b.source[i] = sources[done + i]->data; b.target[i] = outs[done + i]->data; o[i] = outs[done + i]->data; in[nin++] = sources[done + i]->data;
+                for (int l = 0; l < noverlays; l++) { b.over[i][l] = overlays[(size_t)(done + i) * noverlays + l]->data; in[nin++] = b.over[i][l]; }
+            }
+            if (n < 2 || batch_has_hazard(o, bytes, in, bytes, n, nin)) break;     /* the rest frame by frame */
+            rc = blur_fused_over_batch(b.target[0], full, 1, b.source[0], &sources[done]->full_window, &sources[done]->current_window, 1, full,
+                                       taps, ntaps, b.over[0], noverlays, &b, s);
+            if (rc == 1) { rc = 0; break; }
+            if (rc == 0) { for (int i = 0; i < n; i++) outs[done + i]->current_window = *full; done += n; }
+        }
+    }
+    for (; rc == 0 && done < count; done++)
+        rc = cvs_blur_over_f16_dev(outs[done], sources[done], taps, ntaps, noverlays ? overlays + (size_t)done * noverlays : NULL, noverlays, stream);
+    if (rc != 0) for (int i = done; i < count; i++) box2i_set_empty(&outs[i]->current_window);
+    return rc;
+}
+
+/* cvs_blur_lanczos_f16_dev for `count` independent frames: the one-sweep form (odd blur, halving on both axes) takes
+ * CVK_FRAME_BATCH frames of one geometry per launch; anything else frame by frame. */
+CVS_EXPORT int cvs_blur_lanczos_f16_batch_dev(rgba_frame_f16 *const *targets, const rgba_frame_f16 *const *sources, int count,
+                                              const float *taps, int ntaps, float fx, float fy, int ksize, cvs_stream_t stream) {
+    if (count <= 0) return 0;
+    if (!targets || !sources || ntaps < 1 || !taps || !(fx > 0.0f) || !(fy > 0.0f) || ksize < 1) { cvs_set_error("blur+lanczos batch: bad arguments"); return -1; }
+    if (cvs_enter() != 0) { for (int i = 0; i < count; i++) box2i_set_empty(&targets[i]->current_window); return -1; }
+    hipStream_t s = cvs_pick_stream(stream);
+    int rc = 0, done = 0;
+    bool uniform = count > 1 && fx == 0.5f && fy == 0.5f && (ntaps & 1) && !(ntaps == 1 && taps[0] == 1.0f) && !(atomic_load(&g_fir_path) & CVS_FIR_PATH_TABLES) &&
+                   !box2i_is_empty(&sources[0]->current_window) && !box2i_is_empty(&targets[0]->full_window);
+    for (int i = 1; uniform && i < count; i++)
+        uniform = same_box(&targets[i]->full_window, &targets[0]->full_window) && same_box(&sources[i]->full_window, &sources[0]->full_window) &&
+                  same_box(&sources[i]->current_window, &sources[0]->current_window);
+    if (uniform) {
+        fir_filter f = { NULL, 0, 0 };
+        filter_createLanczos(0.5f, ksize, 0.0f, &f);
+        const box2i *tf = &targets[0]->full_window, *sw = &sources[0]->current_window;
+        bool usable = f.coeff && f.center == f.width / 2 && cvk_blur_halve_supported(ntaps, f.width) &&
+                      tf->min.x > -(1 << 22) && tf->max.x < (1 << 22) && tf->min.y > -(1 << 22) && tf->max.y < (1 << 22);
+        for (int k = 0; usable && k < f.width; k++) usable = isfinite(f.coeff[k]);
+        for (int k = 0; usable && k < ntaps; k++) usable = isfinite(taps[k]);
+        const size_t sbytes = cvs_box_pixels(&sources[0]->full_window) * sizeof(rgba_f16), tbytes = cvs_box_pixels(tf) * sizeof(rgba_f16);
+        while (usable && rc == 0 && done < count) {
+            const int n = count - done < CVK_FRAME_BATCH ? count - done : CVK_FRAME_BATCH;
+            cvk_blur_halve_params bp;
+            memset(&bp, 0, sizeof bp);
+            void *o[CVK_FRAME_BATCH]; const void *in[CVK_FRAME_BATCH];
+            for (int i = 0; i < n; i++) { bp.batch.source[i] = in[i] = sources[done + i]->data; bp.batch.target[i] = o[i] = targets[done + i]->data; }
+            if (n < 2 || batch_has_hazard(o, tbytes, in, sbytes, n, n)) break;
+            bp.batch.n = n;
+            bp.target = cvs_view(targets[done]->data, tf);
+            bp.source = cvs_view((void *)sources[done]->data, &sources[done]->full_window);
+            bp.in_half = 1; bp.out_half = 1;
+            bp.tx0 = tf->min.x; bp.ty0 = tf->min.y; bp.tx1 = tf->max.x; bp.ty1 = tf->max.y;
+            bp.sx0 = sw->min.x; bp.sy0 = sw->min.y; bp.sx1 = sw->max.x; bp.sy1 = sw->max.y;
+            bp.ntaps1 = ntaps; bp.ntaps2 = f.width;
+            memcpy(bp.taps1, taps, sizeof(float) * (size_t)ntaps);
+            memcpy(bp.taps2, f.coeff, sizeof(float) * (size_t)f.width);
+            int krc = cvk_blur_halve(&bp, cvs_cus(), s);
+            if (krc != 0) { cvs_set_error("blur + halving launch failed: %s", hipGetErrorString((hipError_t)krc)); rc = -1; break; }
+            for (int i = 0; i < n; i++) targets[done + i]->current_window = targets[done + i]->full_window;
+            t_fir_kernel = CVS_FIR_KERNEL_HALVE;
+            done += n;
+        }
+        filter_free(&f);
+    }
+    for (; rc == 0 && done < count; done++)
+        rc = cvs_blur_lanczos_f16_dev(targets[done], sources[done], taps, ntaps, fx, fy, ksize, stream);
+    if (rc != 0) for (int i = done; i < count; i++) box2i_set_empty(&targets[i]->current_window);
     return rc;
 }

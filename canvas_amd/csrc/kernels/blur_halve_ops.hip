@@ -135,9 +135,15 @@ __global__ __launch_bounds__(W) void k_blur_halve(cvk_blur_halve_params bp) {
     const size_t srow = (size_t)bp.source.pitch * SPX;
     const int scol = sfirst + lane;
     const bool scol_live = scol >= bp.sx0 && scol <= bp.sx1;
-    const char *sbase = reinterpret_cast<const char *>(bp.source.data) + (ptrdiff_t)(scol - bp.source.fx0) * (ptrdiff_t)SPX;
+    // a batch of frames: grid.z picks the frame (uniform)
+    // (read through the kernel-argument segment: indexing the by-value struct with blockIdx.z sends it to scratch memory)
+    typedef const cvk_blur_halve_params __attribute__((address_space(4))) *kargs_t;
+    const kargs_t ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();          // `bp` is the kernel's first and only argument
+    const void *src_data = bp.batch.n ? ka->batch.source[blockIdx.z] : bp.source.data;
+    void *dst_data = bp.batch.n ? ka->batch.target[blockIdx.z] : bp.target.data;
+    const char *sbase = reinterpret_cast<const char *>(src_data) + (ptrdiff_t)(scol - bp.source.fx0) * (ptrdiff_t)SPX;
     const size_t tpx = bp.out_half ? 8 : 16;
-    char *tbase = reinterpret_cast<char *>(bp.target.data) + (ptrdiff_t)(tcol - bp.target.fx0) * (ptrdiff_t)tpx + (size_t)pair * (tpx / 2);
+    char *tbase = reinterpret_cast<char *>(dst_data) + (ptrdiff_t)(tcol - bp.target.fx0) * (ptrdiff_t)tpx + (size_t)pair * (tpx / 2);
     const size_t trow = (size_t)bp.target.pitch * tpx;
 
     if (lane < PITCH - W) { rowS[0][W + lane] = make_float4(0.f, 0.f, 0.f, 0.f); rowS[1][W + lane] = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -236,9 +242,14 @@ int launch(cvk_blur_halve_params bp, int cus, hipStream_t s) {
         mine = bp.in_half ? resident_per_cu(k_blur_halve<NT1, NT2, W, true>, W) : resident_per_cu(k_blur_halve<NT1, NT2, W, false>, W);
         cached.store(mine, std::memory_order_relaxed);
     }
+#ifdef CVS_DIAG
+    if (bp.rows_per_wg <= 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_HALVE_ROWS"); if (e && atoi(e) > 0) bp.rows_per_wg = atoi(e); }
+#endif
+    const int nframes = bp.batch.n > 0 ? bp.batch.n : 1;
     if (bp.rows_per_wg <= 0) {
-        // one wave of resident workgroups; a segment never shorter than its own halo (NT1 + NT2 - 2 source rows = that many / 2 target rows)
-        int segs = (mine * cus) / strips;
+        // one wave of resident workgroups over all the frames of the batch; a segment never shorter than its own halo
+        // (NT1 + NT2 - 2 source rows = that many / 2 target rows)
+        int segs = (mine * cus) / (strips * nframes);
         if (segs < 1) segs = 1;
         int r = (rows + segs - 1) / segs;
         const int lo = (NT1 + NT2) / 2;
@@ -246,7 +257,7 @@ int launch(cvk_blur_halve_params bp, int cus, hipStream_t s) {
         if (r > rows) r = rows;
         bp.rows_per_wg = r;
     }
-    dim3 grid((unsigned)strips, (unsigned)((rows + bp.rows_per_wg - 1) / bp.rows_per_wg));
+    dim3 grid((unsigned)strips, (unsigned)((rows + bp.rows_per_wg - 1) / bp.rows_per_wg), (unsigned)nframes);
     if (bp.in_half) hipLaunchKernelGGL((k_blur_halve<NT1, NT2, W, true>), grid, dim3(W), 0, s, bp);
     else            hipLaunchKernelGGL((k_blur_halve<NT1, NT2, W, false>), grid, dim3(W), 0, s, bp);
     return (int)hipGetLastError();

@@ -89,6 +89,18 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
 #pragma unroll
     for (int k = 0; k < NT; k++) w[k] = bp.taps[k];
 
+    // a batch of frames: grid.z picks the frame (uniform)
+    // (the pointer arrays are read through the kernel-argument segment itself: indexing the by-value struct with
+    // blockIdx.z made hipcc copy all of it to scratch memory, 688 bytes per lane)
+    const int z = (int)blockIdx.z;
+    typedef const cvk_blur_params __attribute__((address_space(4))) *kargs_t;
+    const kargs_t ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();          // `bp` is the kernel's first and only argument
+    const void *src_data = bp.batch.n ? ka->batch.source[z] : bp.source.data;
+    void *dst_data = bp.batch.n ? ka->batch.target[z] : bp.target.data;
+    const void *over_data[CVK_BLUR_MAX_OVER];
+#pragma unroll
+    for (int l = 0; l < CVK_BLUR_MAX_OVER; l++) over_data[l] = bp.batch.n ? ka->batch.over[z][l] : bp.over[l];
+
     constexpr size_t SPX = INH ? 8 : 16;
     const size_t srow = (size_t)bp.source.pitch * SPX;
     // lane loads source columns sfirst + lane + r * W, r < STEP
@@ -98,10 +110,10 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
     for (int r = 0; r < STEP; r++) {
         const int scol = sfirst + lane + r * W;
         col_live[r] = scol >= bp.sx0 && scol <= bp.sx1;
-        sbase[r] = reinterpret_cast<const char *>(bp.source.data) + (ptrdiff_t)(scol - bp.source.fx0) * (ptrdiff_t)SPX;
+        sbase[r] = reinterpret_cast<const char *>(src_data) + (ptrdiff_t)(scol - bp.source.fx0) * (ptrdiff_t)SPX;
     }
     const size_t tpx = bp.out_half ? 8 : 16;
-    char *tbase = reinterpret_cast<char *>(bp.target.data) + (ptrdiff_t)(tcol - bp.target.fx0) * (ptrdiff_t)tpx;
+    char *tbase = reinterpret_cast<char *>(dst_data) + (ptrdiff_t)(tcol - bp.target.fx0) * (ptrdiff_t)tpx;
     const size_t trow = (size_t)bp.target.pitch * tpx;
 
     if (lane < PITCH - W) {
@@ -148,7 +160,7 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
                 for (int l = 0; l < CVK_BLUR_MAX_OVER; l++) {
                     ov[l] = ov_next[l];
                     ov_next[l] = make_uint2(0u, 0u);
-                    if (l < bp.nover && next_emits && out_live) ov_next[l] = reinterpret_cast<const uint2 *>(bp.over[l])[o];
+                    if (l < bp.nover && next_emits && out_live) ov_next[l] = reinterpret_cast<const uint2 *>(over_data[l])[o];
                 }
             }
             float4 (*buf)[PITCH] = rowbuf[i & 1];
@@ -253,8 +265,9 @@ int launch(cvk_blur_params bp, int cus, hipStream_t s) {
         if (!mine) mine = bp.in_half ? resident_per_cu(k_blur<NT, W, true, false, STEP>, W) : resident_per_cu(k_blur<NT, W, false, false, STEP>, W);
         cached.store(mine, std::memory_order_relaxed);
     }
+    const int nframes = bp.batch.n > 0 ? bp.batch.n : 1;
     if (bp.rows_per_wg <= 0) {
-        int segs = (mine * cus) / strips;
+        int segs = (mine * cus) / (strips * nframes);
         if (segs < 1) segs = 1;
         int r = (rows + segs - 1) / segs;
         const int lo = (NT - 1) / STEP;            // halo rows cost at most as much as the rows produced
@@ -262,7 +275,7 @@ int launch(cvk_blur_params bp, int cus, hipStream_t s) {
         if (r > rows) r = rows;
         bp.rows_per_wg = r;
     }
-    dim3 grid((unsigned)strips, (unsigned)((rows + bp.rows_per_wg - 1) / bp.rows_per_wg));
+    dim3 grid((unsigned)strips, (unsigned)((rows + bp.rows_per_wg - 1) / bp.rows_per_wg), (unsigned)nframes);
     if constexpr (STEP == 1) {
         if (epi) { hipLaunchKernelGGL((k_blur<NT, W, true, true, 1>), grid, dim3(W), 0, s, bp); return (int)hipGetLastError(); }     // f16 in, f16 out
     }

@@ -155,9 +155,21 @@ int cvk_fir_vh(const cvk_fir2d_params *fp, int line0, int cus, void *stream);
 size_t cvk_fir2d_lds_bytes(const cvk_fir2d_params *fp);     /* dynamic LDS the launch would need */
 int cvk_fir2d(const cvk_fir2d_params *fp, void *stream);
 
+/* Several frames of one geometry in ONE launch of a strip x segment kernel (grid.z = frame): the chip is filled by
+ * frames x strips x segments workgroups, so the segments of each frame are taller and re-filter fewer halo rows
+ * (a 4K frame alone: 48 useful source rows per 65 of config 3's sweep; four frames: 192 per 209).  n == 0: one frame,
+ * the views' own data pointers. */
+#define CVK_FRAME_BATCH 8
+#define CVK_BLUR_MAX_OVER 4
+typedef struct {
+    int n, pad;
+    const void *source[CVK_FRAME_BATCH];
+    void *target[CVK_FRAME_BATCH];
+    const void *over[CVK_FRAME_BATCH][CVK_BLUR_MAX_OVER];
+} cvk_frame_batch;
+
 /* separable FIR with one tap list for every line (3..31 taps odd, 4..16 even, all finite), optionally decimating by 2:
  * both passes in one sweep, the vertical window in registers.  Source pixels outside (sx0..sx1, sy0..sy1) count as skipped taps. */
-#define CVK_BLUR_MAX_OVER 4
 typedef struct {
     cvk_view target, source;
     int in_half, out_half;     /* 0: rgba_f32 pixels, 1: rgba_f16 pixels */
@@ -170,6 +182,7 @@ typedef struct {
     int nover;                 /* f16 frames blended over the blur result before the (f16) store; 0..CVK_BLUR_MAX_OVER */
     int pad;
     const void *over[CVK_BLUR_MAX_OVER];       /* rgba_f16 device buffers laid out exactly like `target` */
+    cvk_frame_batch batch;                     /* batch.n frames of this geometry (their pointers replace target / source / over) */
 } cvk_blur_params;
 int cvk_blur_supported(int ntaps, int step);
 int cvk_blur(const cvk_blur_params *bp, int cus, void *stream);
@@ -186,6 +199,7 @@ typedef struct {
     int rows_per_wg;           /* 0: let the launcher choose */
     int pad;
     float taps1[16], taps2[16];
+    cvk_frame_batch batch;                     /* batch.n frames of this geometry (over[] unused) */
 } cvk_blur_halve_params;
 int cvk_blur_halve_supported(int ntaps1, int ntaps2);
 int cvk_blur_halve(const cvk_blur_halve_params *bp, int cus, void *stream);

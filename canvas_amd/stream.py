@@ -85,6 +85,24 @@ class GraphStream:
                                              self.overlays, stream), "blur+over")
         return s["out"]
 
+    def render_batch(self, slots, stream=None):
+        """The same frames as render() of each slot, with the blur + over launches of all of them as ONE call of the batch
+        entry (up to eight frames of one geometry per launch: taller row segments, fewer halo rows re-filtered).  The
+        colour launches stay one per frame (they are HBM-bound and have no halo).  Returns the output DeviceFrames."""
+        lib, n = self.lib, len(slots)
+        ss = [self.slots[i % self.ring] for i in slots]
+        for s in ss:
+            _lib.check(lib.cvs_color_matrix_f16_to_dev(s["graded"].ref(), s["src"].ref(), self._m, self.pre_lut, self.post_lut, stream), "colour")
+        key = tuple(i % self.ring for i in slots)
+        if getattr(self, "_batch_key", None) != key:                      # pointer tables for this set of slots, built once
+            fp = C.POINTER(_lib.rgba_frame_f16_t)
+            self._b_out = (fp * n)(*[C.pointer(s["out"].c) for s in ss])
+            self._b_src = (fp * n)(*[C.pointer(s["graded"].c) for s in ss])
+            self._b_ov = (fp * (n * self.overlays))(*[C.pointer(o.c) for s in ss for o in s["over"]])
+            self._batch_key = key
+        _lib.check(lib.cvs_blur_over_f16_batch_dev(self._b_out, self._b_src, self._t, len(self.taps), self._b_ov, self.overlays, n, stream), "blur+over batch")
+        return [s["out"] for s in ss]
+
     def run(self, frames_per_rank, rank=0, world=1, stream=None):
         """Render `frames_per_rank` frames on this rank (weak scaling: the stream has frames_per_rank * world frames,
         global frame g belongs to rank g % world); returns how many it rendered."""

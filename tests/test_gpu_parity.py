@@ -1257,6 +1257,86 @@ def _blur_over(cvs, out_full, src, taps, overlays):
     return d_out.download()
 
 
+def _frame_table(frames):
+    return (C.POINTER(_lib.rgba_frame_f16_t) * max(len(frames), 1))(*[C.pointer(f.c) for f in frames])
+
+
+@pytest.mark.parametrize("count,ntaps,nover", [(5, 9, 3), (11, 5, 1), (3, 21, 4), (4, 10, 2)])
+def test_blur_over_batch_is_the_single_calls(cvs, orc, count, ntaps, nover):
+    """cvs_blur_over_f16_batch_dev: independent frames of one geometry, up to eight per launch (grid.z = frame, row segments
+    sized for the whole batch).  The pixels must be those of `count` single calls, which are checked against the oracle
+    (11 frames: a launch of eight and one of three; 21 taps: the long-list instances; 10 taps: no batched form, frame by frame)."""
+    from tests.util import oracle_blur_over
+    w, h = 150, 70
+    full = (0, 0, w - 1, h - 1)
+    rng = np.random.default_rng(9100 + count)
+    taps = synth.gaussian_taps(ntaps | 1, 1.5)[:ntaps].copy()
+    srcs = [rand_f16_frame(rng, full, full) for _ in range(count)]
+    ovs = [[rand_f16_frame(rng, full, full) for _ in range(nover)] for _ in range(count)]
+    d_src = [DeviceFrame.from_host(f) for f in srcs]
+    d_ov = [[DeviceFrame.from_host(f) for f in fs] for fs in ovs]
+    d_out = [DeviceFrame(full, np.uint16) for _ in range(count)]
+    _lib.check(cvs.cvs_blur_over_f16_batch_dev(_frame_table(d_out), _frame_table(d_src), f32p(taps), ntaps,
+                                               _frame_table([o for fs in d_ov for o in fs]), nover, count, None))
+    for i in range(count):
+        got = d_out[i].download()
+        single = _blur_over(cvs, full, srcs[i], taps, ovs[i])
+        assert same_window(got.current_window, single.current_window)
+        assert np.array_equal(got.array, single.array), "frame %d of the batch differs from its single call" % i
+    want = oracle_blur_over(orc, srcs[count - 1], taps, ovs[count - 1])
+    assert_same_f16(d_out[count - 1].download().window_view(), want.window_view(), "last frame of the batch against the oracle")
+
+
+def test_blur_over_batch_with_ragged_frames_and_frames_that_feed_each_other(cvs):
+    """A batch whose frames do not share one geometry, and one whose second frame blurs the first frame's OUTPUT: both are
+    carried out frame by frame, in order -- the results of the single calls made one after the other."""
+    w, h = 96, 40
+    full = (0, 0, w - 1, h - 1)
+    rng = np.random.default_rng(9200)
+    taps = synth.gaussian_taps(9, 1.5)
+    # (a) the second frame's source covers only part of its buffer
+    srcs = [rand_f16_frame(rng, full, full), rand_f16_frame(rng, full, (3, 2, 80, 30)), rand_f16_frame(rng, full, full)]
+    ovs = [[rand_f16_frame(rng, full, full)] for _ in srcs]
+    d_src = [DeviceFrame.from_host(f) for f in srcs]
+    d_ov = [[DeviceFrame.from_host(f) for f in fs] for fs in ovs]
+    d_out = [DeviceFrame(full, np.uint16) for _ in srcs]
+    _lib.check(cvs.cvs_blur_over_f16_batch_dev(_frame_table(d_out), _frame_table(d_src), f32p(taps), 9, _frame_table([o for fs in d_ov for o in fs]), 1, 3, None))
+    for i in range(3):
+        single = _blur_over(cvs, full, srcs[i], taps, ovs[i])
+        got = d_out[i].download()
+        assert same_window(got.current_window, single.current_window)
+        assert np.array_equal(got.window_view(), single.window_view()), i
+    # (b) frame 1 reads what frame 0 writes
+    a, b = DeviceFrame(full, np.uint16), DeviceFrame(full, np.uint16)
+    _lib.check(cvs.cvs_blur_over_f16_batch_dev(_frame_table([a, b]), _frame_table([d_src[0], a]), f32p(taps), 9, _frame_table([d_ov[0][0], d_ov[2][0]]), 1, 2, None))
+    first = _blur_over(cvs, full, srcs[0], taps, ovs[0])
+    second = _blur_over(cvs, full, first, taps, ovs[2])
+    assert np.array_equal(a.download().array, first.array)
+    assert np.array_equal(b.download().array, second.array)
+
+
+@pytest.mark.parametrize("count,ntaps", [(2, 9), (9, 5), (3, 13)])
+def test_blur_lanczos_batch_is_the_single_calls(cvs, orc, count, ntaps):
+    """cvs_blur_lanczos_f16_batch_dev at factor 1/2 (config 3's sweep, eight frames per launch; 13 taps: no one-sweep form,
+    frame by frame): the single calls' pixels, the last frame also against the oracle."""
+    sw, sh = 200, 90
+    sfull, tfull = (0, 0, sw - 1, sh - 1), (0, 0, sw // 2 - 1, sh // 2 - 1)
+    rng = np.random.default_rng(9300 + count)
+    taps = synth.gaussian_taps(ntaps, 1.5)
+    srcs = [rand_f16_frame(rng, sfull, sfull) for _ in range(count)]
+    d_src = [DeviceFrame.from_host(f) for f in srcs]
+    d_out = [DeviceFrame(tfull, np.uint16) for _ in range(count)]
+    _lib.check(cvs.cvs_blur_lanczos_f16_batch_dev(_frame_table(d_out), _frame_table(d_src), count, f32p(taps), ntaps, C.c_float(0.5), C.c_float(0.5), 3, None))
+    if ntaps <= 11:
+        assert cvs.cvs_fir_last_kernel() == _lib.FIR_KERNEL_HALVE
+    for i in range(count):
+        one = DeviceFrame(tfull, np.uint16)
+        _lib.check(cvs.cvs_blur_lanczos_f16_dev(one.ref(), d_src[i].ref(), f32p(taps), ntaps, C.c_float(0.5), C.c_float(0.5), 3, None))
+        assert np.array_equal(d_out[i].download().array, one.download().array), i
+    want = _oracle_config3(orc, srcs[count - 1], (sw // 2, sh // 2), taps, 0.5, 0.5)
+    assert_same_f16(d_out[count - 1].download().array, want.array, "last frame of the batch against the oracle")
+
+
 @pytest.mark.parametrize("nover", [1, 3, 4])
 @pytest.mark.parametrize("ntaps", [9, 3, 15, 23])
 @pytest.mark.parametrize("size", [(300, 41), (64, 36)])         # two strips / one narrow strip
