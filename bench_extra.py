@@ -166,15 +166,20 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
         srcs.append(d)
     bigs = [DeviceFrame((0, 0, w - 1, h - 1), np.uint16) for _ in srcs]              # 16 x (17 + 66) MB rotate
 
-    def pass_s():
-        for src, dst in zip(srcs, bigs):
-            _lib.check(lib.cvs_scale_bilinear_f16_dev(dst.ref(), v2f(0, 0), src.ref(), v2f(0, 0), v2f(2.0, 2.0), stream), "scaler")
+    streams_s = [stream, lib.cvs_stream_create()]               # two frames in flight (the reference's pull queue has two workers)
 
-    n, dt = _timed_passes(lib, _lib, [stream], pass_s, seconds / 2)
+    def pass_s():
+        for i, (src, dst) in enumerate(zip(srcs, bigs)):
+            _lib.check(lib.cvs_scale_bilinear_f16_dev(dst.ref(), v2f(0, 0), src.ref(), v2f(0, 0), v2f(2.0, 2.0), streams_s[i % 2]), "scaler")
+
+    n, dt = _timed_passes(lib, _lib, streams_s, pass_s, seconds / 2)
+    lib.cvs_stream_sync(streams_s[1])
+    lib.cvs_stream_destroy(streams_s[1])
     digest = verify.canon_sha256(bigs[0].download(stream).array)
     rec = _record(dist, gather_stats, checksum52, "scaler_x2.00", "1920x1080 f16 -> video_scale_bilinear (triangle) x2 -> 3840x2160 f16",
                   n * len(srcs), w * h, dt, digest, verify.stream_fixture("scaler_1920x1080_x2.00", g0), 10,
-                  "Mpixels/s and bytes are per OUTPUT pixel: source read once (2 B per output px) + target written once; both passes in one launch", rank,
+                  "Mpixels/s and bytes are per OUTPUT pixel: source read once (2 B per output px) + target written once; both passes in one launch; "
+                  "frames alternate over two HIP streams", rank,
                   kernels=["k_fir_vh<2, 2, 2, f16, 2 px per lane> (one launch)"])
     if rec:
         out.append(rec)
