@@ -25,6 +25,8 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS
 echo "extras sq done"
 # config 5's two kernels one at a time (the bench alternates frames over two streams, so its kernels overlap in a trace)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5_trace -- python3 tools/bench_stream.py --frames 200 --streams 1 > $O/c5_trace.json 2> $O/c5_trace.log || exit 1
+# config 3's sweep four frames per launch on ONE stream (in the bench two such launches overlap on two streams)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3_trace -- python3 tools/time_config3_batches.py 4 1 > $O/c3_trace.txt 2> $O/c3_trace.log || exit 1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/cal_fetch -- python3 tools/calibrate_fetch.py > $O/cal_fetch.txt 2> $O/cal_fetch.log || exit 1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/cal_write -- python3 tools/calibrate_fetch.py > $O/cal_write.txt 2> $O/cal_write.log || exit 1
 find $O -name "*.csv" | wc -l

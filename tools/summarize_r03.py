@@ -128,8 +128,10 @@ tr = trace("x_trace")
 fe, wr_, s1, s2 = counters("x_fetch"), counters("x_write"), counters("x_sq1"), counters("x_sq2")
 # kernel -> (bytes per lane of its loads, of its stores, algorithmic bytes per launch as the extras run it, note)
 PX4K, PX1080, PX8K = 3840 * 2160, 1920 * 1080, 7680 * 4320
+# (the extras run config 3's sweep and config 5's blur + over four frames per launch: their FETCH / WRITE figures are per
+# launch of four, their durations come from one-stream traces -- c3_trace: four frames per launch; c5_trace: one)
 KERNELS = [
-    ("k_blur_halve<", 8, 4, PX4K * 8 + PX1080 * 8, "config 3: 4K f16 in, 1080p f16 out (a lane stores one channel pair: 4 B)"),
+    ("k_blur_halve<", 8, 4, 4 * (PX4K * 8 + PX1080 * 8), "config 3: four 4K f16 frames in, four 1080p f16 frames out per launch (a lane stores one channel pair: 4 B)"),
     ("k_color_flat", 16, 16, PX4K * 16, "config 5, launch 1: colour filter 8 r + 8 w per px (pixel pairs: 16 B per lane)"),
     ("k_blur<9, 256, true, true, 1>", 8, 8, PX4K * 40, "config 5, launch 2: blur + 3 overlays + store = 8 r + 24 r + 8 w per px"),
     ("k_fir_vh<", 8, 16, PX1080 * 8 + PX4K * 8, "scaler 1080p -> 4K f16"),
@@ -139,12 +141,26 @@ try:
     tr_c5 = trace("c5_trace")
 except SystemExit:
     tr_c5 = None
+try:
+    tr_c3 = trace("c3_trace")
+except SystemExit:
+    tr_c3 = None
+try:
+    tr_vh = trace("vh_up16_p1")                           # tools/profile_kernel.sh on tools/time_scaler.py --only "1080p->4K": one stream
+except SystemExit:
+    tr_vh = None
 xs = {}
 for pat, lb, sb, algo_b, note in KERNELS:
     d = [t for n, t in tr if pat in n]
     if tr_c5 is not None and ("k_color_flat" in pat or "k_blur<9" in pat):
         d = [t for n, t in tr_c5 if pat in n]            # one stream: the kernel alone on the chip
-        note += "; durations from tools/bench_stream.py --streams 1 (in the bench its frames alternate over two streams and overlap)"
+        note += "; durations from tools/bench_stream.py --streams 1 (one frame per launch; in the bench its frames alternate over two streams and overlap)"
+    if tr_vh is not None and "k_fir_vh" in pat:
+        d = [t for n, t in tr_vh if "k_fir_vh<2, 2, 2, true" in n]
+        note += "; durations from tools/time_scaler.py --only 1080p->4K under tools/profile_kernel.sh (one stream, counters on; in the bench its frames alternate over two streams)"
+    if tr_c3 is not None and "k_blur_halve" in pat:
+        d = [t for n, t in tr_c3 if pat in n]
+        note += "; durations from tools/time_config3_batches.py 4 1 (four frames per launch, one stream; in the bench two such launches overlap on two streams)"
     if not d:
         continue
     d = d[len(d) // 5:]                                   # the first fifth of a kernel's launches are its warm-up passes
@@ -156,6 +172,8 @@ for pat, lb, sb, algo_b, note in KERNELS:
         rfac = rf16 if lb == 16 else rf8
         wfac = 1.0 if sb == 16 else wf8
         fb, wb = sum(f) / len(f) * 1024 * rfac, sum(w_) / len(w_) * 1024 * wfac
+        if "k_blur<9" in pat:                            # counted on the extras' launches of four frames
+            fb, wb = fb / 4, wb / 4
         rec["traffic"] = {"FETCH_SIZE_KiB_mean": round(sum(f) / len(f), 1), "read_factor_applied": rfac, "read_bytes": round(fb),
                           "WRITE_SIZE_KiB_mean": round(sum(w_) / len(w_), 1), "write_factor_applied": wfac, "written_bytes": round(wb),
                           "hbm_bytes_per_launch": round(fb + wb), "ratio_to_algorithmic": round((fb + wb) / algo_b, 3),

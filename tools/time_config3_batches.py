@@ -18,7 +18,10 @@ taps = synth.gaussian_taps(9, 1.5)
 tp = taps.ctypes.data_as(C.POINTER(C.c_float))
 fp = C.POINTER(_lib.rgba_frame_f16_t)
 streams = [lib.cvs_stream_create() for _ in range(4)]
-for per, ns in ((1, 1), (2, 1), (4, 1), (8, 1), (1, 2), (4, 2), (8, 2), (8, 3)):
+combos = ((1, 1), (2, 1), (4, 1), (8, 1), (1, 2), (4, 2), (8, 2), (8, 3))
+if len(sys.argv) > 2:                                   # time_config3_batches.py <frames per call> <streams>: that one only (profiling)
+    combos = ((int(sys.argv[1]), int(sys.argv[2])),)
+for per, ns in combos:
     tabs = []
     for a in range(0, N, per):
         tabs.append(((fp * per)(*[C.pointer(o.c) for o in outs[a:a + per]]), (fp * per)(*[C.pointer(o.c) for o in srcs[a:a + per]])))
