@@ -332,6 +332,8 @@ const Instance *pick(const cvk_fir2d_params *fp) {
         const int tiles = kLanes * in.pxl / CVK_FIR2D_TILE_X;
         const int nq = (tiles * fp->max_sw + kLanes - 1) / kLanes;
         if (in.pxl == 2 && cols < 1024) continue;                  // small targets: more, narrower strips
+        // two halfs-pixels per lane are ONE 16-byte store: the pair must sit on a 16-byte boundary in every row
+        if (in.pxl == 2 && fp->out_half && ((((uintptr_t)fp->target.data) & 15u) || (fp->target.pitch & 1) || ((fp->tx0 - fp->target.fx0) & 1))) continue;
         if (fp->v.max_taps <= in.w && fp->h.max_taps <= in.maxth && nq <= in.nq) return &in;
     }
     return NULL;

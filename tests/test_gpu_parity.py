@@ -1863,6 +1863,35 @@ def test_scale_bilinear_f16_twin(cvs, orc, tfull, sfull, scur, tp, sp, fac):
         assert_same_f16(got.window_view(), want.window_view(), "f16 scale %r" % (fac,))
 
 
+@pytest.mark.parametrize("tw,fmt", [(1025, "f16"), (1026, "f16"), (1100, "f32"), (1027, "f32")])
+@pytest.mark.parametrize("fac", [(2.0, 2.0), (1.5, 1.5), (1.25, 1.25)])
+def test_scale_wide_targets_two_columns_per_lane(cvs, orc, tw, fmt, fac):
+    """Targets of 1024 columns and more take the scaler kernel's two-columns-per-lane instances (strips of 128: the adjacent
+    pair as one 16-byte store for halfs, columns l and l + 64 for floats); an odd row pitch (1025, 1027) puts half of the
+    rows' pairs off a 16-byte boundary, so those targets stay with one column per lane.  Ragged last strip either way."""
+    th = 37
+    sw, sh = int(tw / fac[0]) + 2, int(th / fac[1]) + 2
+    sfull, tfull = (0, 0, sw - 1, sh - 1), (0, 0, tw - 1, th - 1)
+    rng = np.random.default_rng(4100 + tw)
+    src16 = rand_f16_frame(rng, sfull, sfull)
+    src32 = HostFrame(sfull, np.float32, orc.half_to_float(src16.array), sfull)
+    want32 = HostFrame(tfull, np.float32)
+    orc.lib().orc_scale_bilinear_f32(want32.ref(), v2f(0, 0), src32.ref(), v2f(0, 0), v2f(*fac))
+    if fmt == "f16":
+        d_src, d_out = DeviceFrame.from_host(src16), DeviceFrame(tfull, np.uint16)
+        _lib.check(cvs.cvs_scale_bilinear_f16_dev(d_out.ref(), v2f(0, 0), d_src.ref(), v2f(0, 0), v2f(*fac), None))
+        got = d_out.download()
+        assert same_window(got.current_window, want32.current_window)
+        assert_same_f16(got.window_view(), orc.float_to_half(want32.window_view()), "wide f16 scale %r" % (fac,))
+    else:
+        d_src, d_out = DeviceFrame.from_host(src32), DeviceFrame(tfull, np.float32)
+        _lib.check(cvs.cvs_scale_bilinear_f32_dev(d_out.ref(), v2f(0, 0), d_src.ref(), v2f(0, 0), v2f(*fac), None))
+        got = d_out.download()
+        assert same_window(got.current_window, want32.current_window)
+        assert_same_f32(got.window_view(), want32.window_view(), "wide f32 scale %r" % (fac,))
+    assert cvs.cvs_scale_last_was_fused() == 1 and cvs.cvs_fir_last_kernel() == _lib.FIR_KERNEL_VH
+
+
 # ------------------------------------------------------------------ randomized window sweeps (region walks of video_mix.c / copy / scale)
 
 def _random_window(rng, full, allow_empty=True, inside=None):
