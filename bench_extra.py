@@ -10,7 +10,7 @@ with copies of config 2's ring (same value distribution, opaque bottom layer), w
   config 4   7680x4320 3-layer alpha-over stack                                             cvs_chain_color_over_f16_dev (m = NULL)
   config 5   3840x2160 10-node graph (4 sources, colour -> blur -> 4-step composite)        canvas_amd.stream.GraphStream
   lanczos3_x0.40 / x0.75 / x1.50   3840x2160 Lanczos3 at factors other than 1/2: the GENERAL FIR path (per-line tap
-             tables, sweep_ops.hip), not a BASELINE config                                  cvs_resample_lanczos_f16_dev
+             tables, sweep_ops.hip / sweep_hv_ops.hip), not a BASELINE config               cvs_resample_lanczos_f16_dev
   scaler_x2.00   1920x1080 -> 3840x2160 through the reference's own scaler        cvs_scale_bilinear_f16_dev
 """
 import ctypes as C
@@ -147,7 +147,7 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
         in_bytes, out_bytes = 8, 8 * (tw * th) / (w * h)
         rec = _record(dist, gather_stats, checksum52, "lanczos3_x" + tag, "3840x2160 f16 -> Lanczos3 -> %dx%d f16 (per-line tap tables)" % (tw, th),
                       n * len(sources), w * h, dt, digest, verify.stream_fixture("lanczos3_3840x2160_x" + tag, g0), round(in_bytes + out_bytes, 2),
-                      "Mpixels/s and bytes are per INPUT pixel: source read once + target written once", rank, kernels=["k_fir_lanes (one launch)"])
+                      "Mpixels/s and bytes are per INPUT pixel: source read once + target written once", rank, kernels=["k_fir_hv (per-line gather) when enlarging, k_fir_lanes (channel-pair sweep) when reducing: one launch"])
         if rec:
             out.append(rec)
         for d in outs:

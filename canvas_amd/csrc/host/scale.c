@@ -28,11 +28,17 @@ static _Thread_local int t_fir_kernel;          /* CVS_FIR_KERNEL_*: the kernel 
 CVS_EXPORT int cvs_fir_last_kernel(void) { return t_fir_kernel; }
 /* A fused kernel that was chosen for a table pair and then did not launch: the next kernel in line still computes the
  * same pixels, 3-7x slower -- that must not go unnoticed. */
+/* Which of the two sweeps for per-line tables goes first (both compute the same sums; profiles/r03/general_fir_hv.txt):
+ * the per-line gather (sweep_hv_ops.hip) when neither axis reduces much -- Lanczos3 4K -> 1.5x 0.097 against 0.119 ms, and
+ * enlargements beyond 2.2x, which the channel-pair sweep (sweep_ops.hip, 32 accumulator slots) does not take at all; the
+ * channel-pair sweep when reducing (4K -> 0.4x 0.041 against 0.043 ms: twice the waves on a small target, shorter halos). */
+static bool hv_goes_first(const cvk_fir2d_params *fp) { return fp->max_sw <= 44; }
+
 static void fir_launch_fell_through(const char *kernel, int rc) {
     (void)hipGetLastError();
     cvs_set_error("%s did not launch (%s): falling back to the next FIR kernel", kernel, hipGetErrorString((hipError_t)rc));
 }
-CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_LANES)); }
+CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_LANES | CVS_FIR_PATH_HV)); }
 
 typedef struct {
     int t0, t1;            /* target lines covered by the table */
@@ -248,12 +254,14 @@ static int triangle_fused_hv(any_frame *target, v2f tp, const any_frame *source,
             fp.ty0 = tf->min.y; fp.ty1 = tf->max.y;                   /* every line: those without taps are written as zeros */
             fp.h = th; fp.v = tv;
             fp.max_sw = hfoot > 0 ? hfoot : 1;
-            if (vhi >= vlo && cvk_fir_lanes_supported(&fp)) {
+            const bool use_hv = !(atomic_load(&g_fir_path) & CVS_FIR_PATH_LANES) && cvk_fir_hv_supported(&fp) &&
+                                ((atomic_load(&g_fir_path) & CVS_FIR_PATH_HV) || hv_goes_first(&fp) || !cvk_fir_lanes_supported(&fp));
+            if (vhi >= vlo && (use_hv || cvk_fir_lanes_supported(&fp))) {
                 const bool covers = fp.tx0 == tf->min.x && hi2 == tf->max.x;
                 hipError_t e = covers || !any_bytes(target) ? hipSuccess : hipMemsetAsync(target->data, 0, any_bytes(target), s);
-                int krc = e == hipSuccess ? cvk_fir_lanes(&fp, cvs_cus(), s) : (int)e;
-                if (krc == 0) { box2i_set(&target->cur, lo2, vlo, hi2, vhi); t_fir_kernel = CVS_FIR_KERNEL_LANES; rc = 0; }
-                else { fir_launch_fell_through("k_fir_lanes", krc); rc = 1; }
+                int krc = e != hipSuccess ? (int)e : use_hv ? cvk_fir_hv(&fp, cvs_cus(), s) : cvk_fir_lanes(&fp, cvs_cus(), s);
+                if (krc == 0) { box2i_set(&target->cur, lo2, vlo, hi2, vhi); t_fir_kernel = use_hv ? CVS_FIR_KERNEL_HV : CVS_FIR_KERNEL_LANES; rc = 0; }
+                else { fir_launch_fell_through(use_hv ? "k_fir_hv" : "k_fir_lanes", krc); rc = 1; }
             }
         }
     }
@@ -774,7 +782,17 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
      * Small footprints (enlargements, blurs) stay with the tiles, which are as fast or faster there.
      * cvs_fir_path_override() pins one or the other (parity tests of each kernel, A/B runs). */
     const int force = atomic_load(&g_fir_path);
-    /* First choice: the sweep with one lane per target column and channel pair (sweep_ops.hip), whenever the vertical table
+    /* First choice: the gather per target line (sweep_hv_ops.hip), whenever first taps never decrease down the vertical
+     * table and the lists fit an instance. */
+    const bool pinned = (force & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_LANES | CVS_FIR_PATH_HV)) != 0;
+    if ((force & CVS_FIR_PATH_HV) || (!pinned && (hv_goes_first(&fp) || !cvk_fir_lanes_supported(&fp)))) {
+        if (cvk_fir_hv_supported(&fp)) {
+            int rc = cvk_fir_hv(&fp, cvs_cus(), s);
+            if (rc == 0) { t_fir_kernel = CVS_FIR_KERNEL_HV; return 0; }
+            fir_launch_fell_through("k_fir_hv", rc);          /* did not launch: the older kernels decide */
+        }
+    }
+    /* Second: the sweep with one lane per target column and channel pair (sweep_ops.hip), whenever the vertical table
      * could be turned round for it and the lists fit. */
     if ((force & CVS_FIR_PATH_LANES) || !(force & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED))) {
         if (cvk_fir_lanes_supported(&fp)) {

@@ -132,7 +132,7 @@ typedef struct {
      * tap k; unused entries 0.  One spare all-zero record (count 0) follows the last.  sweep_vh_ops.hip reads one per line. */
     const uint32_t *lrec;
 } cvk_fir_axis;
-#define CVK_FIR_LREC 16
+#define CVK_FIR_LREC 32
 typedef struct {
     cvk_view target, source;
     int in_half, out_half;     /* 0: rgba_f32 pixels, 1: rgba_f16 pixels */
@@ -148,6 +148,10 @@ int cvk_fir_stream(const cvk_fir2d_params *fp, int h_taps, int v_active, int cus
 /* the same tables again, one lane per target column and channel pair (sweep_ops.hip): needs h tap lists <= 32, v.rec */
 int cvk_fir_lanes_supported(const cvk_fir2d_params *fp);
 int cvk_fir_lanes(const cvk_fir2d_params *fp, int cus, void *stream);
+/* the same tables once more, horizontal pass first, as a gather per target line (sweep_hv_ops.hip): needs v.streamable and
+ * v.lrec (vertical lists <= CVK_FIR_LREC - 2), horizontal lists <= 24; first choice for these tables */
+int cvk_fir_hv_supported(const cvk_fir2d_params *fp);
+int cvk_fir_hv(const cvk_fir2d_params *fp, int cus, void *stream);
 /* the same tables with the VERTICAL pass first (sweep_vh_ops.hip): what video_scale_bilinear_f32 does when the factors are
  * equal or the vertical one is smaller.  fp->ty0 = first line of the vertical table; lines ty0 + line0 .. ty1 are produced */
 int cvk_fir_vh_supported(const cvk_fir2d_params *fp);

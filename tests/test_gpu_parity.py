@@ -827,6 +827,8 @@ def force_fir(request):
             mode |= _lib.FIR_PATH_TILED
         elif which == "lanes":
             mode |= _lib.FIR_PATH_LANES
+        elif which == "hv":
+            mode |= _lib.FIR_PATH_HV
 
         lib.cvs_fir_path_override(mode)
     yield pin
@@ -840,7 +842,7 @@ def force_fir(request):
 
 _KERNEL_NAMES = {_lib.FIR_KERNEL_NONE: "none", _lib.FIR_KERNEL_WINDOW: "window", _lib.FIR_KERNEL_HALVE: "halve", _lib.FIR_KERNEL_LANES: "lanes",
                  _lib.FIR_KERNEL_VH: "vh", _lib.FIR_KERNEL_TILED: "tiled", _lib.FIR_KERNEL_STREAM: "stream",
-                 _lib.FIR_KERNEL_TWO_PASS: "two-pass", _lib.FIR_KERNEL_PASS: "pass"}
+                 _lib.FIR_KERNEL_TWO_PASS: "two-pass", _lib.FIR_KERNEL_PASS: "pass", _lib.FIR_KERNEL_HV: "hv"}
 _FIR_SEEN = {}
 
 
@@ -866,7 +868,7 @@ _FALLBACK = {
 }
 
 
-@pytest.mark.parametrize("kernel", ["lanes", "stream", "tiled"])
+@pytest.mark.parametrize("kernel", ["hv", "lanes", "stream", "tiled"])
 @pytest.mark.parametrize("ssize,scur,tsize,fx,fy", [
     ((64, 36), None, (32, 18), 0.5, 0.5),
     ((400, 300), None, (160, 120), 0.4, 0.4),                # several strips of 128 columns, several row segments
@@ -878,8 +880,8 @@ _FALLBACK = {
     ((130, 70), None, (40, 200), 0.3, 3.0),                  # more target rows than the source covers: lines without taps
 ])
 def test_lanczos_resample_both_kernels(cvs, orc, force_fir, kernel, ssize, scur, tsize, fx, fy):
-    """The general resampler has two kernels (tiles in LDS, and the sweep down the frame that takes over when the tiles
-    would fill the LDS); whichever the footprint would choose, both must give the gather's sums bit for bit."""
+    """The general resampler has four kernels (the per-line gather, the channel-pair sweep, tiles in LDS, the lane-per-pixel
+    sweep); whichever a table pair would get, all must give the gather's sums bit for bit."""
     rng = np.random.default_rng(62)
     sfull = (0, 0, ssize[0] - 1, ssize[1] - 1)
     src = rand_f32_frame(rng, sfull, scur, lo=-0.5, hi=1.5)
@@ -903,7 +905,7 @@ def test_lanczos_resample_both_kernels(cvs, orc, force_fir, kernel, ssize, scur,
     assert_same_f16(o16.download().array, want16.array, "lanczos f16 (%s)" % kernel)
 
 
-@pytest.mark.parametrize("kernel", ["lanes", "stream", "tiled"])
+@pytest.mark.parametrize("kernel", ["hv", "lanes", "stream", "tiled"])
 @pytest.mark.parametrize("ssize,tsize,fx,fy", [((400, 300), (160, 120), 0.4, 0.4), ((96, 54), (144, 81), 1.5, 1.5), ((300, 200), (225, 150), 0.75, 0.75),
                                                ((96, 54), (192, 108), 2.0, 2.0)])
 def test_lanczos_resample_with_inf_and_nan_pixels(cvs, orc, force_fir, kernel, ssize, tsize, fx, fy):
@@ -931,7 +933,7 @@ def test_lanczos_resample_with_inf_and_nan_pixels(cvs, orc, force_fir, kernel, s
     assert_same_f32(got.array, want.array, "lanczos with non-finite pixels (%s)" % kernel)
 
 
-@pytest.mark.parametrize("kernel", ["lanes", "stream", "tiled"])
+@pytest.mark.parametrize("kernel", ["hv", "lanes", "stream", "tiled"])
 @pytest.mark.parametrize("ntaps", [1, 2, 4, 10, 16])
 def test_even_and_short_blurs_both_kernels(cvs, orc, force_fir, kernel, ntaps):
     rng = np.random.default_rng(63)
@@ -968,14 +970,15 @@ def test_full_size_resample_agrees_between_the_kernels(cvs, force_fir, f, fmt):
         d_src, dtype = DeviceFrame.from_host(HostFrame(src16.full_window, np.float32, h2f_ieee(src16.array).astype(np.float32))), np.float32
     outs = []
     cvs.cvs_clear_last_error()
-    for kernel in (None, "tiled", "lanes"):
+    for kernel in (None, "tiled", "lanes", "hv"):
         force_fir(kernel)
         d_out = DeviceFrame((0, 0, tw - 1, th - 1), dtype)
         if fmt == "f16":
             _lib.check(cvs.cvs_resample_lanczos_f16_dev(d_out.ref(), d_src.ref(), C.c_float(f), C.c_float(f), 3, None))
         else:
             _lib.check(cvs.cvs_resample_lanczos_f32_dev(d_out.ref(), d_src.ref(), C.c_float(f), C.c_float(f), 3, None))
-        ran_on(cvs, kernel or "lanes", note="full size %s %r %s" % (kernel, f, fmt))       # the automatic choice at these factors is the channel-pair sweep
+        # the automatic choice (host/scale.c hv_goes_first): the per-line gather when enlarging, the channel-pair sweep when reducing
+        ran_on(cvs, kernel or ("hv" if f > 1.0 else "lanes"), note="full size %s %r %s" % (kernel, f, fmt))
         got = d_out.download()
         assert got.current_window.tuple() == (0, 0, tw - 1, th - 1)
         outs.append(got.array.copy())
@@ -1376,7 +1379,7 @@ def test_blur_over_node_by_node(cvs, orc, case):
     assert_same_f16(got.window_view(), want.window_view(), "blur+over %s" % case)
 
 
-@pytest.mark.parametrize("kernel", ["lanes", "stream", "tiled"])
+@pytest.mark.parametrize("kernel", ["hv", "lanes", "stream", "tiled"])
 @pytest.mark.parametrize("ntaps", [9, 10])
 def test_blur_over_node_by_node_through_the_table_kernels(cvs, orc, force_fir, kernel, ntaps):
     """The node-by-node form blurs an f16 source into an f32 frame; with the register-window kernels out of the way that is
@@ -2014,7 +2017,8 @@ def test_scaler_in_one_launch_agrees_with_the_two_passes(cvs, force_fir, fac, fm
             _lib.check(cvs.cvs_scale_bilinear_f32_dev(d_out.ref(), v2f(0, 0), d_src.ref(), v2f(0, 0), v2f(*fac), None))
         fused.append(cvs.cvs_scale_last_was_fused())
         # video_scale.c:252: the smaller factor's pass first -- horizontal first is the channel-pair sweep, else k_fir_vh
-        assert _KERNEL_NAMES[cvs.cvs_fir_last_kernel()] == ("pass" if kernel else "lanes" if fac[0] < fac[1] else "vh")
+        # ... and when the horizontal pass goes first: the per-line gather unless the horizontal axis reduces (hv_goes_first)
+        assert _KERNEL_NAMES[cvs.cvs_fir_last_kernel()] == ("pass" if kernel else ("hv" if fac[0] >= 1.0 else "lanes") if fac[0] < fac[1] else "vh")
         got = d_out.download()
         outs.append((got.current_window.tuple(), got.array.copy()))
         d_src.free(); d_out.free()
