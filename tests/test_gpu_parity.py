@@ -2090,6 +2090,49 @@ def test_lanczos_random_geometry(cvs, orc):
             assert_same_f32(got.window_view(), want.window_view(), "lanczos, random case %d (%g, %g, k=%d)" % (case, fx, fy, ksize))
 
 
+def test_lanczos_random_factors_every_sweep_against_the_oracle(cvs, orc, force_fir):
+    """60 resamples at factors drawn from [0.28, 3.2] per axis (no two lines share a tap list), targets of several strips,
+    source windows inside their buffers, a few Inf / NaN pixels: the automatic choice, then the per-line gather and the
+    channel-pair sweep pinned in turn (each falls back to the next kernel in line where it has no instance) -- all three
+    must give the oracle's frame.  f16 frames on every third case (the f16 entry: widen, resample, truncate)."""
+    rng = np.random.default_rng(20261103)
+    for case in range(60):
+        fx, fy = float(np.float32(rng.uniform(0.28, 3.2))), float(np.float32(rng.uniform(0.28, 3.2)))
+        sw, sh = int(rng.integers(40, 260)), int(rng.integers(24, 90))
+        tw, th = max(8, min(420, int(sw * fx))), max(6, min(140, int(sh * fy)))
+        sfull, tfull = (0, 0, sw - 1, sh - 1), (0, 0, tw - 1, th - 1)
+        scur = _random_window(rng, sfull, allow_empty=False) if case % 4 == 0 else sfull
+        half = case % 3 == 0
+        if half:
+            src = rand_f16_frame(rng, sfull, scur)
+            src32 = HostFrame(sfull, np.float32, orc.half_to_float(src.array), scur)
+        else:
+            src = src32 = rand_f32_frame(rng, sfull, scur, lo=-0.5, hi=1.5)
+            for k, v in enumerate([np.inf, np.nan, -np.inf]):
+                src.array[(13 * k + case) % sh, (29 * k + 3 * case) % sw, k % 4] = v
+        want = HostFrame(tfull, np.float32)
+        orc.lib().orc_resample_lanczos_f32(want.ref(), src32.ref(), C.c_float(fx), C.c_float(fy), 3)
+        d_src = DeviceFrame.from_host(src)
+        for kernel in (None, "hv", "lanes"):
+            force_fir(kernel)
+            if half:
+                d_out = DeviceFrame(tfull, np.uint16)
+                _lib.check(cvs.cvs_resample_lanczos_f16_dev(d_out.ref(), d_src.ref(), C.c_float(fx), C.c_float(fy), 3, None))
+                got = d_out.download()
+                assert same_window(got.current_window, want.current_window), (case, fx, fy, kernel)
+                if not want.current_window.is_empty():
+                    assert_same_f16(got.window_view(), orc.float_to_half(want.window_view()), "case %d (%g, %g) %s f16" % (case, fx, fy, kernel))
+            else:
+                d_out = DeviceFrame(tfull, np.float32)
+                _lib.check(cvs.cvs_resample_lanczos_f32_dev(d_out.ref(), d_src.ref(), C.c_float(fx), C.c_float(fy), 3, None))
+                got = d_out.download()
+                assert same_window(got.current_window, want.current_window), (case, fx, fy, kernel)
+                if not want.current_window.is_empty():
+                    assert_same_f32(got.window_view(), want.window_view(), "case %d (%g, %g) %s" % (case, fx, fy, kernel))
+            d_out.free()
+        d_src.free()
+
+
 def test_chain_and_crossfade_on_arbitrary_half_codes(cvs, orc):
     """Layers made of uniformly random 16-bit patterns -- every exponent class, subnormals, Inf, NaN, both signs, in
     colour and in alpha: the band test of the shared-reciprocal divide, the Inf saturation of the truncation and the
