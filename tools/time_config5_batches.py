@@ -8,7 +8,8 @@ from canvas_amd.stream import GraphStream
 import bench_extra
 lib = _lib.load(); _lib.check(lib.cvs_init(0)); lib.init_half()
 w, h = 3840, 2160
-g = GraphStream(w, h, ring=8, exact_slots=8)
+RING = 24
+g = GraphStream(w, h, ring=RING, exact_slots=2, donors=None) if False else GraphStream(w, h, ring=RING, exact_slots=RING)
 streams = [lib.cvs_stream_create() for _ in range(4)]
 def sync():
     for s in streams: lib.cvs_stream_sync(s)
@@ -17,15 +18,15 @@ def timed(fn, frames_per_pass):
     best = 1e9
     for rep in range(3):
         t0 = time.perf_counter()
-        for _ in range(30): fn()
-        sync(); best = min(best, (time.perf_counter() - t0) / (30 * frames_per_pass))
+        for _ in range(10): fn()
+        sync(); best = min(best, (time.perf_counter() - t0) / (10 * frames_per_pass))
     return best * 1e3
 for ns in (1, 2, 3, 4):
     def per_frame():
-        for i in range(8): g.render(i, streams[i % ns])
-    print("per frame, %d stream(s): %.4f ms per frame" % (ns, timed(per_frame, 8)), flush=True)
-for per, ns in ((2, 1), (2, 2), (4, 1), (4, 2), (8, 1), (2, 4)):
-    views = [bench_extra.GraphStreamView(g, list(range(a, a + per))) for a in range(0, 8, per)]
+        for i in range(RING): g.render(i, streams[i % ns])
+    print("per frame, %d stream(s): %.4f ms per frame" % (ns, timed(per_frame, RING)), flush=True)
+for per, ns in ((2, 2), (4, 1), (4, 2), (4, 3), (8, 1), (8, 2), (8, 3)):
+    views = [bench_extra.GraphStreamView(g, list(range(a, a + per))) for a in range(0, RING, per)]
     def batched():
         for k, v in enumerate(views): v.render(streams[k % ns])
-    print("batches of %d, %d stream(s): %.4f ms per frame" % (per, ns, timed(batched, 8)), flush=True)
+    print("batches of %d, %d stream(s): %.4f ms per frame" % (per, ns, timed(batched, RING)), flush=True)
