@@ -40,6 +40,7 @@ using cvs::f32x2;
 struct Px { f32x2 rg, ba; };
 
 constexpr int RL = 12;                     // ring length of both rings; the step loop is unrolled RL times
+constexpr int kTwoRowsDefault = 1;         // the product launches the two-rows-per-barrier form (3 % faster, same pixels: profiles/r03/config3_batches.txt)
 
 template <class F, int... Js>
 __device__ __forceinline__ void each_slot(F &f, std::integer_sequence<int, Js...>) {
@@ -223,6 +224,141 @@ __global__ __launch_bounds__(W) void k_blur_halve(cvk_blur_halve_params bp) {
     }
 }
 
+// The same sweep with TWO source rows per barrier.  A row step is a latency chain (row -> LDS -> barrier -> H1 -> ring ->
+// V1 -> LDS -> barrier -> H2 -> ring -> V2) that three waves per SIMD do not hide, and a good part of it is the barrier
+// itself: four waves on four SIMDs meet once per row (one-wave workgroups, with no barrier to wait at, are 22 % more
+// efficient per lane and step -- and lose it to their horizontal halo, profiles/r03).  Here a step takes rows i and i + 1:
+// both go to LDS, ONE barrier, stage 2 consumes the two blurred rows of the previous step (exactly one of them completes
+// a target row: a compile-time fact, NT1 and NT2 are odd), stage 1 filters both rows.  Same sums, same order; the second
+// stage runs one row later than in the one-row form, so the loop drains one step more.
+template <int NT1, int NT2, int W, bool INH>
+__global__ __launch_bounds__(W) void k_blur_halve2(cvk_blur_halve_params bp) {
+    static_assert(NT1 % 2 == 1 && NT2 % 2 == 1 && NT1 <= RL && NT2 < RL && RL % 4 == 0, "ring layout");
+    constexpr int C1 = NT1 / 2, C2 = NT2 / 2;
+    constexpr int OUTW = (W - NT1 - NT2 + 1) / 2 + 1;          // target columns per strip
+    constexpr int PITCH = W + 16, HALF = W / 2 + 16;
+    __shared__ float4 rowS[2][2][PITCH];                       // [step parity][row of the pair]: source rows, widened
+    __shared__ float4 rowB[2][2][2][HALF];                     // [step parity][row of the pair][column parity][column / 2]: blurred rows
+    const int lane = threadIdx.x;
+    const int xo = bp.tx0 + (int)blockIdx.x * OUTW;
+    const int sfirst = 2 * xo - C2 - C1;
+    const int bcol = sfirst + C1 + lane;
+    static_assert(OUTW <= W / 2, "the two halves of the workgroup share the strip's target columns");
+    const int tl = lane & (W / 2 - 1);
+    const int pair = lane / (W / 2);
+    const int tcol = xo + tl;
+    const bool out_live = tl < OUTW && tcol <= bp.tx1;
+    const bool bcol_live = bcol >= bp.sx0 && bcol <= bp.sx1;
+    const int ta = bp.ty0 + (int)blockIdx.y * bp.rows_per_wg;
+    const int tb = min(ta + bp.rows_per_wg - 1, bp.ty1);
+    const int ys0 = 2 * ta - C2 - C1;
+    const int steps = 2 * (tb - ta) + NT2 + NT1 - 1;           // source rows 0 .. steps - 1 of the segment
+
+    float w1[NT1], w2[NT2];
+#pragma unroll
+    for (int k = 0; k < NT1; k++) w1[k] = bp.taps1[k];
+#pragma unroll
+    for (int k = 0; k < NT2; k++) w2[k] = bp.taps2[k];
+
+    constexpr size_t SPX = INH ? 8 : 16;
+    const size_t srow = (size_t)bp.source.pitch * SPX;
+    const int scol = sfirst + lane;
+    const bool scol_live = scol >= bp.sx0 && scol <= bp.sx1;
+    typedef const cvk_blur_halve_params __attribute__((address_space(4))) *kargs_t;
+    const kargs_t ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const void *src_data = bp.batch.n ? ka->batch.source[blockIdx.z] : bp.source.data;
+    void *dst_data = bp.batch.n ? ka->batch.target[blockIdx.z] : bp.target.data;
+    const char *sbase = reinterpret_cast<const char *>(src_data) + (ptrdiff_t)(scol - bp.source.fx0) * (ptrdiff_t)SPX;
+    const size_t tpx = bp.out_half ? 8 : 16;
+    char *tbase = reinterpret_cast<char *>(dst_data) + (ptrdiff_t)(tcol - bp.target.fx0) * (ptrdiff_t)tpx + (size_t)pair * (tpx / 2);
+    const size_t trow = (size_t)bp.target.pitch * tpx;
+
+    if (lane < PITCH - W) {
+#pragma unroll
+        for (int a = 0; a < 2; a++) { rowS[a][0][W + lane] = make_float4(0.f, 0.f, 0.f, 0.f); rowS[a][1][W + lane] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+    if (lane < 2 * (HALF - W / 2)) {
+        const int par = lane & 1, slot = W / 2 + (lane >> 1);
+#pragma unroll
+        for (int a = 0; a < 2; a++) { rowB[a][0][par][slot] = make_float4(0.f, 0.f, 0.f, 0.f); rowB[a][1][par][slot] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+
+    Px ring1[RL];
+    f32x2 ring2[RL];
+#pragma unroll
+    for (int k = 0; k < RL; k++) { ring1[k].rg = ring1[k].ba = ring2[k] = f32x2{ 0.0f, 0.0f }; }
+
+    auto fetch_row = [&](int ys, bool wanted) -> float4 {
+        const bool live = wanted && scol_live && ys >= bp.sy0 && ys <= bp.sy1;
+        return fetch_px<INH>(sbase + (ptrdiff_t)(ys - bp.source.fy0) * (ptrdiff_t)srow, live);
+    };
+    float4 pre[4];                                             // slot = row % 4 (RL is a multiple of 4)
+    pre[0] = fetch_row(ys0, true);
+    pre[1] = fetch_row(ys0 + 1, steps > 1);
+    const uint32_t col_mask = bcol_live ? 0xFFFFFFFFu : 0u;
+
+    // blurred row rb (0-based in the segment) is complete when source row rb + NT1 - 1 has been filtered; it completes
+    // target row ta + (rb - (NT2 - 1)) / 2 when that is a whole number >= 0.  Step (i, i + 1), i even: stage 2 takes blurred
+    // rows i - NT1 - 1 and i - NT1 (completed by the previous step); the first of them is even, the second odd.
+    for (int i0 = 0; i0 <= steps + 1; i0 += RL) {
+        auto step = [&](auto jc) -> bool {
+            constexpr int j = 2 * decltype(jc)::value;         // == i % RL, even
+            const int i = i0 + j;
+            if (i > steps + 1) return false;                   // uniform over the workgroup
+            const int par = (i >> 1) & 1;
+            pre[(j + 2) % 4] = fetch_row(ys0 + i + 2, i + 2 < steps);
+            pre[(j + 3) % 4] = fetch_row(ys0 + i + 3, i + 3 < steps);
+            if (i < steps) rowS[par][0][lane] = pre[j % 4];
+            if (i + 1 < steps) rowS[par][1][lane] = pre[(j + 1) % 4];
+            __syncthreads();                                   // both rows S of this step and both rows B of the previous one are visible
+
+            // ---- second stage: blurred rows rbx = i - NT1 - 1 (even) and rby = i - NT1 (odd)
+            constexpr int sx = (j + 2 * RL - ((NT1 + 1) % RL)) % RL, sy = (sx + 1) % RL;      // their ring2 slots (== rb % RL)
+            const int rbx = i - NT1 - 1, rby = i - NT1;
+            const int jl = tl < OUTW ? tl : 0;
+            auto h2 = [&](int which) {
+                const float2 *bb0 = reinterpret_cast<const float2 *>(&rowB[par ^ 1][which][0][0]) + pair;      // written by the previous step
+                const float2 *bb1 = reinterpret_cast<const float2 *>(&rowB[par ^ 1][which][1][0]) + pair;
+                return fir1<NT2>(w2, [&](int k) { const float2 v = ((k & 1) ? bb1 : bb0)[2 * (jl + (k >> 1))]; return f32x2{ v.x, v.y }; });
+            };
+            if (rbx >= 0) {
+                ring2[sx] = h2(0);
+                if (rbx >= NT2 - 1) {
+                    const int t = ta + (rbx - (NT2 - 1)) / 2;
+                    const f32x2 o = fir1<NT2>(w2, [&](int k) { return ring2[(sx + RL - (NT2 - 1) + k) % RL]; });
+                    if (out_live && t <= tb) {
+                        char *dst = tbase + (size_t)(t - bp.target.fy0) * trow;
+                        if (bp.out_half) *reinterpret_cast<uint32_t *>(dst) = cvs::f2h_rz2(o.x, o.y);
+                        else *reinterpret_cast<float2 *>(dst) = make_float2(o.x, o.y);
+                    }
+                }
+            }
+            if (rby >= 0) ring2[sy] = h2(1);
+
+            // ---- first stage: H1 of both source rows, then the blurred rows they complete
+            auto stage1 = [&](auto wc) {
+                constexpr int which = decltype(wc)::value, jj = j + which;
+                const int ii = i + which;
+                if (ii < steps) {
+                    const float4 *sb = rowS[par][which];
+                    ring1[jj] = fir<NT1>(w1, [&](int k) { const float4 v = sb[lane + k]; return Px{ f32x2{ v.x, v.y }, f32x2{ v.z, v.w } }; });
+                    if (ii >= NT1 - 1) {
+                        Px b = fir<NT1>(w1, [&](int k) { return ring1[(jj + RL - (NT1 - 1) + k) % RL]; });
+                        const int by = ys0 + ii - C1;
+                        const uint32_t m = (by >= bp.sy0 && by <= bp.sy1) ? col_mask : 0u;
+                        rowB[par][which][lane & 1][lane >> 1] = make_float4(__uint_as_float(__float_as_uint(b.rg.x) & m), __uint_as_float(__float_as_uint(b.rg.y) & m),
+                                                                               __uint_as_float(__float_as_uint(b.ba.x) & m), __uint_as_float(__float_as_uint(b.ba.y) & m));
+                    }
+                }
+            };
+            stage1(std::integral_constant<int, 0>{});
+            stage1(std::integral_constant<int, 1>{});
+            return true;
+        };
+        each_slot(step, std::make_integer_sequence<int, RL / 2>{});
+    }
+}
+
 template <class K>
 int resident_per_cu(K kernel, int block) {
     int n = 0;
@@ -230,16 +366,26 @@ int resident_per_cu(K kernel, int block) {
     return n;
 }
 
+// which form of the sweep (diagnostic build: CVS_BLUR_HALVE_FORM=1 / 2 for A/B runs)
+inline bool two_rows_per_barrier() {
+    static std::atomic<int> cached{ -1 };
+    int v = cached.load(std::memory_order_relaxed);
+    if (v < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_HALVE_FORM"); v = e ? (atoi(e) == 2) : kTwoRowsDefault; cached.store(v, std::memory_order_relaxed); }
+    return v != 0;
+}
+
 template <int NT1, int NT2, int W>
 int launch(cvk_blur_halve_params bp, int cus, hipStream_t s) {
     constexpr int OUTW = (W - NT1 - NT2 + 1) / 2 + 1;
     const int cols = bp.tx1 - bp.tx0 + 1, rows = bp.ty1 - bp.ty0 + 1;
     const int strips = (cols + OUTW - 1) / OUTW;
-    static std::atomic<int> occ[2];                  // (several threads may launch at once: pull-queue workers)
-    std::atomic<int> &cached = occ[bp.in_half ? 1 : 0];
+    const bool two = two_rows_per_barrier();
+    static std::atomic<int> occ[2][2];               // (several threads may launch at once: pull-queue workers)
+    std::atomic<int> &cached = occ[two ? 1 : 0][bp.in_half ? 1 : 0];
     int mine = cached.load(std::memory_order_relaxed);
     if (!mine) {
-        mine = bp.in_half ? resident_per_cu(k_blur_halve<NT1, NT2, W, true>, W) : resident_per_cu(k_blur_halve<NT1, NT2, W, false>, W);
+        if (two) mine = bp.in_half ? resident_per_cu(k_blur_halve2<NT1, NT2, W, true>, W) : resident_per_cu(k_blur_halve2<NT1, NT2, W, false>, W);
+        else     mine = bp.in_half ? resident_per_cu(k_blur_halve<NT1, NT2, W, true>, W) : resident_per_cu(k_blur_halve<NT1, NT2, W, false>, W);
         cached.store(mine, std::memory_order_relaxed);
     }
 #ifdef CVS_DIAG
@@ -258,8 +404,13 @@ int launch(cvk_blur_halve_params bp, int cus, hipStream_t s) {
         bp.rows_per_wg = r;
     }
     dim3 grid((unsigned)strips, (unsigned)((rows + bp.rows_per_wg - 1) / bp.rows_per_wg), (unsigned)nframes);
-    if (bp.in_half) hipLaunchKernelGGL((k_blur_halve<NT1, NT2, W, true>), grid, dim3(W), 0, s, bp);
-    else            hipLaunchKernelGGL((k_blur_halve<NT1, NT2, W, false>), grid, dim3(W), 0, s, bp);
+    if (two) {
+        if (bp.in_half) hipLaunchKernelGGL((k_blur_halve2<NT1, NT2, W, true>), grid, dim3(W), 0, s, bp);
+        else            hipLaunchKernelGGL((k_blur_halve2<NT1, NT2, W, false>), grid, dim3(W), 0, s, bp);
+    } else {
+        if (bp.in_half) hipLaunchKernelGGL((k_blur_halve<NT1, NT2, W, true>), grid, dim3(W), 0, s, bp);
+        else            hipLaunchKernelGGL((k_blur_halve<NT1, NT2, W, false>), grid, dim3(W), 0, s, bp);
+    }
     return (int)hipGetLastError();
 }
 
