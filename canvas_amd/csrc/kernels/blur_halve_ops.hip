@@ -439,7 +439,10 @@ extern "C" int cvk_blur_halve(const cvk_blur_halve_params *bp, int cus, void *st
     int env_w = env_cached.load(std::memory_order_relaxed);
     if (env_w < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_HALVE_WIDTH"); env_w = e ? atoi(e) : 0; env_cached.store(env_w, std::memory_order_relaxed); }
     const int cols = bp->tx1 - bp->tx0 + 1;
-    const int width = env_w == 64 || env_w == 128 || env_w == 256 ? env_w : (cols <= 60 ? 128 : 256);
+    // strips of 256 lanes, except narrow frames -- and batches: callers of the batch entry keep calls in flight, and with
+    // two of them overlapping two-wave workgroups (twice as many barrier groups per CU) are 3 % faster at 4K, 1 % slower
+    // for one call at a time (profiles/r03/config3_batches.txt)
+    const int width = env_w == 64 || env_w == 128 || env_w == 256 ? env_w : (cols <= 60 || bp->batch.n >= 2 ? 128 : 256);
 #ifdef CVS_DIAG
     if (width == 64) return pick<64>(*bp, cus, (hipStream_t)stream);         // experiment: one wave per workgroup, the barrier costs nothing
 #endif
