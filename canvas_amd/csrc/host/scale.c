@@ -38,7 +38,7 @@ static void fir_launch_fell_through(const char *kernel, int rc) {
     (void)hipGetLastError();
     cvs_set_error("%s did not launch (%s): falling back to the next FIR kernel", kernel, hipGetErrorString((hipError_t)rc));
 }
-CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_LANES | CVS_FIR_PATH_HV)); }
+CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_LANES | CVS_FIR_PATH_HV | CVS_FIR_PATH_ONE_COLUMN | CVS_FIR_PATH_TWO_COLUMNS)); }
 
 typedef struct {
     int t0, t1;            /* target lines covered by the table */
@@ -845,9 +845,11 @@ static int blur_fused_over_batch(void *tdata, const box2i *tfull, int out_half, 
             if (!(ntaps & 1) || ntaps > 31) return 1;                 /* the batched form exists for the odd lists of blur_kernel.hpp */
             bp.batch = *batch;
         }
+        const int pin = atomic_load(&g_fir_path);
+        bp.flags = (pin & CVS_FIR_PATH_ONE_COLUMN ? CVK_BLUR_ONE_COLUMN : 0) | (pin & CVS_FIR_PATH_TWO_COLUMNS ? CVK_BLUR_TWO_COLUMNS : 0);
         int rc = cvk_blur(&bp, cvs_cus(), s);
         if (rc != 0) { cvs_set_error("blur launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
-        t_fir_kernel = CVS_FIR_KERNEL_WINDOW;
+        t_fir_kernel = cvk_blur_takes_pairs(&bp) ? CVS_FIR_KERNEL_WINDOW_PAIR : CVS_FIR_KERNEL_WINDOW;
         return 0;
     }
     if (nover > 0 || batch) return 1;   /* the gather kernel has no epilogue and takes one frame: the caller goes node by node / frame by frame */

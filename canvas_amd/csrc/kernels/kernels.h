@@ -184,12 +184,19 @@ typedef struct {
     int step;                  /* target line t reads source lines step*t - ntaps/2 + k; 0 or 1: blur, 2: halving resampler */
     float taps[32];
     int nover;                 /* f16 frames blended over the blur result before the (f16) store; 0..CVK_BLUR_MAX_OVER */
-    int pad;
+    int flags;                 /* CVK_BLUR_* */
     const void *over[CVK_BLUR_MAX_OVER];       /* rgba_f16 device buffers laid out exactly like `target` */
     cvk_frame_batch batch;                     /* batch.n frames of this geometry (their pointers replace target / source / over) */
 } cvk_blur_params;
+#define CVK_BLUR_ONE_COLUMN  1   /* never the two-columns-per-lane form */
+#define CVK_BLUR_TWO_COLUMNS 2   /* that form wherever it takes the launch (by itself cvk_blur keeps it for frames of 256 columns and more) */
 int cvk_blur_supported(int ntaps, int step);
 int cvk_blur(const cvk_blur_params *bp, int cus, void *stream);
+int cvk_blur_takes_pairs(const cvk_blur_params *bp);      /* would cvk_blur launch k_blur_pair for this? */
+/* the same blur with two target columns per lane (blur_pair_ops.hip): f16 in and out, 1:1, 3..9 taps odd, every buffer,
+ * window and pitch such that a pair of columns is one whole, aligned 16-byte access.  cvk_blur goes there by itself. */
+int cvk_blur_pair_supported(const cvk_blur_params *bp);
+int cvk_blur_pair(const cvk_blur_params *bp, int cus, void *stream);
 
 /* blur (ntaps1 odd, one list for every line) followed by the Lanczos halving resampler (ntaps2 taps, target line t reads
  * blurred lines 2t - ntaps2/2 + k), both separable, in one sweep: blur_halve_ops.hip.  The blurred frame exists only

@@ -381,7 +381,9 @@ CVS_EXPORT int cvs_blur_lanczos_f16_batch_dev(rgba_frame_f16 *const *targets, co
  * All compute the same sums in the same order -- results are bit-equal, which the parity tests show by pinning each kernel
  * in turn through this call.  It changes speed only, never pixels; process-wide; 0 restores the automatic choice. */
 enum { CVS_FIR_PATH_AUTO = 0, CVS_FIR_PATH_SWEEP = 1 /* lane per pixel */, CVS_FIR_PATH_TILED = 2, CVS_FIR_PATH_TABLES = 4 /* skip the register-window kernel */,
-       CVS_FIR_PATH_LANES = 8 /* lane per channel */, CVS_FIR_PATH_HV = 16 /* per-line gather, horizontal pass first (the automatic first choice) */ };
+       CVS_FIR_PATH_LANES = 8 /* lane per channel */, CVS_FIR_PATH_HV = 16 /* per-line gather, horizontal pass first (the automatic first choice) */,
+       CVS_FIR_PATH_ONE_COLUMN = 32 /* the register-window blur with one column per lane, never two */,
+       CVS_FIR_PATH_TWO_COLUMNS = 64 /* ... with two columns per lane wherever that form takes the launch, narrow frames included */ };
 CVS_EXPORT void cvs_fir_path_override(int mode);
 /* Which kernel the calling thread's last FIR launch (scaler, blur, Lanczos resample, blur + resample) went to -- what a
  * test pinned to one kernel asserts, and what tells a silent fallback from the intended kernel.  A fused kernel that was
@@ -395,7 +397,8 @@ enum { CVS_FIR_KERNEL_NONE = 0,
        CVS_FIR_KERNEL_STREAM = 6,      /* k_fir_stream: lane-per-pixel sweep */
        CVS_FIR_KERNEL_TWO_PASS = 7,    /* two k_fir launches through an f32 frame (cached tables) */
        CVS_FIR_KERNEL_PASS = 8,        /* k_fir: one pass of the triangle scaler (both passes: two of these) */
-       CVS_FIR_KERNEL_HV = 9 };        /* k_fir_hv: per-line tables, horizontal pass first, gather per target line */
+       CVS_FIR_KERNEL_HV = 9,          /* k_fir_hv: per-line tables, horizontal pass first, gather per target line */
+       CVS_FIR_KERNEL_WINDOW_PAIR = 10 };  /* k_blur_pair: the register-window blur with two columns per lane (f16, up to 9 taps) */
 CVS_EXPORT int cvs_fir_last_kernel(void);
 
 /* ------------------------------------------------------------------ (3) fused chain: BASELINE config 2

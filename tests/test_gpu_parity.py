@@ -842,7 +842,8 @@ def force_fir(request):
 
 _KERNEL_NAMES = {_lib.FIR_KERNEL_NONE: "none", _lib.FIR_KERNEL_WINDOW: "window", _lib.FIR_KERNEL_HALVE: "halve", _lib.FIR_KERNEL_LANES: "lanes",
                  _lib.FIR_KERNEL_VH: "vh", _lib.FIR_KERNEL_TILED: "tiled", _lib.FIR_KERNEL_STREAM: "stream",
-                 _lib.FIR_KERNEL_TWO_PASS: "two-pass", _lib.FIR_KERNEL_PASS: "pass", _lib.FIR_KERNEL_HV: "hv"}
+                 _lib.FIR_KERNEL_TWO_PASS: "two-pass", _lib.FIR_KERNEL_PASS: "pass", _lib.FIR_KERNEL_HV: "hv",
+                 _lib.FIR_KERNEL_WINDOW_PAIR: "window-pair"}
 _FIR_SEEN = {}
 
 
@@ -1359,6 +1360,115 @@ def test_blur_over_fused(cvs, orc, nover, ntaps, size):
     got = _blur_over(cvs, full, src, taps, overlays)
     assert same_window(got.current_window, want.current_window)
     assert_same_f16(got.array, want.array, "blur+over fused")
+
+
+@pytest.fixture
+def blur_columns():
+    """Pins the register-window blur to its one-column-per-lane or its two-columns-per-lane form (cvs_fir_path_override)."""
+    lib = _lib.load()
+
+    def pin(columns):
+        lib.cvs_fir_path_override({1: _lib.FIR_PATH_ONE_COLUMN, 2: _lib.FIR_PATH_TWO_COLUMNS, None: _lib.FIR_PATH_AUTO}[columns])
+    yield pin
+    pin(None)
+
+
+def _blur_kernel_seen(cvs):
+    assert _lib.last_error() == "", _lib.last_error()
+    return _KERNEL_NAMES[cvs.cvs_fir_last_kernel()]
+
+
+# (full frame, source window, does the two-column form take it?)
+_PAIR_GEOMETRIES = [
+    ((0, 0, 299, 40), None, True),                    # three 120-column strips, the last one partly filled
+    ((0, 0, 61, 19), None, True),                     # one narrow strip
+    ((0, 0, 129, 39), (4, 3, 121, 35), True),         # a source window inside its buffer, on pair boundaries: skipped taps on all four sides
+    ((0, 0, 129, 39), (5, 3, 120, 35), False),        # ... starting on an odd column: pairs would straddle the window's edge
+    ((0, 0, 130, 39), None, False),                   # an odd width
+    ((-6, -3, 123, 30), (-6, -3, 123, 30), True),     # negative coordinates
+]
+
+
+@pytest.mark.parametrize("full,scur,pairs", _PAIR_GEOMETRIES)
+@pytest.mark.parametrize("ntaps", [3, 5, 7, 9, 11])
+@pytest.mark.parametrize("nover", [0, 1, 3, 4])
+def test_blur_two_columns_per_lane_is_the_one_column_blur(cvs, orc, blur_columns, full, scur, pairs, ntaps, nover):
+    """k_blur_pair (two neighbouring columns per lane, buffer loads with range-checked rows, blends on pixel pairs) against
+    the oracle and, code for code, against k_blur on the same frames; launches it cannot take (pairs that would straddle
+    an edge, more than 9 taps) must say so and run on k_blur."""
+    from tests.util import oracle_blur_over
+    from canvas_amd.synth import truncate_to_half
+    rng = np.random.default_rng(9300 + ntaps * 10 + nover)
+    src = rand_f16_frame(rng, full, scur or full)
+    overlays = [HostFrame(full, np.uint16, truncate_to_half(rand_f32_frame(rng, full, full, alpha="mixed", lo=-0.25, hi=1.5).array))
+                for _ in range(nover)]
+    taps = synth.gaussian_taps(ntaps, 1.5)
+    want = oracle_blur_over(orc, src, taps, overlays)
+    cvs.cvs_clear_last_error()
+    blur_columns(2)
+    got2 = _blur_over(cvs, full, src, taps, overlays)
+    # (layers over a blur whose source does not cover the frame go node by node: the blur then writes an f32 frame, on k_blur)
+    fused = nover == 0 or scur is None or scur == full
+    assert _blur_kernel_seen(cvs) == ("window-pair" if pairs and ntaps <= 9 and fused else "window")
+    blur_columns(1)
+    got1 = _blur_over(cvs, full, src, taps, overlays)
+    assert _blur_kernel_seen(cvs) == "window"
+    assert same_window(got2.current_window, want.current_window) and same_window(got1.current_window, want.current_window)
+    assert_same_f16(got2.window_view(), want.window_view(), "two columns per lane against the oracle")
+    assert_same_f16(got2.array, got1.array, "two columns per lane against one")
+
+
+def test_blur_two_columns_per_lane_with_special_values(cvs, orc, blur_columns):
+    """Zeros (whole black regions: the blend's fast reciprocal path must hand over to the IEEE divide), exact alpha 0 and 1,
+    denormals, the largest halfs (sums beyond the half range must come out as infinities), Inf and NaN."""
+    from tests.util import oracle_blur_over
+    rng = np.random.default_rng(9400)
+    full = (0, 0, 259, 47)
+    src = rand_f16_frame(rng, full, full)
+    src.array[:, 40:90] = 0                                   # black AND transparent
+    src.array[10:30, 100:140, 3] = 0x3C00                     # opaque
+    src.array[5:9, 150:170, :3] = 0x7BFF                      # 65504: nine of them overflow the half range
+    src.array[20, 200] = [0x7C00, 0xFC00, 0x7E00, 0x3C00]     # Inf, -Inf, NaN
+    src.array[31, 7] = [0x0001, 0x8001, 0x03FF, 0x0001]       # denormals
+    overlays = [rand_f16_frame(rng, full, full) for _ in range(3)]
+    overlays[0].array[:, 60:120, 3] = 0                       # transparent over black: 0 / 0
+    overlays[1].array[:, 100:160, 3] = 0x3C00
+    overlays[1].array[12:20, 10:30] = 0
+    overlays[2].array[25, 50] = [0x7BFF, 0xFBFF, 0x7C00, 0x3800]
+    overlays[2].array[26, 51] = [0x0001, 0x0002, 0x8003, 0x0001]
+    taps = synth.gaussian_taps(9, 1.5)
+    want = oracle_blur_over(orc, src, taps, overlays)
+    for nover in (3, 1, 0):
+        want = oracle_blur_over(orc, src, taps, overlays[:nover])
+        cvs.cvs_clear_last_error()
+        blur_columns(2)
+        got = _blur_over(cvs, full, src, taps, overlays[:nover])
+        assert _blur_kernel_seen(cvs) == "window-pair"
+        assert_same_f16(got.array, want.array, "special values, %d layers" % nover)
+        blur_columns(1)
+        assert_same_f16(_blur_over(cvs, full, src, taps, overlays[:nover]).array, got.array, "special values, %d layers, against one column per lane" % nover)
+
+
+def test_blur_over_batch_on_two_columns_per_lane(cvs, orc, blur_columns):
+    """The batched launch (grid.z = frame) of the two-column form: five frames, each the single call's pixels."""
+    from tests.util import oracle_blur_over
+    w, h, count, nover = 244, 37, 5, 3
+    full = (0, 0, w - 1, h - 1)
+    rng = np.random.default_rng(9500)
+    taps = synth.gaussian_taps(9, 1.5)
+    srcs = [rand_f16_frame(rng, full, full) for _ in range(count)]
+    ovs = [[rand_f16_frame(rng, full, full) for _ in range(nover)] for _ in range(count)]
+    d_src = [DeviceFrame.from_host(f) for f in srcs]
+    d_ov = [[DeviceFrame.from_host(f) for f in fs] for fs in ovs]
+    d_out = [DeviceFrame(full, np.uint16) for _ in range(count)]
+    cvs.cvs_clear_last_error()
+    blur_columns(2)
+    _lib.check(cvs.cvs_blur_over_f16_batch_dev(_frame_table(d_out), _frame_table(d_src), f32p(taps), 9,
+                                               _frame_table([o for fs in d_ov for o in fs]), nover, count, None))
+    assert _blur_kernel_seen(cvs) == "window-pair"
+    for i in range(count):
+        want = oracle_blur_over(orc, srcs[i], taps, ovs[i])
+        assert_same_f16(d_out[i].download().array, want.array, "frame %d of the batch" % i)
 
 
 @pytest.mark.parametrize("case", ["ragged", "even_taps", "five_layers", "no_layers", "small_source"])
