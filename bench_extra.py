@@ -244,7 +244,7 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
                   "72 B/px is BASELINE's per-node denominator; the launches move %d B/px; eight frames in two groups of four on two HIP streams: "
                   "a colour launch per frame, one blur + over launch per group (cvs_blur_over_f16_batch_dev)" % BYTES_PER_PIXEL,
                   rank, {"moved_bytes_per_px": BYTES_PER_PIXEL}, moved_bytes_per_px=BYTES_PER_PIXEL,
-                  kernels=["k_color_flat (8 r + 8 w)", "k_blur<9, 256, f16, over epilogue> (8 r + 3 x 8 r + 8 w; four frames per launch)"])
+                  kernels=["k_color_flat (8 r + 8 w)", "k_blur_pair<9 taps, 3 layers> (two columns per lane; 8 r + 3 x 8 r + 8 w; four frames per launch)"])
     if rec:
         out.append(rec)
     lib.cvs_stream_destroy(streams[1])

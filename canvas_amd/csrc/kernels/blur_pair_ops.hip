@@ -123,10 +123,15 @@ __global__ __launch_bounds__(W) void k_blur_pair(cvk_blur_params bp) {
         for (int l = 0; l < NOV; l++) r.v[l] = load_pair(row_rsrc(over_data[l], o, emits ? orect : 0u), toff);
         return r;
     };
-    // everything a step needs was requested two steps before it (NT >= 3: the first completing step is never one of the first two)
+    // A row goes to LDS during the step BEFORE the one that filters it (right behind that step's reads, into the other
+    // buffer), so no step starts by waiting for its own write (2 % on the launch); the rows in flight are those of steps
+    // i+1 .. i+3, the upper layers are requested one step ahead (a second set in flight would cost the third wave per SIMD).
     u32x4 cur = fetch_row(ys0, true);
-    u32x4 nxt = fetch_row(ys0 + 1, steps > 1);
-    Layers ov_cur = fetch_layers(0), ov_nxt = fetch_layers(1);
+    rowbuf[0][0][lane] = widen_px(cur.x, cur.y);
+    rowbuf[0][1][lane] = widen_px(cur.z, cur.w);
+    cur = fetch_row(ys0 + 1, steps > 1);
+    u32x4 nxt = fetch_row(ys0 + 2, steps > 2);
+    Layers ov_cur = fetch_layers(0);                          // (NT >= 3: step 0 completes nothing)
 
     for (int i0 = 0; i0 < steps; i0 += NT) {
         // NT steps with the ring slot as a compile-time constant
@@ -136,18 +141,20 @@ __global__ __launch_bounds__(W) void k_blur_pair(cvk_blur_params bp) {
             if (i >= steps) return false;                     // uniform over the workgroup
             const bool emits = i >= NT - 1;                   // uniform
             const int t = ta + (i - (NT - 1));                // the target row this step completes
-            const u32x4 far = fetch_row(ys0 + i + 2, i + 2 < steps);
-            const Layers ov_far = fetch_layers(i + 2);
+            const u32x4 far = fetch_row(ys0 + i + 3, i + 3 < steps);
+            const Layers ov_nxt = fetch_layers(i + 1);
             float4 (*buf)[PITCH] = rowbuf[i & 1];
-            buf[0][lane] = widen_px(cur.x, cur.y);
-            buf[1][lane] = widen_px(cur.z, cur.w);
-            cur = nxt;
-            nxt = far;
             __syncthreads();
             // the NT + 1 neighbours both sums draw on: source column 2 * lane + D + c of the strip
             float4 v[NT + 1];
 #pragma unroll
             for (int c = 0; c <= NT; c++) v[c] = buf[(c + D) & 1][lane + ((c + D) >> 1)];
+            // the next step's row, into the other buffer (last read a step ago)
+            float4 (*nbuf)[PITCH] = rowbuf[(i + 1) & 1];
+            nbuf[0][lane] = widen_px(cur.x, cur.y);
+            nbuf[1][lane] = widen_px(cur.z, cur.w);
+            cur = nxt;
+            nxt = far;
             // four chains side by side (two channel pairs x two pixels): a packed add never sits right behind the multiply it needs
             f32x2 rg0, ba0, rg1, ba1;
 #pragma unroll
@@ -183,7 +190,6 @@ __global__ __launch_bounds__(W) void k_blur_pair(cvk_blur_params bp) {
                 __builtin_amdgcn_raw_buffer_store_b128(codes, row_rsrc(dst_data, (size_t)((ptrdiff_t)(t - bp.target.fy0) * (ptrdiff_t)trow + trect0), wrect), (int)toff, 0, 0);
             }
             ov_cur = ov_nxt;
-            ov_nxt = ov_far;
             return true;
         };
         each_slot(step, std::make_integer_sequence<int, NT>{});

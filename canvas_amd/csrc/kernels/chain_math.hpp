@@ -190,15 +190,28 @@ __device__ __forceinline__ u32x4 narrow_pair(px32x2 v) {
 
 // ---- the same blend and truncation with the checks in their cheapest form (blur_pair_ops.hip, whose sweep is bound by vector
 // issue, not by memory like the chain kernel's) -------------------------------------------------------------------
-// |x| extrema of three values in ONE instruction: hipcc's fmaxf(fabsf(a), fabsf(b)) first canonicalises each operand with
-// a v_max_f32 of its own (16 instructions for the band check of one blended pair, 8 this way).  A quiet NaN operand is
-// dropped and a signalling one comes out as NaN (which fails both comparisons below: the plain path, as before).
-__device__ __forceinline__ float absmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-__device__ __forceinline__ float absmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// |x| extrema with v_max3_f32 / v_min3_f32 and |abs| operand modifiers: hipcc's fmaxf(fabsf(a), fabsf(b)) first canonicalises each
+// operand with a v_max_f32 of its own (16 instructions for the band check of one blended pair, 8 this way).  A quiet NaN
+// operand is dropped and a signalling one comes out as NaN (which fails both comparisons below: the plain path, as before).
+// largest and smallest magnitude of eight values: eight instructions in ONE statement (after every asm statement hipcc leaves
+// a wait state, not knowing what it ended with; plain VALU results feeding plain VALU operands need none on gfx950)
+__device__ __forceinline__ void abs_extrema8(float a, float b, float c, float d, float e, float f, float g, float h, float &hi, float &lo) {
+    float t0, t1, t2, u0, u1, u2;
+    asm("v_max3_f32 %2, |%8|, |%9|, |%10|\n\t"
+        "v_max3_f32 %3, |%11|, |%12|, |%13|\n\t"
+        "v_max3_f32 %4, |%14|, |%15|, |%15|\n\t"
+        "v_min3_f32 %5, |%8|, |%9|, |%10|\n\t"
+        "v_min3_f32 %6, |%11|, |%12|, |%13|\n\t"
+        "v_min3_f32 %7, |%14|, |%15|, |%15|\n\t"
+        "v_max3_f32 %0, %2, %3, %4\n\t"
+        "v_min3_f32 %1, %5, %6, %7"
+        : "=&v"(hi), "=&v"(lo), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(u0), "=&v"(u1), "=&v"(u2)
+        : "v"(a), "v"(b), "v"(c), "v"(d), "v"(e), "v"(f), "v"(g), "v"(h));
+}
 
 __device__ __forceinline__ bool div_band_lean(f32x2 n0, f32x2 n1, f32x2 n2, f32x2 d) {
-    const float hi = absmax3(absmax3(n0.x, n0.y, n1.x), absmax3(n1.y, n2.x, n2.y), absmax3(d.x, d.y, d.y));
-    const float lo = absmin3(absmin3(n0.x, n0.y, n1.x), absmin3(n1.y, n2.x, n2.y), absmin3(d.x, d.y, d.y));
+    float hi, lo;
+    abs_extrema8(n0.x, n0.y, n1.x, n1.y, n2.x, n2.y, d.x, d.y, hi, lo);
     return lo >= 0x1p-60f && hi < 0x1p60f;
 }
 
@@ -209,35 +222,48 @@ __device__ __forceinline__ px32x2 over_pair_uniform(px32x2 lo, px32x2 b) {
     const f32x2 alpha_b = b.a;                       // b.a * 1.0f
     const f32x2 alpha_a = lo.a * (1.0f - b.a);
     const f32x2 a = alpha_a + alpha_b;
+    // the refined reciprocal of the blended alpha is started here, ahead of the products it does not depend on, so that the
+    // two waits of its chain (reciprocal -> packed FMA -> packed FMA) are filled with them; unused when every alpha is 1.0f
+    f32x2 r = { __builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y) };
+    const f32x2 nd = -a;
     px32x2 o;
-    o.r = lo.r * alpha_a + b.r * alpha_b;
-    o.g = lo.g * alpha_a + b.g * alpha_b;
-    o.b = lo.b * alpha_a + b.b * alpha_b;
+    const f32x2 pr = lo.r * alpha_a, qr = b.r * alpha_b, pg = lo.g * alpha_a, qg = b.g * alpha_b, pb = lo.b * alpha_a, qb = b.b * alpha_b;
+    const f32x2 r1 = fma2(nd, r, f32x2{ 1.0f, 1.0f });
+    o.r = pr + qr; o.g = pg + qg;
+    r = fma2(r1, r, r);
+    asm volatile("" : "+v"(r));                      // (keeps the chain up here: hipcc would sink it into the branch that uses it)
+    o.b = pb + qb;
     o.a = a;
     if (wave_any(!(a.x == 1.0f && a.y == 1.0f))) {
-        if (!wave_any(!div_band_lean(o.r, o.g, o.b, a))) {
-            f32x2 r = { __builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y) };
-            const f32x2 nd = -a;
-            r = fma2(fma2(nd, r, f32x2{ 1.0f, 1.0f }), r, r);
-            f32x2 q0 = o.r * r, q1 = o.g * r, q2 = o.b * r;
-            f32x2 e0 = fma2(nd, q0, o.r), e1 = fma2(nd, q1, o.g), e2 = fma2(nd, q2, o.b);
-            q0 = fma2(e0, r, q0); q1 = fma2(e1, r, q1); q2 = fma2(e2, r, q2);
-            e0 = fma2(nd, q0, o.r); e1 = fma2(nd, q1, o.g); e2 = fma2(nd, q2, o.b);
-            o.r = fma2(e0, r, q0); o.g = fma2(e1, r, q1); o.b = fma2(e2, r, q2);
-        } else {
+        // the quotients are formed without asking first (outside the band they are garbage, never a trap) and replaced on
+        // the plain path: written this way round, the copies that join the two paths sit on the rare one
+        const bool in_band = div_band_lean(o.r, o.g, o.b, a);
+        f32x2 q0 = o.r * r, q1 = o.g * r, q2 = o.b * r;
+        f32x2 e0 = fma2(nd, q0, o.r), e1 = fma2(nd, q1, o.g), e2 = fma2(nd, q2, o.b);
+        q0 = fma2(e0, r, q0); q1 = fma2(e1, r, q1); q2 = fma2(e2, r, q2);
+        e0 = fma2(nd, q0, o.r); e1 = fma2(nd, q1, o.g); e2 = fma2(nd, q2, o.b);
+        q0 = fma2(e0, r, q0); q1 = fma2(e1, r, q1); q2 = fma2(e2, r, q2);
+        if (wave_any(!in_band)) {
             rare_path();
-            o.r = f32x2{ o.r.x / a.x, o.r.y / a.y };
-            o.g = f32x2{ o.g.x / a.x, o.g.y / a.y };
-            o.b = f32x2{ o.b.x / a.x, o.b.y / a.y };
-            if (a.x == 0.0f) { o.r.x = 0.0f; o.g.x = 0.0f; o.b.x = 0.0f; o.a.x = 0.0f; }
-            if (a.y == 0.0f) { o.r.y = 0.0f; o.g.y = 0.0f; o.b.y = 0.0f; o.a.y = 0.0f; }
+            q0 = f32x2{ o.r.x / a.x, o.r.y / a.y };
+            q1 = f32x2{ o.g.x / a.x, o.g.y / a.y };
+            q2 = f32x2{ o.b.x / a.x, o.b.y / a.y };
+            if (a.x == 0.0f) { q0.x = 0.0f; q1.x = 0.0f; q2.x = 0.0f; o.a.x = 0.0f; }
+            if (a.y == 0.0f) { q0.y = 0.0f; q1.y = 0.0f; q2.y = 0.0f; o.a.y = 0.0f; }
         }
+        o.r = q0; o.g = q1; o.b = q2;
     }
     return o;
 }
 
 __device__ __forceinline__ u32x4 narrow_pair_lean(px32x2 v) {
-    const float big = absmax3(absmax3(v.r.x, v.g.x, v.b.x), absmax3(v.a.x, v.r.y, v.g.y), absmax3(v.b.y, v.a.y, v.a.y));
+    float big, t0, t1;
+    asm("v_max3_f32 %1, |%3|, |%4|, |%5|\n\t"
+        "v_max3_f32 %2, |%6|, |%7|, |%8|\n\t"
+        "v_max3_f32 %0, |%9|, |%10|, %1\n\t"
+        "v_max_f32 %0, %0, %2"
+        : "=&v"(big), "=&v"(t0), "=&v"(t1)
+        : "v"(v.r.x), "v"(v.g.x), "v"(v.b.x), "v"(v.a.x), "v"(v.r.y), "v"(v.g.y), "v"(v.b.y), "v"(v.a.y));
     if (wave_any(!(big < 65536.0f))) { rare_path(); v.r = saturate_to_inf2(v.r); v.g = saturate_to_inf2(v.g); v.b = saturate_to_inf2(v.b); v.a = saturate_to_inf2(v.a); }
     return u32x4{ pkrtz(v.r.x, v.g.x), pkrtz(v.b.x, v.a.x), pkrtz(v.r.y, v.g.y), pkrtz(v.b.y, v.a.y) };
 }

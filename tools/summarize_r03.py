@@ -133,7 +133,7 @@ PX4K, PX1080, PX8K = 3840 * 2160, 1920 * 1080, 7680 * 4320
 KERNELS = [
     ("k_blur_halve2<", 8, 4, 4 * (PX4K * 8 + PX1080 * 8), "config 3: four 4K f16 frames in, four 1080p f16 frames out per launch (a lane stores one channel pair: 4 B)"),
     ("k_color_flat", 16, 16, PX4K * 16, "config 5, launch 1: colour filter 8 r + 8 w per px (pixel pairs: 16 B per lane)"),
-    ("k_blur<9, 256, true, true, 1>", 8, 8, PX4K * 40, "config 5, launch 2: blur + 3 overlays + store = 8 r + 24 r + 8 w per px"),
+    ("k_blur_pair<9, 64, 3>", 16, 16, PX4K * 40, "config 5, launch 2: blur + 3 overlays + store = 8 r + 24 r + 8 w per px (two columns per lane: 16 B accesses)"),
     ("k_fir_vh<", 8, 16, PX1080 * 8 + PX4K * 8, "scaler 1080p -> 4K f16"),
     ("k_chain<3, 1", 16, 16, PX8K * 32, "config 4: three 8K layers in, one out"),
 ]
@@ -152,7 +152,7 @@ except SystemExit:
 xs = {}
 for pat, lb, sb, algo_b, note in KERNELS:
     d = [t for n, t in tr if pat in n]
-    if tr_c5 is not None and ("k_color_flat" in pat or "k_blur<9" in pat):
+    if tr_c5 is not None and ("k_color_flat" in pat or "k_blur_pair<9" in pat):
         d = [t for n, t in tr_c5 if pat in n]            # one stream: the kernel alone on the chip
         note += "; durations from tools/bench_stream.py --streams 1 (one frame per launch; in the bench its frames alternate over two streams and overlap)"
     if tr_vh is not None and "k_fir_vh" in pat:
@@ -172,7 +172,7 @@ for pat, lb, sb, algo_b, note in KERNELS:
         rfac = rf16 if lb == 16 else rf8
         wfac = 1.0 if sb == 16 else wf8
         fb, wb = sum(f) / len(f) * 1024 * rfac, sum(w_) / len(w_) * 1024 * wfac
-        if "k_blur<9" in pat:                            # counted on the extras' launches of four frames
+        if "k_blur_pair<9" in pat:                            # counted on the extras' launches of four frames
             fb, wb = fb / 4, wb / 4
         rec["traffic"] = {"FETCH_SIZE_KiB_mean": round(sum(f) / len(f), 1), "read_factor_applied": rfac, "read_bytes": round(fb),
                           "WRITE_SIZE_KiB_mean": round(sum(w_) / len(w_), 1), "write_factor_applied": wfac, "written_bytes": round(wb),

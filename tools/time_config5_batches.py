@@ -24,11 +24,11 @@ def timed(fn, frames_per_pass):
         for _ in range(10): fn()
         sync(); best = min(best, (time.perf_counter() - t0) / (10 * frames_per_pass))
     return best * 1e3
-for ns in (2,):
+for ns in (1, 2, 3, 4):
     def per_frame():
         for i in range(RING): g.render(i, streams[i % ns])
     print("per frame, %d stream(s): %.4f ms per frame" % (ns, timed(per_frame, RING)), flush=True)
-for per, ns in ((4, 1), (4, 2), (8, 2)):
+for per, ns in ((2, 2), (2, 3), (4, 1), (4, 2), (4, 3), (8, 2)):
     views = [bench_extra.GraphStreamView(g, list(range(a, a + per))) for a in range(0, RING, per)]
     def batched():
         for k, v in enumerate(views): v.render(streams[k % ns])
