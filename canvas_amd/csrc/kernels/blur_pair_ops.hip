@@ -182,7 +182,7 @@ __global__ __launch_bounds__(W) void k_blur_pair(cvk_blur_params bp) {
                     acc.r = f32x2{ org0.x, org1.x }; acc.g = f32x2{ org0.y, org1.y };
                     acc.b = f32x2{ oba0.x, oba1.x }; acc.a = f32x2{ oba0.y, oba1.y };
 #pragma unroll
-                    for (int l = 0; l < NOV; l++) acc = cvs::over_pair_uniform(acc, cvs::widen_pair(ov_cur.v[l]));
+                    for (int l = 0; l < NOV; l++) acc = cvs::over_pair_uniform(acc, ov_cur.v[l]);
                     codes = cvs::narrow_pair_lean(acc);
                 } else {
                     codes = u32x4{ cvs::f2h_rz2(org0.x, org0.y), cvs::f2h_rz2(oba0.x, oba0.y), cvs::f2h_rz2(org1.x, org1.y), cvs::f2h_rz2(oba1.x, oba1.y) };

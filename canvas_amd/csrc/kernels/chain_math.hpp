@@ -218,16 +218,37 @@ __device__ __forceinline__ bool div_band_lean(f32x2 n0, f32x2 n1, f32x2 n2, f32x
 // over_pair with wave-uniform control flow only: when ANY lane of the wave has a blended alpha other than 1.0f every lane
 // divides (x / 1.0f == x exactly, by either path), so no exec-mask region and no merge copies surround the quotients; and
 // the alpha == 0 fix-up lives on the plain path alone (inside the band |alpha| >= 2^-60 in every lane).
-__device__ __forceinline__ px32x2 over_pair_uniform(px32x2 lo, px32x2 b) {
-    const f32x2 alpha_b = b.a;                       // b.a * 1.0f
-    const f32x2 alpha_a = lo.a * (1.0f - b.a);
+// The colour channels of the upper layer times their weight, straight from the halfs: v_fma_mix_f32 widens its f16 operand and
+// multiplies in one instruction (fma(widen(h), w, +0): the product, rounded once -- what v_cvt_f32_f16 + v_mul_f32 give in
+// two, except that an exactly zero product is always +0: the sign of a zero, which nothing here pins; half denormals are
+// kept, as by the conversion).  `code`: the dword holding the half, HI: its upper 16 bits.
+// All six products of a layer pair in ONE statement (hipcc leaves a wait state behind every asm statement).
+__device__ __forceinline__ void halves_times(u32x4 up, f32x2 w, f32x2 &qr, f32x2 &qg, f32x2 &qb) {
+    float r0, r1, g0, g1, b0, b1;
+    asm("v_fma_mix_f32 %0, %6, %10, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %1, %8, %11, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %2, %6, %10, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %3, %8, %11, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %4, %7, %10, 0 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %5, %9, %11, 0 op_sel_hi:[1,0,0]"
+        : "=&v"(r0), "=&v"(r1), "=&v"(g0), "=&v"(g1), "=&v"(b0), "=&v"(b1)
+        : "v"(up.x), "v"(up.y), "v"(up.z), "v"(up.w), "v"(w.x), "v"(w.y));
+    qr = f32x2{ r0, r1 }; qg = f32x2{ g0, g1 }; qb = f32x2{ b0, b1 };
+}
+
+// `up`: the upper layer's two pixels as loaded (dwords g:r, a:b of the first pixel, then of the second)
+__device__ __forceinline__ px32x2 over_pair_uniform(px32x2 lo, u32x4 up) {
+    const f32x2 alpha_b = { h2f(up.y >> 16), h2f(up.w >> 16) };       // b.a * 1.0f
+    const f32x2 alpha_a = lo.a * (1.0f - alpha_b);
     const f32x2 a = alpha_a + alpha_b;
     // the refined reciprocal of the blended alpha is started here, ahead of the products it does not depend on, so that the
     // two waits of its chain (reciprocal -> packed FMA -> packed FMA) are filled with them; unused when every alpha is 1.0f
     f32x2 r = { __builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y) };
     const f32x2 nd = -a;
     px32x2 o;
-    const f32x2 pr = lo.r * alpha_a, qr = b.r * alpha_b, pg = lo.g * alpha_a, qg = b.g * alpha_b, pb = lo.b * alpha_a, qb = b.b * alpha_b;
+    const f32x2 pr = lo.r * alpha_a, pg = lo.g * alpha_a, pb = lo.b * alpha_a;
+    f32x2 qr, qg, qb;
+    halves_times(up, alpha_b, qr, qg, qb);
     const f32x2 r1 = fma2(nd, r, f32x2{ 1.0f, 1.0f });
     o.r = pr + qr; o.g = pg + qg;
     r = fma2(r1, r, r);
