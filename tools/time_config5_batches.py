@@ -9,6 +9,8 @@ if os.environ.get("CANVAS_DIAG") == "1":
 from canvas_amd import _lib, synth, REC709_RGB_TO_YPBPR
 from canvas_amd.stream import GraphStream
 import bench_extra
+if os.environ.get("CANVAS_LIB"):                      # A/B runs: another build of the library (never set by the package)
+    _lib.LIB_PATH = os.environ["CANVAS_LIB"]
 lib = _lib.load(); _lib.check(lib.cvs_init(0)); lib.init_half()
 w, h = 3840, 2160
 RING = 24

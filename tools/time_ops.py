@@ -12,6 +12,8 @@ from canvas_amd import REC709_RGB_TO_YPBPR, _lib, synth  # noqa: E402
 from canvas_amd.abi import box2i  # noqa: E402
 from canvas_amd.device import DeviceFrame  # noqa: E402
 
+if os.environ.get("CANVAS_LIB"):                      # A/B runs: another build of the library (never set by the package)
+    _lib.LIB_PATH = os.environ["CANVAS_LIB"]
 lib = _lib.load()
 _lib.check(lib.cvs_init(0))
 lib.init_half()
