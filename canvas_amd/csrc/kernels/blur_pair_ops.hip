@@ -1,5 +1,5 @@
 // blur_pair_ops.hip -- the register-window blur of blur_kernel.hpp with TWO neighbouring target columns per lane (f16 in,
-// f16 out, 1:1, 3..15 taps odd), with or without the workspace stack's over epilogue.
+// f16 out, 1:1, 3..13 taps odd), with or without the workspace stack's over epilogue.
 //
 // Same sums in the same order as k_blur (target = sum_k taps[k] * H(y - c + k), H = sum_k taps[k] * src(x - c + k), every
 // product and every addition rounded on its own, first product instead of 0 + p0); what changes is who computes them:
@@ -249,6 +249,8 @@ int pick(const cvk_blur_params *bp, int cus, hipStream_t s) {
     case 5: return pick_layers<5, W>(bp, cus, s);
     case 7: return pick_layers<7, W>(bp, cus, s);
     case 9: return pick_layers<9, W>(bp, cus, s);
+    case 11: return pick_layers<11, W>(bp, cus, s);
+    case 13: return pick_layers<13, W>(bp, cus, s);
     }
     return (int)hipErrorInvalidValue;
 }
@@ -257,10 +259,10 @@ inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
 }  // namespace
 
-// f16 in and out, 1:1, an odd tap count up to 15, and every pair of columns whole and on a 16-byte boundary in every buffer
+// f16 in and out, 1:1, an odd tap count up to 13, and every pair of columns whole and on a 16-byte boundary in every buffer
 extern "C" int cvk_blur_pair_supported(const cvk_blur_params *bp) {
     if (!(bp->in_half && bp->out_half) || (bp->step != 0 && bp->step != 1)) return 0;
-    if (!(bp->ntaps & 1) || bp->ntaps < 3 || bp->ntaps > 9) return 0;       // beyond 9 taps the doubled ring costs a wave per SIMD
+    if (!(bp->ntaps & 1) || bp->ntaps < 3 || bp->ntaps > 13) return 0;      // (15 taps: 230 VGPRs, no faster than k_blur)
     if (bp->nover < 0 || bp->nover > CVK_BLUR_MAX_OVER) return 0;
     const int c = bp->ntaps / 2, d = c & 1;
     // every pair one aligned 16-byte access, none straddling an edge: even pitches, the rectangle and the window start on

@@ -193,7 +193,7 @@ typedef struct {
 int cvk_blur_supported(int ntaps, int step);
 int cvk_blur(const cvk_blur_params *bp, int cus, void *stream);
 int cvk_blur_takes_pairs(const cvk_blur_params *bp);      /* would cvk_blur launch k_blur_pair for this? */
-/* the same blur with two target columns per lane (blur_pair_ops.hip): f16 in and out, 1:1, 3..9 taps odd, every buffer,
+/* the same blur with two target columns per lane (blur_pair_ops.hip): f16 in and out, 1:1, 3..13 taps odd, every buffer,
  * window and pitch such that a pair of columns is one whole, aligned 16-byte access.  cvk_blur goes there by itself. */
 int cvk_blur_pair_supported(const cvk_blur_params *bp);
 int cvk_blur_pair(const cvk_blur_params *bp, int cus, void *stream);

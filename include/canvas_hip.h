@@ -398,7 +398,7 @@ enum { CVS_FIR_KERNEL_NONE = 0,
        CVS_FIR_KERNEL_TWO_PASS = 7,    /* two k_fir launches through an f32 frame (cached tables) */
        CVS_FIR_KERNEL_PASS = 8,        /* k_fir: one pass of the triangle scaler (both passes: two of these) */
        CVS_FIR_KERNEL_HV = 9,          /* k_fir_hv: per-line tables, horizontal pass first, gather per target line */
-       CVS_FIR_KERNEL_WINDOW_PAIR = 10 };  /* k_blur_pair: the register-window blur with two columns per lane (f16, up to 9 taps) */
+       CVS_FIR_KERNEL_WINDOW_PAIR = 10 };  /* k_blur_pair: the register-window blur with two columns per lane (f16, up to 13 taps) */
 CVS_EXPORT int cvs_fir_last_kernel(void);
 
 /* ------------------------------------------------------------------ (3) fused chain: BASELINE config 2

@@ -1390,12 +1390,12 @@ _PAIR_GEOMETRIES = [
 
 
 @pytest.mark.parametrize("full,scur,pairs", _PAIR_GEOMETRIES)
-@pytest.mark.parametrize("ntaps", [3, 5, 7, 9, 11])
+@pytest.mark.parametrize("ntaps", [3, 5, 7, 9, 13, 15])
 @pytest.mark.parametrize("nover", [0, 1, 3, 4])
 def test_blur_two_columns_per_lane_is_the_one_column_blur(cvs, orc, blur_columns, full, scur, pairs, ntaps, nover):
     """k_blur_pair (two neighbouring columns per lane, buffer loads with range-checked rows, blends on pixel pairs) against
     the oracle and, code for code, against k_blur on the same frames; launches it cannot take (pairs that would straddle
-    an edge, more than 9 taps) must say so and run on k_blur."""
+    an edge, more than 13 taps) must say so and run on k_blur."""
     from tests.util import oracle_blur_over
     from canvas_amd.synth import truncate_to_half
     rng = np.random.default_rng(9300 + ntaps * 10 + nover)
@@ -1409,7 +1409,7 @@ def test_blur_two_columns_per_lane_is_the_one_column_blur(cvs, orc, blur_columns
     got2 = _blur_over(cvs, full, src, taps, overlays)
     # (layers over a blur whose source does not cover the frame go node by node: the blur then writes an f32 frame, on k_blur)
     fused = nover == 0 or scur is None or scur == full
-    assert _blur_kernel_seen(cvs) == ("window-pair" if pairs and ntaps <= 9 and fused else "window")
+    assert _blur_kernel_seen(cvs) == ("window-pair" if pairs and ntaps <= 13 and fused else "window")
     blur_columns(1)
     got1 = _blur_over(cvs, full, src, taps, overlays)
     assert _blur_kernel_seen(cvs) == "window"
