@@ -818,6 +818,12 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
     return 0;
 }
 
+/* cvs_fir_path_override's pins of the register-window kernels' form, as the kernels' flags */
+static int blur_column_pins(void) {
+    const int pin = atomic_load(&g_fir_path);
+    return (pin & CVS_FIR_PATH_ONE_COLUMN ? CVK_BLUR_ONE_COLUMN : 0) | (pin & CVS_FIR_PATH_TWO_COLUMNS ? CVK_BLUR_TWO_COLUMNS : 0);
+}
+
 static bool blur_has_fast_kernel(const float *taps, int ntaps) {
     bool finite = true;
     for (int k = 0; k < ntaps; k++) finite = finite && isfinite(taps[k]);
@@ -845,8 +851,7 @@ static int blur_fused_over_batch(void *tdata, const box2i *tfull, int out_half, 
             if (!(ntaps & 1) || ntaps > 31) return 1;                 /* the batched form exists for the odd lists of blur_kernel.hpp */
             bp.batch = *batch;
         }
-        const int pin = atomic_load(&g_fir_path);
-        bp.flags = (pin & CVS_FIR_PATH_ONE_COLUMN ? CVK_BLUR_ONE_COLUMN : 0) | (pin & CVS_FIR_PATH_TWO_COLUMNS ? CVK_BLUR_TWO_COLUMNS : 0);
+        bp.flags = blur_column_pins();
         int rc = cvk_blur(&bp, cvs_cus(), s);
         if (rc != 0) { cvs_set_error("blur launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
         t_fir_kernel = cvk_blur_takes_pairs(&bp) ? CVS_FIR_KERNEL_WINDOW_PAIR : CVS_FIR_KERNEL_WINDOW;
@@ -1070,10 +1075,11 @@ CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame
             memcpy(bp.taps1, taps, sizeof(float) * (size_t)ntaps);
             memcpy(bp.taps2, f.coeff, sizeof(float) * (size_t)f.width);
             filter_free(&f);
+            bp.flags = blur_column_pins();
             int rc = cvk_blur_halve(&bp, cvs_cus(), s);
             if (rc != 0) { cvs_set_error("blur + halving launch failed: %s", hipGetErrorString((hipError_t)rc)); box2i_set_empty(&target->current_window); return -1; }
             target->current_window = target->full_window;
-            t_fir_kernel = CVS_FIR_KERNEL_HALVE;
+            t_fir_kernel = cvk_blur_halve_takes_pairs(&bp) ? CVS_FIR_KERNEL_HALVE_PAIR : CVS_FIR_KERNEL_HALVE;
             return 0;
         }
         filter_free(&f);
@@ -1174,10 +1180,11 @@ CVS_EXPORT int cvs_blur_lanczos_f16_batch_dev(rgba_frame_f16 *const *targets, co
             bp.ntaps1 = ntaps; bp.ntaps2 = f.width;
             memcpy(bp.taps1, taps, sizeof(float) * (size_t)ntaps);
             memcpy(bp.taps2, f.coeff, sizeof(float) * (size_t)f.width);
+            bp.flags = blur_column_pins();
             int krc = cvk_blur_halve(&bp, cvs_cus(), s);
             if (krc != 0) { cvs_set_error("blur + halving launch failed: %s", hipGetErrorString((hipError_t)krc)); rc = -1; break; }
             for (int i = 0; i < n; i++) targets[done + i]->current_window = targets[done + i]->full_window;
-            t_fir_kernel = CVS_FIR_KERNEL_HALVE;
+            t_fir_kernel = cvk_blur_halve_takes_pairs(&bp) ? CVS_FIR_KERNEL_HALVE_PAIR : CVS_FIR_KERNEL_HALVE;
             done += n;
         }
         filter_free(&f);

@@ -432,9 +432,21 @@ extern "C" int cvk_blur_halve_supported(int ntaps1, int ntaps2) {
     return ntaps2 == 11 && (ntaps1 == 3 || ntaps1 == 5 || ntaps1 == 7 || ntaps1 == 9 || ntaps1 == 11);
 }
 
+// Two source columns per lane, one wave per workgroup (blur_halve_pair_ops.hip) for frames of at least two of its strips
+extern "C" int cvk_blur_halve_takes_pairs(const cvk_blur_halve_params *bp) {
+    if (bp->flags & CVK_BLUR_ONE_COLUMN) return 0;
+    static std::atomic<int> env_cached{ -2 };
+    int env = env_cached.load(std::memory_order_relaxed);
+    if (env == -2) { const char *e = CVS_DIAG_ENV("CVS_BLUR_HALVE_PAIR"); env = e ? atoi(e) : -1; env_cached.store(env, std::memory_order_relaxed); }
+    if (env == 0) return 0;
+    if (!(bp->flags & CVK_BLUR_TWO_COLUMNS) && bp->tx1 - bp->tx0 + 1 < 108) return 0;
+    return cvk_blur_halve_pair_supported(bp);
+}
+
 extern "C" int cvk_blur_halve(const cvk_blur_halve_params *bp, int cus, void *stream) {
     if (bp->tx1 < bp->tx0 || bp->ty1 < bp->ty0) return 0;
     if (!cvk_blur_halve_supported(bp->ntaps1, bp->ntaps2)) return (int)hipErrorInvalidValue;
+    if (cvk_blur_halve_takes_pairs(bp)) return cvk_blur_halve_pair(bp, cus, stream);
     static std::atomic<int> env_cached{ -1 };
     int env_w = env_cached.load(std::memory_order_relaxed);
     if (env_w < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_HALVE_WIDTH"); env_w = e ? atoi(e) : 0; env_cached.store(env_w, std::memory_order_relaxed); }

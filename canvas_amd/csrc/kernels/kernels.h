@@ -208,11 +208,16 @@ typedef struct {
     int sx0, sy0, sx1, sy1;
     int ntaps1, ntaps2;
     int rows_per_wg;           /* 0: let the launcher choose */
-    int pad;
+    int flags;                 /* CVK_BLUR_ONE_COLUMN / CVK_BLUR_TWO_COLUMNS */
     float taps1[16], taps2[16];
     cvk_frame_batch batch;                     /* batch.n frames of this geometry (over[] unused) */
 } cvk_blur_halve_params;
 int cvk_blur_halve_supported(int ntaps1, int ntaps2);
+/* the same sweep with two source columns per lane and one-wave workgroups (blur_halve_pair_ops.hip): f16 in and out, every
+ * pair of source columns one whole, aligned 16-byte access.  cvk_blur_halve goes there by itself (cvk_blur_halve_takes_pairs). */
+int cvk_blur_halve_pair_supported(const cvk_blur_halve_params *bp);
+int cvk_blur_halve_pair(const cvk_blur_halve_params *bp, int cus, void *stream);
+int cvk_blur_halve_takes_pairs(const cvk_blur_halve_params *bp);
 int cvk_blur_halve(const cvk_blur_halve_params *bp, int cus, void *stream);
 
 /* display / export edge: f16 RGBA -> 4 bytes per pixel through a 65536-entry half->u8 table (device pointer,

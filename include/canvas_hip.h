@@ -382,7 +382,7 @@ CVS_EXPORT int cvs_blur_lanczos_f16_batch_dev(rgba_frame_f16 *const *targets, co
  * in turn through this call.  It changes speed only, never pixels; process-wide; 0 restores the automatic choice. */
 enum { CVS_FIR_PATH_AUTO = 0, CVS_FIR_PATH_SWEEP = 1 /* lane per pixel */, CVS_FIR_PATH_TILED = 2, CVS_FIR_PATH_TABLES = 4 /* skip the register-window kernel */,
        CVS_FIR_PATH_LANES = 8 /* lane per channel */, CVS_FIR_PATH_HV = 16 /* per-line gather, horizontal pass first (the automatic first choice) */,
-       CVS_FIR_PATH_ONE_COLUMN = 32 /* the register-window blur with one column per lane, never two */,
+       CVS_FIR_PATH_ONE_COLUMN = 32 /* the register-window kernels (blur, blur + halving) with one column per lane, never two */,
        CVS_FIR_PATH_TWO_COLUMNS = 64 /* ... with two columns per lane wherever that form takes the launch, narrow frames included */ };
 CVS_EXPORT void cvs_fir_path_override(int mode);
 /* Which kernel the calling thread's last FIR launch (scaler, blur, Lanczos resample, blur + resample) went to -- what a
@@ -398,7 +398,8 @@ enum { CVS_FIR_KERNEL_NONE = 0,
        CVS_FIR_KERNEL_TWO_PASS = 7,    /* two k_fir launches through an f32 frame (cached tables) */
        CVS_FIR_KERNEL_PASS = 8,        /* k_fir: one pass of the triangle scaler (both passes: two of these) */
        CVS_FIR_KERNEL_HV = 9,          /* k_fir_hv: per-line tables, horizontal pass first, gather per target line */
-       CVS_FIR_KERNEL_WINDOW_PAIR = 10 };  /* k_blur_pair: the register-window blur with two columns per lane (f16, up to 13 taps) */
+       CVS_FIR_KERNEL_WINDOW_PAIR = 10,    /* k_blur_pair: the register-window blur with two columns per lane (f16, up to 13 taps) */
+       CVS_FIR_KERNEL_HALVE_PAIR = 11 };   /* k_blur_halve_pair: blur + Lanczos halving with two source columns per lane (f16) */
 CVS_EXPORT int cvs_fir_last_kernel(void);
 
 /* ------------------------------------------------------------------ (3) fused chain: BASELINE config 2

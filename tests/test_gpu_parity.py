@@ -843,7 +843,7 @@ def force_fir(request):
 _KERNEL_NAMES = {_lib.FIR_KERNEL_NONE: "none", _lib.FIR_KERNEL_WINDOW: "window", _lib.FIR_KERNEL_HALVE: "halve", _lib.FIR_KERNEL_LANES: "lanes",
                  _lib.FIR_KERNEL_VH: "vh", _lib.FIR_KERNEL_TILED: "tiled", _lib.FIR_KERNEL_STREAM: "stream",
                  _lib.FIR_KERNEL_TWO_PASS: "two-pass", _lib.FIR_KERNEL_PASS: "pass", _lib.FIR_KERNEL_HV: "hv",
-                 _lib.FIR_KERNEL_WINDOW_PAIR: "window-pair"}
+                 _lib.FIR_KERNEL_WINDOW_PAIR: "window-pair", _lib.FIR_KERNEL_HALVE_PAIR: "halve-pair"}
 _FIR_SEEN = {}
 
 
@@ -1055,6 +1055,77 @@ def test_blur_then_halving_in_one_sweep(cvs, orc, ntaps, ssize, scur, tsize):
     got = d_out.download()
     assert same_window(got.current_window, want.current_window)
     assert_same_f16(got.array, want.array, "blur %d taps + halving, %r window %r" % (ntaps, ssize, scur))
+
+
+@pytest.mark.parametrize("ntaps", [3, 5, 7, 9, 11])
+@pytest.mark.parametrize("ssize,scur,tsize,pairs", [
+    ((300, 170), None, (150, 85), True),                      # three strips of 54 target columns, several segments
+    ((300, 170), (8, 6, 279, 150), (150, 85), True),          # source window inside its buffer, on pair boundaries: blurred pixels outside it are skipped taps
+    ((300, 170), (9, 6, 280, 150), (150, 85), False),         # ... starting on an odd column: pairs would straddle its edge
+    ((130, 77), (0, 0, 129, 76), (80, 50), True),             # target larger than half the source: lines whose taps all fall outside
+    ((64, 36), (20, 10, 41, 30), (32, 18), True),             # a window far from the buffer's edges, one partly filled strip
+    ((131, 40), None, (65, 20), False),                       # an odd source width
+])
+def test_blur_then_halving_two_columns_per_lane(cvs, orc, blur_columns, ntaps, ssize, scur, tsize, pairs):
+    """k_blur_halve_pair (one-wave workgroups, two source columns per lane, buffer loads, the second stage's rows in a moving
+    window) against the oracle's two nodes and, code for code, against k_blur_halve; launches it cannot take say so."""
+    rng = np.random.default_rng(ntaps * 1000 + ssize[0] + 7)
+    taps = rng.uniform(0.02, 0.3, ntaps).astype(np.float32)
+    taps = (taps / taps.sum(dtype=np.float32)).astype(np.float32)
+    full = (0, 0, ssize[0] - 1, ssize[1] - 1)
+    layer = HostFrame(full, np.uint16, synth.layer_pixels(ssize[0], ssize[1], 1, 5), scur)
+    want = _oracle_config3(orc, layer, tsize, taps, 0.5, 0.5)
+    d_src = DeviceFrame.from_host(layer)
+    got = {}
+    for columns in (2, 1):
+        d_out = DeviceFrame((0, 0, tsize[0] - 1, tsize[1] - 1), np.uint16)
+        _lib.check(cvs.cvs_memset(d_out.ptr, 0x5A, d_out.nbytes, None))
+        cvs.cvs_clear_last_error()
+        blur_columns(columns)
+        _lib.check(cvs.cvs_blur_lanczos_f16_dev(d_out.ref(), d_src.ref(), f32p(taps), ntaps, C.c_float(0.5), C.c_float(0.5), 3, None))
+        assert _blur_kernel_seen(cvs) == ("halve-pair" if columns == 2 and pairs else "halve")
+        got[columns] = d_out.download()
+        assert same_window(got[columns].current_window, want.current_window)
+    assert_same_f16(got[2].array, want.array, "blur %d taps + halving on two columns per lane, %r window %r" % (ntaps, ssize, scur))
+    assert_same_f16(got[2].array, got[1].array, "two columns per lane against one")
+
+
+def test_blur_then_halving_two_columns_with_special_values(cvs, orc, blur_columns):
+    """Inf, NaN, the largest halfs (sums beyond the half range), denormals and whole black regions through both stages."""
+    w, h = 260, 96
+    full = (0, 0, w - 1, h - 1)
+    px = synth.layer_pixels(w, h, 1, 3)
+    px[:, 40:90] = 0
+    px[5:9, 150:170, :3] = 0x7BFF
+    px[20, 200] = [0x7C00, 0xFC00, 0x7E00, 0x3C00]
+    px[31, 7] = [0x0001, 0x8001, 0x03FF, 0x0001]
+    px[h - 1, w - 1] = [0x7C00, 0x7C00, 0x7C00, 0x7C00]
+    layer = HostFrame(full, np.uint16, px, full)
+    taps = synth.gaussian_taps(9, 1.5)
+    want = _oracle_config3(orc, layer, (w // 2, h // 2), taps, 0.5, 0.5)
+    d_src, d_out = DeviceFrame.from_host(layer), DeviceFrame((0, 0, w // 2 - 1, h // 2 - 1), np.uint16)
+    cvs.cvs_clear_last_error()
+    blur_columns(2)
+    _lib.check(cvs.cvs_blur_lanczos_f16_dev(d_out.ref(), d_src.ref(), f32p(taps), 9, C.c_float(0.5), C.c_float(0.5), 3, None))
+    assert _blur_kernel_seen(cvs) == "halve-pair"
+    assert_same_f16(d_out.download().array, want.array, "special values through blur + halving")
+
+
+def test_blur_lanczos_batch_on_two_columns_per_lane(cvs, orc, blur_columns):
+    """The batched launch (grid.z = frame) of k_blur_halve_pair: five frames, each against the oracle."""
+    w, h, count = 244, 90, 5
+    full = (0, 0, w - 1, h - 1)
+    taps = synth.gaussian_taps(9, 1.5)
+    srcs = [HostFrame(full, np.uint16, synth.layer_pixels(w, h, 1, 20 + i), full) for i in range(count)]
+    d_src = [DeviceFrame.from_host(f) for f in srcs]
+    d_out = [DeviceFrame((0, 0, w // 2 - 1, h // 2 - 1), np.uint16) for _ in range(count)]
+    cvs.cvs_clear_last_error()
+    blur_columns(2)
+    _lib.check(cvs.cvs_blur_lanczos_f16_batch_dev(_frame_table(d_out), _frame_table(d_src), count, f32p(taps), 9, C.c_float(0.5), C.c_float(0.5), 3, None))
+    assert _blur_kernel_seen(cvs) == "halve-pair"
+    for i in range(count):
+        want = _oracle_config3(orc, srcs[i], (w // 2, h // 2), taps, 0.5, 0.5)
+        assert_same_f16(d_out[i].download().array, want.array, "frame %d of the batch" % i)
 
 
 def test_config3_full_size_properties(cvs, orc):
