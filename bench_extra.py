@@ -124,7 +124,7 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
                   "a fused form needs 10 B/px (8 r + 2 w); the 16 independent frames of a pass go to the library four at a time "
                   "(cvs_blur_lanczos_f16_batch_dev: one launch per batch), the batches alternating over two HIP streams", rank,
                   {"fused_lower_bound_bytes_per_px": 10, "frames_per_launch": 4, "streams": 2},
-                  moved_bytes_per_px=10, kernels=["k_blur_halve2<9, 11, 128, f16> (two source rows per barrier, four frames per launch: latency / VALU-issue bound, DESIGN 4.2)"])
+                  moved_bytes_per_px=10, kernels=["k_blur_halve_pair<9, 11 taps, 128 lanes> (two source columns per lane, four frames per launch: vector-issue bound, DESIGN 4.2)"])
     if rec:
         out.append(rec)
     for d in smalls:

@@ -1,5 +1,5 @@
 // blur_halve_pair_ops.hip -- BASELINE config 3 in one sweep (blur_halve_ops.hip: separable blur, then the Lanczos resampler at
-// factor 1/2, nothing in between ever in HBM) with TWO source columns per lane and one wave per workgroup.
+// factor 1/2, nothing in between ever in HBM) with TWO source columns per lane and one or two waves per workgroup.
 //
 // Same four sums in the same order as k_blur_halve (blur x, blur y, resample x, resample y; every product and every addition
 // rounded on its own; blurred pixels outside the SOURCE's window are zero, not the blur formula evaluated there).  What
@@ -55,18 +55,18 @@ __device__ __forceinline__ float4 masked(Px b, uint32_t m) {
 
 // geometry of a strip (compile-time): D moves the strip's first source column one to the left when C1 + C2 is odd, so that
 // source pairs start on even columns; BL lanes own a blurred pair, OUTW lanes a target column
-template <int NT1, int NT2> struct Strip {
-    static constexpr int W = 64, C1 = NT1 / 2, C2 = NT2 / 2, D = (C1 + C2) & 1;
+template <int NT1, int NT2, int W_> struct Strip {
+    static constexpr int W = W_, C1 = NT1 / 2, C2 = NT2 / 2, D = (C1 + C2) & 1;
     static constexpr int BL = ((2 * W - 1 - NT1 - D) >> 1) + 1;         // 2 l + 1 + (NT1 - 1) + D <= 2 W - 1
     static constexpr int OUTW = (2 * BL - NT2) / 2 + 1;                  // 2 tl + NT2 - 1 <= 2 BL - 1
     static constexpr int PITCH = W + 8;
     static_assert(C1 + 1 <= 8 && C2 + 1 <= 8 && OUTW >= 8 && OUTW <= W, "strip layout");
 };
 
-template <int NT1, int NT2>
-__global__ __launch_bounds__(64) void k_blur_halve_pair(cvk_blur_halve_params bp) {
-    typedef Strip<NT1, NT2> G;
-    constexpr int W = G::W, C1 = G::C1, C2 = G::C2, D = G::D, BL = G::BL, OUTW = G::OUTW, PITCH = G::PITCH;
+template <int NT1, int NT2, int WG>
+__global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp) {
+    typedef Strip<NT1, NT2, WG> G;
+    constexpr int W = G::W, C1 = G::C1, C2 = G::C2, D = G::D, OUTW = G::OUTW, PITCH = G::PITCH;
     static_assert(NT1 % 2 == 1 && NT2 % 2 == 1 && NT1 >= 3, "odd tap counts");
     constexpr int U = 2 * NT1;                                 // steps per copy of the loop body: ring slot and step parity are its index
     constexpr int WL = NT2 + 1;                                // rows of the second stage's window
@@ -103,9 +103,11 @@ __global__ __launch_bounds__(64) void k_blur_halve_pair(cvk_blur_halve_params bp
     const char *swin0 = reinterpret_cast<const char *>(src_data) + (ptrdiff_t)(bp.sx0 - bp.source.fx0) * 8;
     const ptrdiff_t trect0 = (ptrdiff_t)(bp.tx0 - bp.target.fx0) * 8;
     // is this lane's blurred pixel inside the blurred frame's window (= the source's)?  column part, as all-ones / all-zeros
+    // (lanes past the last blurred pair hold anything: their slots of row B feed only lanes without a target column)
     const int bcol = bo + 2 * lane;
-    const uint32_t cm0 = (lane < BL && bcol >= bp.sx0 && bcol <= bp.sx1) ? 0xFFFFFFFFu : 0u;
-    const uint32_t cm1 = (lane < BL && bcol + 1 >= bp.sx0 && bcol + 1 <= bp.sx1) ? 0xFFFFFFFFu : 0u;
+    const uint32_t cm0 = (bcol >= bp.sx0 && bcol <= bp.sx1) ? 0xFFFFFFFFu : 0u;
+    const uint32_t cm1 = (bcol + 1 >= bp.sx0 && bcol + 1 <= bp.sx1) ? 0xFFFFFFFFu : 0u;
+    const bool cols_inside = bo >= bp.sx0 && bo + 2 * W - 1 <= bp.sx1;     // uniform: no column of the strip needs the mask
 
     if (lane < PITCH - W) {
 #pragma unroll
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(64) void k_blur_halve_pair(cvk_blur_halve_params bp
     for (int b = 0; b < 2; b++)
 #pragma unroll
         for (int ph = 0; ph < 2; ph++) rowB[b][ph][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
 
     Px ring1[NT1][2];
     Px win2[WL];
@@ -135,6 +138,7 @@ __global__ __launch_bounds__(64) void k_blur_halve_pair(cvk_blur_halve_params bp
     rowS[0][1][lane] = widen_px(cur.z, cur.w);
     cur = fetch_row(ys0 + 1, steps > 1);
     u32x4 nxt = fetch_row(ys0 + 2, steps > 2);
+    __syncthreads();
 
     // step i: source row ys0 + i is filtered; blurred row rb = i - (NT1 - 1) leaves the first ring (rb >= 0) and is handed over
     // through LDS; in step i + 1 it enters the second stage as rb2 = (i + 1) - NT1; an EVEN rb2 >= NT2 - 1 completes target row
@@ -172,7 +176,11 @@ __global__ __launch_bounds__(64) void k_blur_halve_pair(cvk_blur_halve_params bp
                         const f32x2 p = win2[1 + k].rg * w2[k], q = win2[1 + k].ba * w2[k];
                         if (k == 0) { org = p; oba = q; } else { org = org + p; oba = oba + q; }
                     }
-                    const u32x2 codes = { cvs::f2h_rz2(org.x, org.y), cvs::f2h_rz2(oba.x, oba.y) };
+                    // truncation to half: |x| >= 65536 must become an infinity, which only waves that hold such a value pay for
+                    float big;
+                    asm("v_max3_f32 %0, |%1|, |%2|, |%3|\n\tv_max_f32 %0, %0, |%4|" : "=&v"(big) : "v"(org.x), "v"(org.y), "v"(oba.x), "v"(oba.y));
+                    if (cvs::wave_any(!(big < 65536.0f))) { cvs::rare_path(); org = cvs::saturate_to_inf2(org); oba = cvs::saturate_to_inf2(oba); }
+                    const u32x2 codes = { cvs::pkrtz(org.x, org.y), cvs::pkrtz(oba.x, oba.y) };
                     __builtin_amdgcn_raw_buffer_store_b64(codes, row_rsrc(dst_data, (size_t)((ptrdiff_t)(t - bp.target.fy0) * (ptrdiff_t)trow + trect0), t <= tb ? trect : 0u), (int)toff, 0, 0);
                 }
                 // the window moves down by two rows
@@ -211,8 +219,13 @@ __global__ __launch_bounds__(64) void k_blur_halve_pair(cvk_blur_halve_params bp
                     }
                     const int by = ys0 + i - C1;               // the blurred row just completed
                     const bool row_in = by >= bp.sy0 && by <= bp.sy1;       // uniform
-                    rowB[par][0][lane] = masked(b0, row_in ? cm0 : 0u);
-                    rowB[par][1][lane] = masked(b1, row_in ? cm1 : 0u);
+                    if (cols_inside && row_in) {
+                        rowB[par][0][lane] = make_float4(b0.rg.x, b0.rg.y, b0.ba.x, b0.ba.y);
+                        rowB[par][1][lane] = make_float4(b1.rg.x, b1.rg.y, b1.ba.x, b1.ba.y);
+                    } else {
+                        rowB[par][0][lane] = masked(b0, row_in ? cm0 : 0u);
+                        rowB[par][1][lane] = masked(b1, row_in ? cm1 : 0u);
+                    }
                 }
             }
             cur = nxt;
@@ -231,15 +244,15 @@ int resident_per_cu(K kernel, int block) {
     return n;
 }
 
-template <int NT1, int NT2>
+template <int NT1, int NT2, int WG>
 int launch(cvk_blur_halve_params bp, int cus, hipStream_t s) {
-    constexpr int OUTW = Strip<NT1, NT2>::OUTW;
+    constexpr int OUTW = Strip<NT1, NT2, WG>::OUTW;
     const int cols = bp.tx1 - bp.tx0 + 1, rows = bp.ty1 - bp.ty0 + 1;
     const int strips = (cols + OUTW - 1) / OUTW;
     static std::atomic<int> cached{ 0 };            // (several threads may launch at once: pull-queue workers)
     int mine = cached.load(std::memory_order_relaxed);
     if (!mine) {
-        mine = resident_per_cu(k_blur_halve_pair<NT1, NT2>, 64);
+        mine = resident_per_cu(k_blur_halve_pair<NT1, NT2, WG>, WG);
         const char *e = CVS_DIAG_ENV("CVS_BLUR_HALVE_PAIR_WGS");     // diagnostic build: workgroups per CU the segments are sized for
         if (e && atoi(e) > 0) mine = atoi(e);
         cached.store(mine, std::memory_order_relaxed);
@@ -255,7 +268,7 @@ int launch(cvk_blur_halve_params bp, int cus, hipStream_t s) {
         bp.rows_per_wg = r;
     }
     dim3 grid((unsigned)strips, (unsigned)((rows + bp.rows_per_wg - 1) / bp.rows_per_wg), (unsigned)nframes);
-    hipLaunchKernelGGL((k_blur_halve_pair<NT1, NT2>), grid, dim3(64), 0, s, bp);
+    hipLaunchKernelGGL((k_blur_halve_pair<NT1, NT2, WG>), grid, dim3(WG), 0, s, bp);
     return (int)hipGetLastError();
 }
 
@@ -286,12 +299,28 @@ extern "C" int cvk_blur_halve_pair(const cvk_blur_halve_params *bp, int cus, voi
     if (bp->tx1 < bp->tx0 || bp->ty1 < bp->ty0) return 0;
     if (!cvk_blur_halve_pair_supported(bp)) return (int)hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
+    // 128 lanes (two waves, one barrier per row, 236 of 256 source columns useful instead of 108 of 128) from two such strips
+    // on: 3 % faster at 4K (0.0465 -> 0.0451 ms per frame); narrower targets keep the one-wave workgroups
+    static std::atomic<int> env_cached{ -1 };
+    int env_w = env_cached.load(std::memory_order_relaxed);
+    if (env_w < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_HALVE_PAIR_WIDTH"); env_w = e ? atoi(e) : 0; env_cached.store(env_w, std::memory_order_relaxed); }
+    const int cols = bp->tx1 - bp->tx0 + 1;
+    const bool wide = env_w == 128 || (env_w != 64 && cols >= 2 * Strip<9, 11, 128>::OUTW);
+    if (wide) {
+        switch (bp->ntaps1) {
+        case 3:  return launch<3, 11, 128>(*bp, cus, s);
+        case 5:  return launch<5, 11, 128>(*bp, cus, s);
+        case 7:  return launch<7, 11, 128>(*bp, cus, s);
+        case 9:  return launch<9, 11, 128>(*bp, cus, s);
+        case 11: return launch<11, 11, 128>(*bp, cus, s);
+        }
+    }
     switch (bp->ntaps1) {
-    case 3:  return launch<3, 11>(*bp, cus, s);
-    case 5:  return launch<5, 11>(*bp, cus, s);
-    case 7:  return launch<7, 11>(*bp, cus, s);
-    case 9:  return launch<9, 11>(*bp, cus, s);
-    case 11: return launch<11, 11>(*bp, cus, s);
+    case 3:  return launch<3, 11, 64>(*bp, cus, s);
+    case 5:  return launch<5, 11, 64>(*bp, cus, s);
+    case 7:  return launch<7, 11, 64>(*bp, cus, s);
+    case 9:  return launch<9, 11, 64>(*bp, cus, s);
+    case 11: return launch<11, 11, 64>(*bp, cus, s);
     }
     return (int)hipErrorInvalidValue;
 }

@@ -1065,6 +1065,8 @@ def test_blur_then_halving_in_one_sweep(cvs, orc, ntaps, ssize, scur, tsize):
     ((130, 77), (0, 0, 129, 76), (80, 50), True),             # target larger than half the source: lines whose taps all fall outside
     ((64, 36), (20, 10, 41, 30), (32, 18), True),             # a window far from the buffer's edges, one partly filled strip
     ((131, 40), None, (65, 20), False),                       # an odd source width
+    ((560, 64), None, (280, 32), True),                       # wide enough for the two-wave workgroups (strips of 118 target columns)
+    ((560, 64), (12, 4, 541, 59), (280, 32), True),           # ... with the source's window inside its buffer
 ])
 def test_blur_then_halving_two_columns_per_lane(cvs, orc, blur_columns, ntaps, ssize, scur, tsize, pairs):
     """k_blur_halve_pair (one-wave workgroups, two source columns per lane, buffer loads, the second stage's rows in a moving

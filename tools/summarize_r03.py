@@ -131,7 +131,7 @@ PX4K, PX1080, PX8K = 3840 * 2160, 1920 * 1080, 7680 * 4320
 # (the extras run config 3's sweep and config 5's blur + over four frames per launch: their FETCH / WRITE figures are per
 # launch of four, their durations come from one-stream traces -- c3_trace: four frames per launch; c5_trace: one)
 KERNELS = [
-    ("k_blur_halve2<", 8, 4, 4 * (PX4K * 8 + PX1080 * 8), "config 3: four 4K f16 frames in, four 1080p f16 frames out per launch (a lane stores one channel pair: 4 B)"),
+    ("k_blur_halve_pair<", 16, 8, 4 * (PX4K * 8 + PX1080 * 8), "config 3: four 4K f16 frames in, four 1080p f16 frames out per launch (16-byte loads, a lane stores one pixel: 8 B)"),
     ("k_color_flat", 16, 16, PX4K * 16, "config 5, launch 1: colour filter 8 r + 8 w per px (pixel pairs: 16 B per lane)"),
     ("k_blur_pair<9, 64, 3>", 16, 16, PX4K * 40, "config 5, launch 2: blur + 3 overlays + store = 8 r + 24 r + 8 w per px (two columns per lane: 16 B accesses)"),
     ("k_fir_vh<", 8, 16, PX1080 * 8 + PX4K * 8, "scaler 1080p -> 4K f16"),
