@@ -21,32 +21,11 @@
 // cvk_blur_halve_pair_supported says so.
 #include <cstdlib>
 #include <atomic>
-#include <type_traits>
-#include <utility>
-#include "kernels.h"
-#include "chain_math.hpp"
+#include "pair_common.hpp"
 
 namespace {
 
-using cvs::f32x2;
-using cvs::u32x4;
-using cvs::u32x2;
-
-struct Px { f32x2 rg, ba; };
-
-template <class F, int... Js>
-__device__ __forceinline__ void each_slot(F &f, std::integer_sequence<int, Js...>) {
-    (void)(f(std::integral_constant<int, Js>{}) && ...);
-}
-
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ rsrc_t row_rsrc(const void *base, size_t row_offset, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(base)) + row_offset, 0, (int)bytes, 0x00020000);
-}
-
-__device__ __forceinline__ float4 widen_px(uint32_t lo, uint32_t hi) {
-    return make_float4(cvs::h2f(lo & 0xFFFFu), cvs::h2f(lo >> 16), cvs::h2f(hi & 0xFFFFu), cvs::h2f(hi >> 16));
-}
+using namespace pairsweep;
 
 __device__ __forceinline__ float4 masked(Px b, uint32_t m) {
     return make_float4(__uint_as_float(__float_as_uint(b.rg.x) & m), __uint_as_float(__float_as_uint(b.rg.y) & m),
@@ -130,7 +109,7 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
 
     auto fetch_row = [&](int ys, bool wanted) -> u32x4 {
         const bool live = wanted && ys >= bp.sy0 && ys <= bp.sy1;           // uniform: a dead row is a descriptor without records
-        return __builtin_amdgcn_raw_buffer_load_b128(row_rsrc(swin0, (size_t)((ptrdiff_t)(ys - bp.source.fy0) * (ptrdiff_t)srow), live ? swin : 0u), (int)soff, 0, 0);
+        return load_pair(row_rsrc(swin0, (size_t)((ptrdiff_t)(ys - bp.source.fy0) * (ptrdiff_t)srow), live ? swin : 0u), soff);
     };
     // row i goes to LDS during step i - 1; the rows in flight are those of steps i + 1 .. i + 3
     u32x4 cur = fetch_row(ys0, true);
@@ -237,13 +216,6 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
     }
 }
 
-template <class K>
-int resident_per_cu(K kernel, int block) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, 0) != hipSuccess || n < 1) n = 1;
-    return n;
-}
-
 template <int NT1, int NT2, int WG>
 int launch(cvk_blur_halve_params bp, int cus, hipStream_t s) {
     constexpr int OUTW = Strip<NT1, NT2, WG>::OUTW;
@@ -271,8 +243,6 @@ int launch(cvk_blur_halve_params bp, int cus, hipStream_t s) {
     hipLaunchKernelGGL((k_blur_halve_pair<NT1, NT2, WG>), grid, dim3(WG), 0, s, bp);
     return (int)hipGetLastError();
 }
-
-inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
 }  // namespace
 

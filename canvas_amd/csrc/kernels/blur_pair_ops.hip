@@ -19,36 +19,11 @@
 // Measured where DESIGN.md section 4.2 says; cvk_blur (blur_ops.hip) sends a launch here when cvk_blur_pair_supported says so.
 #include <cstdlib>
 #include <atomic>
-#include <type_traits>
-#include <utility>
-#include "kernels.h"
-#include "chain_math.hpp"
+#include "pair_common.hpp"
 
 namespace {
 
-using cvs::f32x2;
-using cvs::u32x4;
-
-struct Px { f32x2 rg, ba; };
-
-template <class F, int... Js>
-__device__ __forceinline__ void each_slot(F &f, std::integer_sequence<int, Js...>) {
-    (void)(f(std::integral_constant<int, Js>{}) && ...);
-}
-
-// one row of a buffer as a raw buffer resource (stride 0: offsets are bytes, range-checked against `bytes`); everything here
-// is wave-uniform (kernel arguments and block indices)
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ rsrc_t row_rsrc(const void *base, size_t row_offset, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(base)) + row_offset, 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ u32x4 load_pair(rsrc_t r, uint32_t voff) {
-    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0);
-}
-
-__device__ __forceinline__ float4 widen_px(uint32_t lo, uint32_t hi) {
-    return make_float4(cvs::h2f(lo & 0xFFFFu), cvs::h2f(lo >> 16), cvs::h2f(hi & 0xFFFFu), cvs::h2f(hi >> 16));
-}
+using namespace pairsweep;
 
 // NOV: the number of upper layers, exact (0: no epilogue) -- a kernel per count, so that no step carries loads, registers
 // or branches for layers that are not there
@@ -196,13 +171,6 @@ __global__ __launch_bounds__(W) void k_blur_pair(cvk_blur_params bp) {
     }
 }
 
-template <class K>
-int resident_per_cu(K kernel, int block) {
-    int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, block, 0) != hipSuccess || n < 1) n = 1;
-    return n;
-}
-
 template <int NT, int W, int NOV>
 int launch(cvk_blur_params bp, int cus, hipStream_t s) {
     constexpr int C = NT / 2, D = C & 1, OUTW = 2 * W - 2 * C - 2 * D;
@@ -254,8 +222,6 @@ int pick(const cvk_blur_params *bp, int cus, hipStream_t s) {
     }
     return (int)hipErrorInvalidValue;
 }
-
-inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15u) == 0; }
 
 }  // namespace
 
