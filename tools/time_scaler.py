@@ -14,7 +14,7 @@ from canvas_amd import _lib, synth                      # noqa: E402
 from canvas_amd.abi import v2f                          # noqa: E402
 from canvas_amd.device import DeviceFrame               # noqa: E402
 
-NAMES = ["none", "window", "halve", "lanes", "vh", "tiled", "stream", "two-pass", "pass", "hv"]
+NAMES = ["none", "window", "halve", "lanes", "vh", "tiled", "stream", "two-pass", "pass", "hv", "window-pair", "halve-pair"]
 
 
 def main():
