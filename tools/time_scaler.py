@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--only", default="")
     args = ap.parse_args()
+    if os.environ.get("CANVAS_LIB"):                      # A/B runs: another build of the library (never set by the package)
+        _lib.LIB_PATH = os.environ["CANVAS_LIB"]
     lib = _lib.load()
     assert lib.cvs_init(0) == 0
     lib.init_half()
