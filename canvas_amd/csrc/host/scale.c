@@ -902,6 +902,27 @@ static int lanczos_fused(void *tdata, const box2i *tfull, int out_half, const vo
         bool usable = f.coeff && cvk_blur_supported(f.width, 2) && f.center == f.width / 2 &&
                       tfull->min.x > -(1 << 22) && tfull->max.x < (1 << 22) && tfull->min.y > -(1 << 22) && tfull->max.y < (1 << 22);
         for (int k = 0; usable && k < f.width; k++) usable = isfinite(f.coeff[k]);
+        if (usable && in_half && out_half && f.width <= 16) {
+            /* f16 frames: config 3's two-column sweep behind the identity blur (one tap of weight 1: x * 1.0f is x) */
+            cvk_blur_halve_params hp;
+            memset(&hp, 0, sizeof hp);
+            hp.target = cvs_view(tdata, tfull);
+            hp.source = cvs_view((void *)sdata, sfull);
+            hp.in_half = 1; hp.out_half = 1;
+            hp.tx0 = tfull->min.x; hp.ty0 = tfull->min.y; hp.tx1 = tfull->max.x; hp.ty1 = tfull->max.y;
+            hp.sx0 = sw->min.x; hp.sy0 = sw->min.y; hp.sx1 = sw->max.x; hp.sy1 = sw->max.y;
+            hp.ntaps1 = 1; hp.ntaps2 = f.width;
+            hp.taps1[0] = 1.0f;
+            memcpy(hp.taps2, f.coeff, sizeof(float) * (size_t)f.width);
+            hp.flags = blur_column_pins();
+            if (cvk_blur_halve_takes_pairs(&hp)) {
+                filter_free(&f);
+                int rc = cvk_blur_halve_pair(&hp, cvs_cus(), s);
+                if (rc != 0) { cvs_set_error("resample launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
+                t_fir_kernel = CVS_FIR_KERNEL_HALVE_PAIR;
+                return 0;
+            }
+        }
         if (usable) {
             cvk_blur_params bp;
             memset(&bp, 0, sizeof bp);

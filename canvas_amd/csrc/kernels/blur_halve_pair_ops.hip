@@ -17,7 +17,7 @@
 //     row B -> a WINDOW of NT2 + 1 rows in registers that moves down by two every second step (the step parity, i.e. whether
 //     the row completes a target row, is a compile-time fact of the unrolled body; a ring with compile-time slots for both
 //     stages would need lcm(NT1, NT2 + 1) copies of the body), V2 -> one f16 pixel, an 8-byte buffer store.
-// f16 in, f16 out, NT2 = 11 (Lanczos3 at 1/2), NT1 = 3..11 odd; cvk_blur_halve sends a launch here when
+// f16 in, f16 out, NT2 = 11 (Lanczos3 at 1/2), NT1 = 3..11 odd -- or 1, the identity: the resampler alone; cvk_blur_halve sends a launch here when
 // cvk_blur_halve_pair_supported says so.
 #include <cstdlib>
 #include <atomic>
@@ -46,7 +46,7 @@ template <int NT1, int NT2, int WG>
 __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp) {
     typedef Strip<NT1, NT2, WG> G;
     constexpr int W = G::W, C1 = G::C1, C2 = G::C2, D = G::D, OUTW = G::OUTW, PITCH = G::PITCH;
-    static_assert(NT1 % 2 == 1 && NT2 % 2 == 1 && NT1 >= 3, "odd tap counts");
+    static_assert(NT1 % 2 == 1 && NT2 % 2 == 1 && NT1 >= 1, "odd tap counts");
     constexpr int U = 2 * NT1;                                 // steps per copy of the loop body: ring slot and step parity are its index
     constexpr int WL = NT2 + 1;                                // rows of the second stage's window
     __shared__ float4 rowS[2][2][PITCH];                       // source row, widened: [step parity][column parity][column / 2]
@@ -178,8 +178,10 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
                 nb[0][lane] = widen_px(cur.x, cur.y);
                 nb[1][lane] = widen_px(cur.z, cur.w);
                 f32x2 rg0, ba0, rg1, ba1;
+                // (NT1 == 1: the host sends only the identity, one tap of weight 1.0f -- x * 1.0f is x, twice: the resampler alone)
+                if constexpr (NT1 == 1) { rg0 = f32x2{ v[0].x, v[0].y }; ba0 = f32x2{ v[0].z, v[0].w }; rg1 = f32x2{ v[1].x, v[1].y }; ba1 = f32x2{ v[1].z, v[1].w }; }
 #pragma unroll
-                for (int k = 0; k < NT1; k++) {
+                for (int k = 0; k < (NT1 == 1 ? 0 : NT1); k++) {
                     const f32x2 p0 = f32x2{ v[k].x, v[k].y } * w1[k], q0 = f32x2{ v[k].z, v[k].w } * w1[k];
                     const f32x2 p1 = f32x2{ v[k + 1].x, v[k + 1].y } * w1[k], q1 = f32x2{ v[k + 1].z, v[k + 1].w } * w1[k];
                     if (k == 0) { rg0 = p0; ba0 = q0; rg1 = p1; ba1 = q1; }
@@ -189,8 +191,9 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
                 ring1[j1][1].rg = rg1; ring1[j1][1].ba = ba1;
                 if (i >= NT1 - 1) {
                     Px b0, b1;
+                    if constexpr (NT1 == 1) { b0 = ring1[0][0]; b1 = ring1[0][1]; }
 #pragma unroll
-                    for (int k = 0; k < NT1; k++) {
+                    for (int k = 0; k < (NT1 == 1 ? 0 : NT1); k++) {
                         const Px &a = ring1[(j1 + 1 + k) % NT1][0], &b = ring1[(j1 + 1 + k) % NT1][1];
                         const f32x2 p0 = a.rg * w1[k], q0 = a.ba * w1[k], p1 = b.rg * w1[k], q1 = b.ba * w1[k];
                         if (k == 0) { b0.rg = p0; b0.ba = q0; b1.rg = p1; b1.ba = q1; }
@@ -249,7 +252,8 @@ int launch(cvk_blur_halve_params bp, int cus, hipStream_t s) {
 // f16 in and out, Lanczos3 halving behind a blur of 3..11 taps, and every pair of source columns whole and on a 16-byte boundary
 extern "C" int cvk_blur_halve_pair_supported(const cvk_blur_halve_params *bp) {
     if (!(bp->in_half && bp->out_half) || bp->ntaps2 != 11) return 0;
-    if (!(bp->ntaps1 & 1) || bp->ntaps1 < 3 || bp->ntaps1 > 11) return 0;
+    if (!(bp->ntaps1 & 1) || bp->ntaps1 < 1 || bp->ntaps1 > 11) return 0;
+    if (bp->ntaps1 == 1 && bp->taps1[0] != 1.0f) return 0;               /* one tap: the identity only (the resampler alone) */
     if (bp->sx1 < bp->sx0 || bp->sy1 < bp->sy0) return 0;
     const int c1 = bp->ntaps1 / 2, c2 = bp->ntaps2 / 2, d = (c1 + c2) & 1;
     // even pitch, the window on a pair boundary of its buffer and of the strips' pair grid, an even width
@@ -275,9 +279,10 @@ extern "C" int cvk_blur_halve_pair(const cvk_blur_halve_params *bp, int cus, voi
     int env_w = env_cached.load(std::memory_order_relaxed);
     if (env_w < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_HALVE_PAIR_WIDTH"); env_w = e ? atoi(e) : 0; env_cached.store(env_w, std::memory_order_relaxed); }
     const int cols = bp->tx1 - bp->tx0 + 1;
-    const bool wide = env_w == 128 || (env_w != 64 && cols >= 2 * Strip<9, 11, 128>::OUTW);
+    const bool wide = env_w == 128 || (env_w != 64 && cols >= 2 * Strip<9, 11, 128>::OUTW);       // (118 columns at 9 taps)
     if (wide) {
         switch (bp->ntaps1) {
+        case 1:  return launch<1, 11, 128>(*bp, cus, s);
         case 3:  return launch<3, 11, 128>(*bp, cus, s);
         case 5:  return launch<5, 11, 128>(*bp, cus, s);
         case 7:  return launch<7, 11, 128>(*bp, cus, s);
@@ -286,6 +291,7 @@ extern "C" int cvk_blur_halve_pair(const cvk_blur_halve_params *bp, int cus, voi
         }
     }
     switch (bp->ntaps1) {
+    case 1:  return launch<1, 11, 64>(*bp, cus, s);
     case 3:  return launch<3, 11, 64>(*bp, cus, s);
     case 5:  return launch<5, 11, 64>(*bp, cus, s);
     case 7:  return launch<7, 11, 64>(*bp, cus, s);

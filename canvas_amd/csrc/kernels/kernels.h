@@ -214,7 +214,7 @@ typedef struct {
 } cvk_blur_halve_params;
 int cvk_blur_halve_supported(int ntaps1, int ntaps2);
 /* the same sweep with two source columns per lane and one-wave workgroups (blur_halve_pair_ops.hip): f16 in and out, every
- * pair of source columns one whole, aligned 16-byte access.  cvk_blur_halve goes there by itself (cvk_blur_halve_takes_pairs). */
+ * pair of source columns one whole, aligned 16-byte access; also ntaps1 == 1 with taps1[0] == 1.0f, the resampler alone.  cvk_blur_halve goes there by itself (cvk_blur_halve_takes_pairs). */
 int cvk_blur_halve_pair_supported(const cvk_blur_halve_params *bp);
 int cvk_blur_halve_pair(const cvk_blur_halve_params *bp, int cus, void *stream);
 int cvk_blur_halve_takes_pairs(const cvk_blur_halve_params *bp);

@@ -1092,6 +1092,36 @@ def test_blur_then_halving_two_columns_per_lane(cvs, orc, blur_columns, ntaps, s
     assert_same_f16(got[2].array, got[1].array, "two columns per lane against one")
 
 
+@pytest.mark.parametrize("ssize,scur,tsize,pairs", [
+    ((300, 170), None, (150, 85), True),
+    ((300, 170), (8, 6, 279, 150), (150, 85), True),          # source window inside its buffer: taps outside it are skipped
+    ((300, 170), (9, 6, 280, 150), (150, 85), False),         # ... off the pair grid: the one-column kernel
+    ((560, 64), None, (280, 32), True),                       # the two-wave workgroups
+    ((130, 77), (0, 0, 129, 76), (80, 50), True),             # target larger than half the source
+])
+def test_lanczos_halving_alone_on_two_columns_per_lane(cvs, orc, blur_columns, ssize, scur, tsize, pairs):
+    """cvs_resample_lanczos_f16_dev at 1/2 on f16 frames: config 3's two-column sweep behind an identity blur (one tap of
+    weight 1), against the oracle's resampler and against the decimating register-window kernel it replaces."""
+    full = (0, 0, ssize[0] - 1, ssize[1] - 1)
+    px = synth.layer_pixels(ssize[0], ssize[1], 1, 9)
+    px[11, 40] = [0x7C00, 0xFC00, 0x7E00, 0x3C00]
+    layer = HostFrame(full, np.uint16, px, scur)
+    want = _oracle_config3(orc, layer, tsize, np.array([1.0], np.float32), 0.5, 0.5)
+    d_src = DeviceFrame.from_host(layer)
+    got = {}
+    for columns in (2, 1):
+        d_out = DeviceFrame((0, 0, tsize[0] - 1, tsize[1] - 1), np.uint16)
+        _lib.check(cvs.cvs_memset(d_out.ptr, 0x5A, d_out.nbytes, None))
+        cvs.cvs_clear_last_error()
+        blur_columns(columns)
+        _lib.check(cvs.cvs_resample_lanczos_f16_dev(d_out.ref(), d_src.ref(), C.c_float(0.5), C.c_float(0.5), 3, None))
+        assert _blur_kernel_seen(cvs) == ("halve-pair" if columns == 2 and pairs else "window")
+        got[columns] = d_out.download()
+        assert same_window(got[columns].current_window, want.current_window)
+    assert_same_f16(got[2].array, want.array, "Lanczos3 halving alone on two columns per lane, %r window %r" % (ssize, scur))
+    assert_same_f16(got[2].array, got[1].array, "two columns per lane against one")
+
+
 def test_blur_then_halving_two_columns_with_special_values(cvs, orc, blur_columns):
     """Inf, NaN, the largest halfs (sums beyond the half range), denormals and whole black regions through both stages."""
     w, h = 260, 96
