@@ -10,9 +10,14 @@ with copies of config 2's ring (same value distribution, opaque bottom layer), w
   config 4   7680x4320 3-layer alpha-over stack                                             cvs_chain_color_over_f16_dev (m = NULL)
   config 5   3840x2160 10-node graph (4 sources, colour -> blur -> 4-step composite)        canvas_amd.stream.GraphStream
   lanczos3_x0.40 / x0.75 / x1.50   3840x2160 Lanczos3 at factors other than 1/2: the GENERAL FIR path (per-line tap
-             tables, sweep_ops.hip / sweep_hv_ops.hip), not a BASELINE config               cvs_resample_lanczos_f16_dev
+             tables, sweep_hv_ops.hip), not a BASELINE config               cvs_resample_lanczos_f16_dev
   scaler_x2.00   1920x1080 -> 3840x2160 through the reference's own scaler        cvs_scale_bilinear_f16_dev
+  config3_contracted, config5_contracted   the same two workloads in the library's OTHER arithmetic flavour
+             (cvs_set_arithmetic(CVS_ARITH_CONTRACTED): a * b + c inside an expression fused, as the reference's preferred clang
+             build computes it), each proven against the fixture made by the checker's build of that flavour; the headline and every
+             other record run in the default flavour (the reference's gcc build)
 """
+import contextlib
 import ctypes as C
 import time
 
@@ -71,6 +76,16 @@ def _record(dist, gather_stats, checksum52, name, workload, frames, px_per_frame
     return rec
 
 
+@contextlib.contextmanager
+def arithmetic(lib, _lib, flavour):
+    """The library in the named arithmetic flavour for the duration of the block (process-wide: nothing else may be in flight)."""
+    before = lib.cvs_set_arithmetic(_lib.ARITH_CONTRACTED if flavour == "contracted" else _lib.ARITH_SEPARATE)
+    try:
+        yield
+    finally:
+        lib.cvs_set_arithmetic(before if before >= 0 else _lib.ARITH_SEPARATE)
+
+
 class GraphStreamView:
     """A fixed group of a GraphStream's slots rendered with one batch call (its pointer tables are built once)."""
 
@@ -115,18 +130,21 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
         for k, (dst, src) in enumerate(b3):
             _lib.check(lib.cvs_blur_lanczos_f16_batch_dev(dst, src, per, f32p(taps), 9, C.c_float(0.5), C.c_float(0.5), 3, streams3[k % 2]), "config 3")
 
-    n, dt = _timed_passes(lib, _lib, streams3, pass3, seconds)
-    digest = verify.canon_sha256(smalls[0].download(stream).array)
+    for flavour, sfx in (("separate", ""), ("contracted", "_contracted")):
+        with arithmetic(lib, _lib, flavour):
+            n, dt = _timed_passes(lib, _lib, streams3, pass3, seconds)
+        digest = verify.canon_sha256(smalls[0].download(stream).array)
+        rec = _record(dist, gather_stats, checksum52, "config3" + sfx, "3840x2160 f16 -> 9-tap Gaussian -> Lanczos3 -> 1920x1080 f16",
+                      n * len(sources), w * h, dt, digest, verify.stream_fixture("config3_3840x2160_to_1920x1080" + ("@contracted" if sfx else ""), g0), 26,
+                      "Mpixels/s and bytes are per INPUT pixel; 26 B/px is BASELINE's per-node denominator (blur 8 r + 8 w, scale 8 r + 2 w); "
+                      "a fused form needs 10 B/px (8 r + 2 w); the 16 independent frames of a pass go to the library four at a time "
+                      "(cvs_blur_lanczos_f16_batch_dev: one launch per batch), the batches alternating over two HIP streams", rank,
+                      {"fused_lower_bound_bytes_per_px": 10, "frames_per_launch": 4, "streams": 2, "arithmetic": flavour},
+                      moved_bytes_per_px=10, kernels=["k_blur_halve_pair<9, 11 taps, 128 lanes> (two source columns per lane, four frames per launch)"
+                                                      + (", contracted build: one v_pk_fma_f32 per tap and channel pair where the default flavour issues a multiply and an add" if sfx else "")])
+        if rec:
+            out.append(rec)
     lib.cvs_stream_destroy(streams3[1])
-    rec = _record(dist, gather_stats, checksum52, "config3", "3840x2160 f16 -> 9-tap Gaussian -> Lanczos3 -> 1920x1080 f16",
-                  n * len(sources), w * h, dt, digest, verify.stream_fixture("config3_3840x2160_to_1920x1080", g0), 26,
-                  "Mpixels/s and bytes are per INPUT pixel; 26 B/px is BASELINE's per-node denominator (blur 8 r + 8 w, scale 8 r + 2 w); "
-                  "a fused form needs 10 B/px (8 r + 2 w); the 16 independent frames of a pass go to the library four at a time "
-                  "(cvs_blur_lanczos_f16_batch_dev: one launch per batch), the batches alternating over two HIP streams", rank,
-                  {"fused_lower_bound_bytes_per_px": 10, "frames_per_launch": 4, "streams": 2},
-                  moved_bytes_per_px=10, kernels=["k_blur_halve_pair<9, 11 taps, 128 lanes> (two source columns per lane, four frames per launch: vector-issue bound, DESIGN 4.2)"])
-    if rec:
-        out.append(rec)
     for d in smalls:
         d.free()
 
@@ -147,7 +165,7 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
         in_bytes, out_bytes = 8, 8 * (tw * th) / (w * h)
         rec = _record(dist, gather_stats, checksum52, "lanczos3_x" + tag, "3840x2160 f16 -> Lanczos3 -> %dx%d f16 (per-line tap tables)" % (tw, th),
                       n * len(sources), w * h, dt, digest, verify.stream_fixture("lanczos3_3840x2160_x" + tag, g0), round(in_bytes + out_bytes, 2),
-                      "Mpixels/s and bytes are per INPUT pixel: source read once + target written once", rank, kernels=["k_fir_hv (per-line gather) when enlarging, k_fir_lanes (channel-pair sweep) when reducing: one launch"])
+                      "Mpixels/s and bytes are per INPUT pixel: source read once + target written once", rank, kernels=["k_fir_hv (per-line gather): one launch"])
         if rec:
             out.append(rec)
         for d in outs:
@@ -237,15 +255,17 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
         for k, view in enumerate(gs):
             view.render(streams[k % len(streams)])
 
-    n, dt = _timed_passes(lib, _lib, streams, pass5, seconds)
-    digest = verify.canon_sha256(g.slots[0]["out"].download(streams[0]).array)
-    rec = _record(dist, gather_stats, checksum52, "config5", "3840x2160 10-node graph (4 sources, colour -> blur -> 4-step composite), frame stream",
-                  n * g.ring, w * h, dt, digest, verify.stream_fixture("config5_3840x2160", g0), NODE_BYTES_PER_PIXEL,
-                  "72 B/px is BASELINE's per-node denominator; the launches move %d B/px; eight frames in two groups of four on two HIP streams: "
-                  "a colour launch per frame, one blur + over launch per group (cvs_blur_over_f16_batch_dev)" % BYTES_PER_PIXEL,
-                  rank, {"moved_bytes_per_px": BYTES_PER_PIXEL}, moved_bytes_per_px=BYTES_PER_PIXEL,
-                  kernels=["k_color_flat (8 r + 8 w)", "k_blur_pair<9 taps, 3 layers> (two columns per lane; 8 r + 3 x 8 r + 8 w; four frames per launch)"])
-    if rec:
-        out.append(rec)
+    for flavour, sfx in (("separate", ""), ("contracted", "_contracted")):
+        with arithmetic(lib, _lib, flavour):
+            n, dt = _timed_passes(lib, _lib, streams, pass5, seconds)
+        digest = verify.canon_sha256(g.slots[0]["out"].download(streams[0]).array)
+        rec = _record(dist, gather_stats, checksum52, "config5" + sfx, "3840x2160 10-node graph (4 sources, colour -> blur -> 4-step composite), frame stream",
+                      n * g.ring, w * h, dt, digest, verify.stream_fixture("config5_3840x2160" + ("@contracted" if sfx else ""), g0), NODE_BYTES_PER_PIXEL,
+                      "72 B/px is BASELINE's per-node denominator; the launches move %d B/px; eight frames in two groups of four on two HIP streams: "
+                      "a colour launch per frame, one blur + over launch per group (cvs_blur_over_f16_batch_dev)" % BYTES_PER_PIXEL,
+                      rank, {"moved_bytes_per_px": BYTES_PER_PIXEL, "arithmetic": flavour}, moved_bytes_per_px=BYTES_PER_PIXEL,
+                      kernels=["k_color_flat (8 r + 8 w)", "k_blur_pair<9 taps, 3 layers> (two columns per lane; 8 r + 3 x 8 r + 8 w; four frames per launch)"])
+        if rec:
+            out.append(rec)
     lib.cvs_stream_destroy(streams[1])
     return out

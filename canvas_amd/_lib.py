@@ -14,8 +14,9 @@ LIB_PATH = os.path.join(_HERE, "libcanvas_hip.so")
 
 CHAIN_MAX_LAYERS = 8
 DISPLAY_RGBA8, DISPLAY_ARGB32_PREMUL = 0, 1
-FIR_PATH_AUTO, FIR_PATH_SWEEP, FIR_PATH_TILED, FIR_PATH_TABLES, FIR_PATH_LANES, FIR_PATH_HV, FIR_PATH_ONE_COLUMN, FIR_PATH_TWO_COLUMNS = 0, 1, 2, 4, 8, 16, 32, 64
-FIR_KERNEL_NONE, FIR_KERNEL_WINDOW, FIR_KERNEL_HALVE, FIR_KERNEL_LANES, FIR_KERNEL_VH, FIR_KERNEL_TILED, FIR_KERNEL_STREAM, FIR_KERNEL_TWO_PASS, FIR_KERNEL_PASS, FIR_KERNEL_HV, FIR_KERNEL_WINDOW_PAIR, FIR_KERNEL_HALVE_PAIR = range(12)
+FIR_PATH_AUTO, FIR_PATH_SWEEP, FIR_PATH_TILED, FIR_PATH_TABLES, FIR_PATH_HV, FIR_PATH_ONE_COLUMN, FIR_PATH_TWO_COLUMNS = 0, 1, 2, 4, 16, 32, 64
+FIR_KERNEL_NONE, FIR_KERNEL_WINDOW, FIR_KERNEL_HALVE, _FIR_KERNEL_RETIRED_3, FIR_KERNEL_VH, FIR_KERNEL_TILED, FIR_KERNEL_STREAM, FIR_KERNEL_TWO_PASS, FIR_KERNEL_PASS, FIR_KERNEL_HV, FIR_KERNEL_WINDOW_PAIR, FIR_KERNEL_HALVE_PAIR = range(12)
+ARITH_SEPARATE, ARITH_CONTRACTED = 0, 1          # cvs_set_arithmetic: the reference's gcc build / its clang (contracting) build
 LUT_NONE, LUT_REC709_TO_LINEAR_SCENE, LUT_REC709_TO_LINEAR_DISPLAY, LUT_LINEAR_TO_REC709, LUT_LINEAR_TO_SRGB = -1, 0, 1, 2, 3
 
 
@@ -94,6 +95,8 @@ SIGNATURES = {
     "workspace_set_item_tag": (None, [_vp, _vp]),
     "workspace_update_item": (None, [_vp, P(C.c_int64), P(C.c_int64), P(C.c_int64), P(C.c_int64), P(_vp), P(_vp)]),
     # (2) runtime + device twins
+    "cvs_set_arithmetic": (C.c_int, [C.c_int]),
+    "cvs_get_arithmetic": (C.c_int, []),
     "cvs_init": (C.c_int, [C.c_int]),
     "cvs_device_count": (C.c_int, []),
     "cvs_current_device": (C.c_int, []),
@@ -169,6 +172,7 @@ SIGNATURES = {
     "cvs_chain_last_was_fused": (C.c_int, []),
     "cvs_scale_last_was_fused": (C.c_int, []),
     "cvs_fir_last_kernel": (C.c_int, []),
+    "cvs_fir_fell_through_count": (C.c_int, []),
     "cvs_chain_last_launch_count": (C.c_int, []),
     "cvs_mix_cross_f16_dev": (C.c_int, [_F16, _F16, _F16, C.c_float, _vp]),
 }

@@ -18,7 +18,7 @@ CVS_EXPORT int cvs_color_matrix_f16_dev(rgba_frame_f16 *frame, const float m[9],
     const half *pre = cvs_lut_dev_or_null(pre_lut), *post = cvs_lut_dev_or_null(post_lut);
     if ((pre_lut != CVS_LUT_NONE && !pre) || (post_lut != CVS_LUT_NONE && !post)) return -1;
     cvk_view v = cvs_view(frame->data, &frame->full_window);
-    CVS_KERNEL(cvk_color_matrix(v, v, cvs_rect(&frame->current_window), m, pre, post, cvs_cus(), cvs_pick_stream(s)));
+    CVS_KERNEL(CVK(cvk_color_matrix)(v, v, cvs_rect(&frame->current_window), m, pre, post, cvs_cus(), cvs_pick_stream(s)));
     return 0;
 }
 
@@ -34,7 +34,7 @@ CVS_EXPORT int cvs_color_matrix_f16_to_dev(rgba_frame_f16 *out, const rgba_frame
     if (!cvs_box_contains(&in->full_window, &win)) { cvs_set_error("colour matrix: source window outside its buffer"); box2i_set_empty(&out->current_window); return -1; }
     const half *pre = cvs_lut_dev_or_null(pre_lut), *post = cvs_lut_dev_or_null(post_lut);
     if ((pre_lut != CVS_LUT_NONE && !pre) || (post_lut != CVS_LUT_NONE && !post)) { box2i_set_empty(&out->current_window); return -1; }
-    CVS_KERNEL(cvk_color_matrix(cvs_view(out->data, &out->full_window), cvs_view(in->data, &in->full_window), cvs_rect(&win), m, pre, post, cvs_cus(), cvs_pick_stream(s)));
+    CVS_KERNEL(CVK(cvk_color_matrix)(cvs_view(out->data, &out->full_window), cvs_view(in->data, &in->full_window), cvs_rect(&win), m, pre, post, cvs_cus(), cvs_pick_stream(s)));
     return 0;
 }
 
@@ -66,7 +66,7 @@ CVS_EXPORT void video_color_xyz_to_srgb(rgba_frame_f16 *frame) {
 
 static __thread int t_last_fused = -1;
 CVS_EXPORT int cvs_chain_last_was_fused(void) { return t_last_fused; }
-CVS_EXPORT int cvs_chain_last_launch_count(void) { return cvk_chain_count(); }
+CVS_EXPORT int cvs_chain_last_launch_count(void) { return CVK(cvk_chain_count)(); }
 
 static bool same_box(const box2i *a, const box2i *b) {
     return a->min.x == b->min.x && a->min.y == b->min.y && a->max.x == b->max.x && a->max.y == b->max.y;
@@ -177,11 +177,11 @@ CVS_EXPORT int cvs_chain_color_over_f16_dev(const cvs_chain_job *jobs, int njobs
         jobs[i].out->current_window = jobs[i].out->full_window;
     }
     int rc = 0;
-    cvk_chain_count_reset();
+    CVK(cvk_chain_count_reset)();
     for (int first = 0; rc == 0 && first < njobs; ) {       /* runs of mutually independent jobs, one (set of) launch(es) each */
         int end = first + 1;
         while (end < njobs && !job_depends_on_earlier(jobs, first, end)) end++;
-        rc = cvk_chain_color_over(recs + first, end - first, uniform, m, pre, post, cvs_cus(), s);
+        rc = CVK(cvk_chain_color_over)(recs + first, end - first, uniform, m, pre, post, cvs_cus(), s);
         first = end;
     }
     free(recs);
@@ -207,7 +207,7 @@ CVS_EXPORT int cvs_mix_cross_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16 *
         memset(&rec, 0, sizeof rec);
         rec.out = out->data; rec.layer[0] = a->data; rec.layer[1] = b->data; rec.nlayers = 2;
         rec.npixels = cvs_box_pixels(&out->full_window);
-        int rc = cvk_chain_cross(&rec, 1, 1.0f - mix_b, mix_b, cvs_cus(), s);
+        int rc = CVK(cvk_chain_cross)(&rec, 1, 1.0f - mix_b, mix_b, cvs_cus(), s);
         if (rc != 0) { cvs_set_error("crossfade kernel launch failed: %s", hipGetErrorString((hipError_t)rc)); box2i_set_empty(&out->current_window); return rc; }
         out->current_window = out->full_window;
         t_last_fused = 1;

@@ -70,7 +70,7 @@ CVS_EXPORT int cvs_reconstruct_dv_dev(rgba_frame_f16 *frame, const coded_image *
     const half *lut = cvs_lut_device(CVS_LUT_REC709_TO_LINEAR_SCENE);
     if (dv_taps((float)DV_SUB, &tri) != 0 || !lut) { box2i_set_empty(&frame->current_window); return -1; }
     cvk_dv_planes pl = dv_view(planar);
-    CVS_KERNEL(cvk_dv_reconstruct(cvs_view(frame->data, &frame->full_window), cvs_rect(&frame->current_window), &pl, &tri, lut, cvs_pick_stream(stream)));
+    CVS_KERNEL(CVK(cvk_dv_reconstruct)(cvs_view(frame->data, &frame->full_window), cvs_rect(&frame->current_window), &pl, &tri, lut, cvs_pick_stream(stream)));
     return 0;
 }
 
@@ -90,7 +90,7 @@ CVS_EXPORT int cvs_subsample_dv_dev(coded_image *planar, rgba_frame_f16 *frame, 
     const half *lut = cvs_lut_device(CVS_LUT_LINEAR_TO_REC709);
     if (dv_taps(1.0f / (float)DV_SUB, &tri) != 0 || !lut) return -1;
     cvk_dv_planes pl = dv_view(planar);
-    CVS_KERNEL(cvk_dv_subsample(&pl, cvs_view(frame->data, &frame->full_window), cvs_rect(&w), &tri, lut, encode_input_in_place, s));
+    CVS_KERNEL(CVK(cvk_dv_subsample)(&pl, cvs_view(frame->data, &frame->full_window), cvs_rect(&w), &tri, lut, encode_input_in_place, s));
     return 0;
 }
 

@@ -138,7 +138,7 @@ CVS_EXPORT int cvs_mix_cross_f32_dev(rgba_frame_f32 *out, const rgba_frame_f32 *
     box2i outer;
     plan_mix(&mp, out->data, &out->full_window, a->data, &a->full_window, &a->current_window,
              b->data, &b->full_window, &b->current_window, mix_a, mix_b, CVK_MIX_CROSS, 0, &outer);
-    CVS_KERNEL(cvk_mix(&mp, cvs_pick_stream(s)));
+    CVS_KERNEL(CVK(cvk_mix)(&mp, cvs_pick_stream(s)));
     out->current_window = outer;
     return 0;
 }
@@ -154,7 +154,7 @@ CVS_EXPORT int cvs_mix_over_f32_dev(rgba_frame_f32 *out, const rgba_frame_f32 *b
     box2i outer;
     plan_mix(&mp, out->data, &out->full_window, out->data, &out->full_window, &out->current_window,
              b->data, &b->full_window, &b->current_window, 1.0f, mix_b, CVK_MIX_OVER, 1, &outer);
-    CVS_KERNEL(cvk_mix(&mp, cvs_pick_stream(s)));
+    CVS_KERNEL(CVK(cvk_mix)(&mp, cvs_pick_stream(s)));
     out->current_window = outer;
     return 0;
 }
@@ -166,7 +166,7 @@ CVS_EXPORT int cvs_gain_offset_f16_dev(rgba_frame_f16 *out, const rgba_frame_f16
     box2i_intersect(&win, &out->full_window, &in->current_window);    /* gl.c:584: one-input filters cover out.full ∩ in.current */
     out->current_window = win;
     if (box2i_is_empty(&win)) return 0;
-    CVS_KERNEL(cvk_gain_offset_f16(cvs_view(out->data, &out->full_window), cvs_view(in->data, &in->full_window), cvs_rect(&win), gain, offset, cvs_pick_stream(s)));
+    CVS_KERNEL(CVK(cvk_gain_offset_f16)(cvs_view(out->data, &out->full_window), cvs_view(in->data, &in->full_window), cvs_rect(&win), gain, offset, cvs_pick_stream(s)));
     return 0;
 }
 
@@ -405,8 +405,7 @@ CVS_EXPORT void video_get_frame_f32(video_source *source, int frame_index, rgba_
 /* src/cprocess/main.c:78-103,146-172: "get a frame, but forcibly pull it from the GL pipeline" -- what
  * get_frame_f16/f32(..., force_gl=True) calls (src/process/RgbaFrameF16.c:247-249).  Slot 3 is the device slot
  * here, so the forced pull goes through the source's device entry even when it also fills a host slot; a source
- * without a device slot is pulled the ordinary way (the reference leaves the window empty there: it has no other
- * way to reach its GL pipeline, while every pixel entry of this library runs on the device anyway). */
+ * WITHOUT that slot yields an empty window, exactly as the reference's does without a get_frame_gl (main.c:99-102). */
 static int cvs_device_only(video_source *source, video_frame_source_funcs *f, video_source *forced) {
     if (!source || !source->funcs || !(source->funcs->flags & VIDEO_SOURCE_FLAG_DEVICE) || !source->funcs->get_frame_dev) return 0;
     *f = *source->funcs;
@@ -418,11 +417,13 @@ static int cvs_device_only(video_source *source, video_frame_source_funcs *f, vi
 }
 CVS_EXPORT void video_get_frame_f16_gl(video_source *source, int frame_index, rgba_frame_f16 *frame) {
     video_frame_source_funcs f; video_source forced;
-    video_get_frame_f16(cvs_device_only(source, &f, &forced) ? &forced : source, frame_index, frame);
+    if (!cvs_device_only(source, &f, &forced)) { box2i_set_empty(&frame->current_window); return; }
+    video_get_frame_f16(&forced, frame_index, frame);
 }
 CVS_EXPORT void video_get_frame_f32_gl(video_source *source, int frame_index, rgba_frame_f32 *frame) {
     video_frame_source_funcs f; video_source forced;
-    video_get_frame_f32(cvs_device_only(source, &f, &forced) ? &forced : source, frame_index, frame);
+    if (!cvs_device_only(source, &f, &forced)) { box2i_set_empty(&frame->current_window); return; }
+    video_get_frame_f32(&forced, frame_index, frame);
 }
 
 /* Fill a device frame from any source: slot 3 when the source has one, else a host pull + upload. */

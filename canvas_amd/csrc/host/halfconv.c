@@ -103,25 +103,34 @@ CVS_EXPORT void init_half(void) {                                     /* half.c:
 
 /* ---------------------------------------------------------------- transfer tables */
 
-static float tf_rec709_to_linear(float in) {                          /* gammatab.c:48-56 */
+/* `fl`: the arithmetic flavour (canvas_hip.h cvs_set_arithmetic).  Two of the four functions hold an a * pow - b in one
+ * expression, which the reference's clang build fuses (measured between the two builds of the same C: ONE of the 4 x 65536 entries
+ * differs, linear -> Rec.709 at code 0x789b); the other two are the same in both flavours and exist once. */
+static float tf_rec709_to_linear(float in, int fl) {                  /* gammatab.c:48-56 */
     const float knee = 4.5f * 0.018f;
+    (void)fl;
     return in < knee ? in / 4.5f : powf((in + 0.099f) / 1.099f, 1.0f / 0.45f);
 }
-static float tf_rec709_display(float in) {                            /* gammatab.c:145-150 */
+static float tf_rec709_display(float in, int fl) {                    /* gammatab.c:145-150 */
+    (void)fl;
     return in < 0.0f ? 0.0f : powf(in, 2.5f);
 }
-static float tf_linear_to_rec709(float in) {                          /* gammatab.c:58-66 */
-    return in < 0.018f ? in * 4.5f : 1.099f * powf(in, 0.45f) - 0.099f;
+static float tf_linear_to_rec709(float in, int fl) {                  /* gammatab.c:58-66 */
+    if (in < 0.018f) return in * 4.5f;
+    return fl ? fmaf(1.099f, powf(in, 0.45f), -0.099f) : 1.099f * powf(in, 0.45f) - 0.099f;
 }
-static float tf_linear_to_srgb(float in) {                            /* gammatab.c:201-211 */
+static float tf_linear_to_srgb(float in, int fl) {                    /* gammatab.c:201-211 */
     const float a = 0.055;
-    return in <= 0.0031308f ? in * 12.92f : (1.0f + a) * powf(in, 1.0f / 2.4f) - a;
+    if (in <= 0.0031308f) return in * 12.92f;
+    return fl ? fmaf(1.0f + a, powf(in, 1.0f / 2.4f), -a) : (1.0f + a) * powf(in, 1.0f / 2.4f) - a;
 }
+/* the slot of a table: [flavour][which], the flavour-independent tables always in flavour 0's row */
+static inline int lut_row(int which) { return (which == CVS_LUT_LINEAR_TO_REC709 || which == CVS_LUT_LINEAR_TO_SRGB) && cvs_arith() == CVS_ARITH_CONTRACTED; }
 
 static pthread_mutex_t lut_lock = PTHREAD_MUTEX_INITIALIZER;
-static half *lut_host[CVS_LUT_COUNT];
-static half *lut_dev[CVS_LUT_COUNT];
-static unsigned lut_gen[CVS_LUT_COUNT];
+static half *lut_host2[2][CVS_LUT_COUNT];
+static half *lut_dev2[2][CVS_LUT_COUNT];
+static unsigned lut_gen2[2][CVS_LUT_COUNT];
 static uint8_t *ramp45;
 static float *codes_as_float;       /* h2f of 0..65535, computed once on the GPU */
 
@@ -138,13 +147,14 @@ static int ensure_codes(void) {
     return 0;
 }
 
-static int install_locked(int which, const half *table) {
+static int install_locked(int row, int which, const half *table) {
+    half **lut_host = lut_host2[row], **lut_dev = lut_dev2[row];
     if (!lut_host[which]) lut_host[which] = malloc(HALF_COUNT * sizeof(half));
     if (!lut_host[which]) return -1;
     if (table != lut_host[which]) memcpy(lut_host[which], table, HALF_COUNT * sizeof(half));
     if (!lut_dev[which]) CVS_HIP(hipMalloc((void **)&lut_dev[which], HALF_COUNT * sizeof(half)));
     CVS_HIP(hipMemcpy(lut_dev[which], lut_host[which], HALF_COUNT * sizeof(half), hipMemcpyHostToDevice));
-    lut_gen[which]++;
+    lut_gen2[row][which]++;
     return 0;
 }
 
@@ -157,25 +167,29 @@ const float *cvs_codes_as_float(void) {
     return rc == 0 ? codes_as_float : NULL;
 }
 
-unsigned cvs_lut_generation(int which) { return (which >= 0 && which < CVS_LUT_COUNT) ? __atomic_load_n(&lut_gen[which], __ATOMIC_ACQUIRE) : 0; }
+/* (counts installs of either flavour's table, so that a composed table made from one is rebuilt when the flavour's table changes) */
+unsigned cvs_lut_generation(int which) {
+    return (which >= 0 && which < CVS_LUT_COUNT) ? __atomic_load_n(&lut_gen2[lut_row(which)][which], __ATOMIC_ACQUIRE) * 2u + (unsigned)lut_row(which) : 0;
+}
 
 static int ensure_lut(int which) {
     if (which < 0 || which >= CVS_LUT_COUNT) { cvs_set_error("no such transfer table: %d", which); return -1; }
     if (cvs_enter() != 0) return -1;
+    const int row = lut_row(which);
     pthread_mutex_lock(&lut_lock);
     int rc = 0;
-    if (!lut_dev[which]) {
-        float (*fn[CVS_LUT_COUNT])(float) = { tf_rec709_to_linear, tf_rec709_display, tf_linear_to_rec709, tf_linear_to_srgb };
+    if (!lut_dev2[row][which]) {
+        float (*fn[CVS_LUT_COUNT])(float, int) = { tf_rec709_to_linear, tf_rec709_display, tf_linear_to_rec709, tf_linear_to_srgb };
         rc = ensure_codes();
         if (rc == 0) {
             float *g = malloc(HALF_COUNT * sizeof(float));
             half *t = malloc(HALF_COUNT * sizeof(half));
             if (!g || !t) rc = -1;
             if (rc == 0) {
-                for (int i = 0; i < HALF_COUNT; i++) g[i] = fn[which](codes_as_float[i]);
+                for (int i = 0; i < HALF_COUNT; i++) g[i] = fn[which](codes_as_float[i], row);
                 rc = host_convert(t, HALF_COUNT * 2, g, HALF_COUNT * 4, HALF_COUNT, 0, 0);
             }
-            if (rc == 0) rc = install_locked(which, t);
+            if (rc == 0) rc = install_locked(row, which, t);
             free(g); free(t);
         }
     }
@@ -183,16 +197,18 @@ static int ensure_lut(int which) {
     return rc;
 }
 
-CVS_EXPORT const half *cvs_lut_device(int which) { return ensure_lut(which) == 0 ? lut_dev[which] : NULL; }
-CVS_EXPORT const half *cvs_lut_host(int which) { return ensure_lut(which) == 0 ? lut_host[which] : NULL; }
+CVS_EXPORT const half *cvs_lut_device(int which) { return ensure_lut(which) == 0 ? lut_dev2[lut_row(which)][which] : NULL; }
+CVS_EXPORT const half *cvs_lut_host(int which) { return ensure_lut(which) == 0 ? lut_host2[lut_row(which)][which] : NULL; }
 
 const half *cvs_lut_dev_or_null(int which) { return which == CVS_LUT_NONE ? NULL : cvs_lut_device(which); }
 
 CVS_EXPORT int cvs_lut_install(int which, const half *table_host) {
     if (which < 0 || which >= CVS_LUT_COUNT || !table_host) { cvs_set_error("cvs_lut_install: bad arguments"); return -1; }
     if (cvs_enter() != 0) return -1;
+    /* a caller's table replaces the built-in one of BOTH flavours */
     pthread_mutex_lock(&lut_lock);
-    int rc = install_locked(which, table_host);
+    int rc = install_locked(0, which, table_host);
+    if (rc == 0 && (which == CVS_LUT_LINEAR_TO_REC709 || which == CVS_LUT_LINEAR_TO_SRGB)) rc = install_locked(1, which, table_host);
     pthread_mutex_unlock(&lut_lock);
     return rc;
 }
@@ -205,7 +221,7 @@ static void host_transfer(int which, half *out, const half *in, size_t count) {
     int rc = cvs_stage_in(&din, in, count * 2, 1, s);
     if (rc == 0) rc = cvs_stage_in(&dout, NULL, count * 2, 0, s);
     if (rc == 0) {
-        rc = cvk_half_lookup(lut_dev[which], (uint16_t *)dout.dev, (const uint16_t *)din.dev, count, cvs_cus(), s);
+        rc = cvk_half_lookup(lut_dev2[lut_row(which)][which], (uint16_t *)dout.dev, (const uint16_t *)din.dev, count, cvs_cus(), s);
         if (rc != 0) cvs_set_error("transfer kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     }
     if (rc == 0) cvs_stage_out(&dout, out, s);

@@ -17,6 +17,8 @@
  * a g_warning, to stderr. */
 void cvs_set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 void cvs_clear_error(void);
+/* a notice for the log handler (or stderr) that is NOT an error of the call in progress: cvs_last_error() is left alone */
+void cvs_log_warning(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 
 #define CVS_HIP(expr)                                                                          \
     do {                                                                                       \
@@ -38,6 +40,11 @@ int cvs_capture_hold(hipStream_t st, void (*release)(void *), void *arg);
             return cvs_k_;                                                                     \
         }                                                                                      \
     } while (0)
+
+/* The arithmetic flavour of the call the calling thread is in (canvas_hip.h cvs_set_arithmetic; snapshot taken by
+ * cvs_enter()), and the launcher of that flavour: CVK(cvk_blur)(&bp, cus, s) is cvk_blur or cvk_blur_fma (kernels.h). */
+int cvs_arith(void);
+#define CVK(name) (cvs_arith() ? name##_fma : name)
 
 /* binds the calling thread to the library's device; lazily initialises with CVS_DEVICE (default 0).
  * 0 on success. */

@@ -18,6 +18,8 @@ static int g_device = -1;
 static int g_cus = 256;
 static char g_name[640];
 
+static int g_arith = -1;              /* CVS_ARITH_*; -1: not set yet (the environment decides at the first entry) */
+static __thread int t_arith;          /* the flavour of the call this thread is in */
 static __thread char t_error[512];
 static __thread hipStream_t t_stream;
 static __thread int t_stream_device = -1;
@@ -40,6 +42,17 @@ void cvs_set_error(const char *fmt, ...) {
     cvs_log_func handler = __atomic_load_n(&g_log_handler, __ATOMIC_ACQUIRE);
     if (handler) handler("fluggo.media.cprocess", CVS_LOG_WARNING, t_error, __atomic_load_n(&g_log_user, __ATOMIC_ACQUIRE));
     else fprintf(stderr, "canvas_hip: %s\n", t_error);
+}
+
+void cvs_log_warning(const char *fmt, ...) {
+    char text[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(text, sizeof text, fmt, ap);
+    va_end(ap);
+    cvs_log_func handler = __atomic_load_n(&g_log_handler, __ATOMIC_ACQUIRE);
+    if (handler) handler("fluggo.media.cprocess", CVS_LOG_WARNING, text, __atomic_load_n(&g_log_user, __ATOMIC_ACQUIRE));
+    else fprintf(stderr, "canvas_hip: %s\n", text);
 }
 
 void cvs_clear_error(void) { t_error[0] = 0; }
@@ -84,7 +97,29 @@ CVS_EXPORT int cvs_init(int device) {
     return 0;
 }
 
+static int arith_now(void) {
+    int a = __atomic_load_n(&g_arith, __ATOMIC_RELAXED);
+    if (a < 0) {
+        const char *env = getenv("CVS_ARITHMETIC");
+        a = env && (strcmp(env, "contracted") == 0 || strcmp(env, "fma") == 0 || strcmp(env, "1") == 0) ? CVS_ARITH_CONTRACTED : CVS_ARITH_SEPARATE;
+        int unset = -1;
+        if (!__atomic_compare_exchange_n(&g_arith, &unset, a, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) a = unset;      /* someone set it meanwhile */
+    }
+    return a;
+}
+
+CVS_EXPORT int cvs_set_arithmetic(int mode) {
+    if (mode != CVS_ARITH_SEPARATE && mode != CVS_ARITH_CONTRACTED) { cvs_set_error("cvs_set_arithmetic: unknown mode %d", mode); return -1; }
+    const int before = arith_now();
+    __atomic_store_n(&g_arith, mode, __ATOMIC_RELAXED);
+    t_arith = mode;
+    return before;
+}
+CVS_EXPORT int cvs_get_arithmetic(void) { return arith_now(); }
+int cvs_arith(void) { return t_arith; }
+
 int cvs_enter(void) {
+    t_arith = arith_now();
     if (g_device < 0) {
         const char *env = getenv("CVS_DEVICE");
         if (cvs_init(env ? atoi(env) : 0) != 0) return -1;

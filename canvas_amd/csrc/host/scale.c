@@ -22,23 +22,27 @@
 #include <stdatomic.h>
 
 static _Atomic int g_fir_path = CVS_FIR_PATH_AUTO;
+
+/* a * b + c where the reference's C has it in ONE expression (video_scale.c:65,257-277): rounded twice as its gcc build does,
+ * or once -- the fused multiply-add its clang build emits -- in the contracted flavour (canvas_hip.h cvs_set_arithmetic).
+ * This file is compiled with -ffp-contract=off, so the first form never fuses by itself. */
+static inline float madd_as(int contracted, float a, float b, float c) { return contracted ? fmaf(a, b, c) : a * b + c; }
 static _Thread_local int t_scale_fused;         /* the calling thread's last scaler call ran both passes in one launch */
 CVS_EXPORT int cvs_scale_last_was_fused(void) { return t_scale_fused; }
 static _Thread_local int t_fir_kernel;          /* CVS_FIR_KERNEL_*: the kernel the calling thread's last FIR launch went to */
 CVS_EXPORT int cvs_fir_last_kernel(void) { return t_fir_kernel; }
 /* A fused kernel that was chosen for a table pair and then did not launch: the next kernel in line still computes the
  * same pixels, 3-7x slower -- that must not go unnoticed. */
-/* Which of the two sweeps for per-line tables goes first (both compute the same sums; profiles/r03/general_fir_hv.txt):
- * the per-line gather (sweep_hv_ops.hip) when neither axis reduces much -- Lanczos3 4K -> 1.5x 0.097 against 0.119 ms, and
- * enlargements beyond 2.2x, which the channel-pair sweep (sweep_ops.hip, 32 accumulator slots) does not take at all; the
- * channel-pair sweep when reducing (4K -> 0.4x 0.041 against 0.043 ms: twice the waves on a small target, shorter halos). */
-static bool hv_goes_first(const cvk_fir2d_params *fp) { return fp->max_sw <= 44; }
-
+/* (Goes to the log handler only: the call then succeeds on the next kernel, and a successful call leaves no message in
+ * cvs_last_error(); cvs_fir_last_kernel() and cvs_fir_fell_through_count() are the programmatic signals.) */
+static _Thread_local int t_fell_through;        /* launches of the calling thread that went to the next kernel in line */
+CVS_EXPORT int cvs_fir_fell_through_count(void) { return t_fell_through; }
 static void fir_launch_fell_through(const char *kernel, int rc) {
     (void)hipGetLastError();
-    cvs_set_error("%s did not launch (%s): falling back to the next FIR kernel", kernel, hipGetErrorString((hipError_t)rc));
+    t_fell_through++;
+    cvs_log_warning("%s did not launch (%s): falling back to the next FIR kernel", kernel, hipGetErrorString((hipError_t)rc));
 }
-CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_LANES | CVS_FIR_PATH_HV | CVS_FIR_PATH_ONE_COLUMN | CVS_FIR_PATH_TWO_COLUMNS)); }
+CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_HV | CVS_FIR_PATH_ONE_COLUMN | CVS_FIR_PATH_TWO_COLUMNS)); }
 
 typedef struct {
     int t0, t1;            /* target lines covered by the table */
@@ -79,7 +83,7 @@ static int triangle_cap(float factor) {
 /* Tap table of one triangle pass.  count_touch: whether an in-range tap marks its target line as
  * used even when the other axis is empty (true for the vertical pass, :88-89; the horizontal pass
  * only marks inside its row loop, :186-187). */
-static int plan_triangle(tap_table *tb, float tmin, float smin, float factor, int s0, int s1, int t0, int t1, bool count_touch) {
+static int plan_triangle(tap_table *tb, float tmin, float smin, float factor, int s0, int s1, int t0, int t1, bool count_touch, int contracted) {
     const int cap = triangle_cap(factor);
     float *buf = malloc(sizeof(float) * (size_t)cap);
     if (!buf) return -1;
@@ -98,7 +102,7 @@ static int plan_triangle(tap_table *tb, float tmin, float smin, float factor, in
                 if (rc != 0) break;
             }
             for (int s = s0; s <= s1; s++) {
-                float centre_f = (s - smin) * factor + tmin;
+                float centre_f = madd_as(contracted, s - smin, factor, tmin);       /* video_scale.c:65 */
                 int centre = (int)floor(centre_f);
                 f.width = cap;
                 filter_createTriangle(factor, centre_f - centre, &f);
@@ -180,7 +184,7 @@ static int triangle_pass(any_frame *target, float tmin, const any_frame *source,
         fp.ntaps = table.ntaps + first; fp.tap_src = table.src + first * (size_t)table.stride; fp.taps = table.taps + first * (size_t)table.stride;
         fp.stride = table.stride;
         fp.in_half = source->half; fp.out_half = target->half;
-        rc = cvk_fir_gather(&fp, s);
+        rc = CVK(cvk_fir_gather)(&fp, s);
         if (rc == 0) t_fir_kernel = CVS_FIR_KERNEL_PASS;
     }
     axis_done(pin, s);
@@ -216,11 +220,11 @@ static int triangle_fused_vh(any_frame *target, v2f tp, const any_frame *source,
             fp.ty0 = mid_full->min.y; fp.ty1 = hi2;                   /* the vertical table's lines; lo2 .. hi2 of them are produced */
             fp.h = th; fp.v = tv;
             fp.max_sw = hfoot > 0 ? hfoot : 1;
-            if (hhi >= hlo && cvk_fir_vh_supported(&fp)) {
+            if (hhi >= hlo && CVK(cvk_fir_vh_supported)(&fp)) {
                 /* video_scale.c:25-32,44: rows the pass leaves alone are zeros */
                 const bool covers = lo2 == tf->min.y && hi2 == tf->max.y;
                 hipError_t e = covers || !any_bytes(target) ? hipSuccess : hipMemsetAsync(target->data, 0, any_bytes(target), s);
-                int krc = e == hipSuccess ? cvk_fir_vh(&fp, lo2 - fp.ty0, cvs_cus(), s) : (int)e;
+                int krc = e == hipSuccess ? CVK(cvk_fir_vh)(&fp, lo2 - fp.ty0, cvs_cus(), s) : (int)e;
                 if (krc == 0) { box2i_set(&target->cur, hlo, lo2, hhi, hi2); t_fir_kernel = CVS_FIR_KERNEL_VH; rc = 0; }
                 else { fir_launch_fell_through("k_fir_vh", krc); rc = 1; }   /* did not launch: the two passes decide */
             }
@@ -230,7 +234,7 @@ static int triangle_fused_vh(any_frame *target, v2f tp, const any_frame *source,
     return rc;
 }
 
-/* The other order (horizontal factor strictly smaller: the horizontal pass first) is the order of sweep_ops.hip's kernel.
+/* The other order (horizontal factor strictly smaller: the horizontal pass first) is the order of sweep_hv_ops.hip's kernel.
  * 0 = done, 1 = not for this kernel, < 0 = error. */
 static int triangle_fused_hv(any_frame *target, v2f tp, const any_frame *source, v2f sp, v2f fac, const box2i *mid_full, hipStream_t s) {
     const box2i *tf = &target->full, *sc = &source->cur;
@@ -239,6 +243,7 @@ static int triangle_fused_hv(any_frame *target, v2f tp, const any_frame *source,
     cvk_fir_axis tv, th;
     int vlo, vhi, hlo, hhi, pv = -1, ph = -1, hfoot = 0;
     if (hi1 < lo1) return 1;
+    if (cvs_arith() != CVS_ARITH_SEPARATE) return 1;           /* the horizontal-first sweep exists in the plain flavour only: the two passes */
     if (triangle_table_cached(tp.x, sp.x, fac.x, sc->min.x, sc->max.x, mid_full->min.x, mid_full->max.x, true, &th, &hlo, &hhi, &ph, &hfoot) != 0) return -1;
     int rc = 1;
     if (hhi >= hlo) {
@@ -254,14 +259,12 @@ static int triangle_fused_hv(any_frame *target, v2f tp, const any_frame *source,
             fp.ty0 = tf->min.y; fp.ty1 = tf->max.y;                   /* every line: those without taps are written as zeros */
             fp.h = th; fp.v = tv;
             fp.max_sw = hfoot > 0 ? hfoot : 1;
-            const bool use_hv = !(atomic_load(&g_fir_path) & CVS_FIR_PATH_LANES) && cvk_fir_hv_supported(&fp) &&
-                                ((atomic_load(&g_fir_path) & CVS_FIR_PATH_HV) || hv_goes_first(&fp) || !cvk_fir_lanes_supported(&fp));
-            if (vhi >= vlo && (use_hv || cvk_fir_lanes_supported(&fp))) {
+            if (vhi >= vlo && cvk_fir_hv_supported(&fp)) {
                 const bool covers = fp.tx0 == tf->min.x && hi2 == tf->max.x;
                 hipError_t e = covers || !any_bytes(target) ? hipSuccess : hipMemsetAsync(target->data, 0, any_bytes(target), s);
-                int krc = e != hipSuccess ? (int)e : use_hv ? cvk_fir_hv(&fp, cvs_cus(), s) : cvk_fir_lanes(&fp, cvs_cus(), s);
-                if (krc == 0) { box2i_set(&target->cur, lo2, vlo, hi2, vhi); t_fir_kernel = use_hv ? CVS_FIR_KERNEL_HV : CVS_FIR_KERNEL_LANES; rc = 0; }
-                else { fir_launch_fell_through(use_hv ? "k_fir_hv" : "k_fir_lanes", krc); rc = 1; }
+                int krc = e != hipSuccess ? (int)e : cvk_fir_hv(&fp, cvs_cus(), s);
+                if (krc == 0) { box2i_set(&target->cur, lo2, vlo, hi2, vhi); t_fir_kernel = CVS_FIR_KERNEL_HV; rc = 0; }
+                else { fir_launch_fell_through("k_fir_hv", krc); rc = 1; }
             }
         }
     }
@@ -282,12 +285,13 @@ static int scale_core(any_frame *target, v2f tp, const any_frame *source, v2f sp
     memset(&mid, 0, sizeof mid);
     const box2i *tf = &target->full, *sc = &source->cur;
     const bool x_first = fac.x < fac.y;
+    const int fl = cvs_arith() == CVS_ARITH_CONTRACTED;       /* video_scale.c:257-277: sp - d * fac and sp + d * fac, one expression each */
     if (x_first)
-        box2i_set(&mid.full, (int)(sp.x - (tp.x - tf->min.x) * fac.x), sc->min.y,
-                  (int)(sp.x + (tf->max.x - tp.x) * fac.x), sc->max.y);
+        box2i_set(&mid.full, (int)madd_as(fl, -(tp.x - tf->min.x), fac.x, sp.x), sc->min.y,
+                  (int)madd_as(fl, tf->max.x - tp.x, fac.x, sp.x), sc->max.y);
     else
-        box2i_set(&mid.full, sc->min.x, (int)(sp.y - (tp.y - tf->min.y) * fac.y),
-                  sc->max.x, (int)(sp.y + (tf->max.y - tp.y) * fac.y));
+        box2i_set(&mid.full, sc->min.x, (int)madd_as(fl, -(tp.y - tf->min.y), fac.y, sp.y),
+                  sc->max.x, (int)madd_as(fl, tf->max.y - tp.y, fac.y, sp.y));
     box2i_intersect(&mid.full, &mid.full, tf);
     mid.cur = mid.full;
     if (!(atomic_load(&g_fir_path) & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED))) {
@@ -424,6 +428,7 @@ typedef struct {
     uint64_t taps_hash;       /* blur: FNV-1a of the tap values; triangle: tmin bits << 32 | smin bits */
     int t0, t1, s0, s1;
     int tile;                 /* tile edge along this axis */
+    int flavour;              /* triangle, enlarging: the arithmetic flavour the line centres were computed in (0 elsewhere) */
 } axis_key;
 
 typedef struct {
@@ -437,7 +442,7 @@ typedef struct {
     int used_lo, used_hi;     /* target lines that receive at least one tap (the window the pass reports) */
 } axis_entry;
 
-typedef struct { const float *taps; float factor, tmin, smin; } axis_plan;    /* what the planner of the key's kind needs */
+typedef struct { const float *taps; float factor, tmin, smin; int contracted; } axis_plan;    /* what the planner of the key's kind needs */
 
 #define AXIS_CACHE 128
 static axis_entry g_axis[AXIS_CACHE];
@@ -520,56 +525,11 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
             }
         }
     }
-    /* the table by SOURCE line (kernels.h cvk_fir_axis.rec) */
-    uint32_t *rec = NULL;
-    int rec_s0 = 0, rec_n = 0, nacc = 0, rec_zero_weight = 0;
-    if (streamable && max_active >= 1 && max_active <= 32) {
-        nacc = max_active <= 8 ? 8 : max_active <= 16 ? 16 : 32;
-        int s_first = INT_MAX, s_last = INT_MIN;
-        for (int i = 0; i < lines; i++) {
-            if (!ntaps[i]) continue;
-            const int a = tb->tap_src[(size_t)i * tb->stride];
-            if (a < s_first) s_first = a;
-            if (a + ntaps[i] - 1 > s_last) s_last = a + ntaps[i] - 1;
-        }
-        /* the lines that have taps must be one run of consecutive lines: the sweep stores them to consecutive rows in the
-         * order in which they end, and gives the second line that ends on a source row the next slot */
-        bool one_run = true;
-        {
-            int seen = 0, closed = 0;
-            for (int i = 0; i < lines; i++) {
-                if (ntaps[i]) { if (closed) one_run = false; seen = 1; }
-                else if (seen) closed = 1;
-            }
-        }
-        if (s_last >= s_first && one_run) {
-            rec_s0 = s_first; rec_n = s_last - s_first + 1;
-            const size_t rs = 2 * (size_t)nacc + 4;              /* every weight twice: a register PAIR for the packed multiply */
-            rec = calloc(((size_t)rec_n + 1) * rs, sizeof *rec);          /* + one spare record: the kernel loads a row ahead */
-            if (!rec) { free(foot); free(ntaps); return -1; }
-            for (int i = 0; i < lines; i++) {
-                const int n = ntaps[i];
-                if (!n) continue;
-                const int a = tb->tap_src[(size_t)i * tb->stride], slot = i & (nacc - 1);
-                for (int k = 0; k < n; k++) {
-                    uint32_t *r = rec + (size_t)(a + k - rec_s0) * rs;
-                    r[0] |= 1u << slot;
-                    memcpy(&r[4 + 2 * slot], &tb->taps[(size_t)i * tb->stride + k], 4);
-                    r[5 + 2 * slot] = r[4 + 2 * slot];
-                    if (tb->taps[(size_t)i * tb->stride + k] == 0.0f) rec_zero_weight = 1;
-                    if (k == n - 1) {
-                        if (!r[1]) r[2] = (uint32_t)i;           /* lines come in ascending order: the first to end here */
-                        r[1] |= 1u << slot;
-                    }
-                }
-            }
-        }
-    }
     /* the table by TARGET line in one record each (kernels.h cvk_fir_axis.lrec): one scalar load per line */
     uint32_t *lrec = NULL;
     if (streamable && max_taps >= 1 && max_taps <= CVK_FIR_LREC - 2) {
         lrec = calloc(((size_t)lines + 1) * CVK_FIR_LREC, sizeof *lrec);      /* + one spare record: the kernel loads a line ahead */
-        if (!lrec) { free(foot); free(ntaps); free(rec); return -1; }
+        if (!lrec) { free(foot); free(ntaps); return -1; }
         for (int i = 0; i <= lines; i++) {
             uint32_t *r = lrec + (size_t)i * CVK_FIR_LREC;
             const int n = i < lines ? ntaps[i] : 0;
@@ -582,9 +542,7 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     const size_t off_src = (n_l * sizeof(int) + 255) & ~(size_t)255;
     const size_t off_tap = off_src + ((n_t * sizeof(int) + 255) & ~(size_t)255);
     const size_t off_foot = off_tap + ((n_t * sizeof(float) + 255) & ~(size_t)255);
-    const size_t off_rec = off_foot + ((sizeof(int) * 2 * (size_t)(tiles ? tiles : 1) + 255) & ~(size_t)255);
-    const size_t rec_bytes = rec ? ((size_t)rec_n + 1) * (2 * (size_t)nacc + 4) * sizeof *rec : 0;
-    const size_t off_lrec = off_rec + (((rec_bytes ? rec_bytes : 4) + 255) & ~(size_t)255);
+    const size_t off_lrec = off_foot + ((sizeof(int) * 2 * (size_t)(tiles ? tiles : 1) + 255) & ~(size_t)255);
     const size_t lrec_bytes = lrec ? ((size_t)lines + 1) * CVK_FIR_LREC * sizeof *lrec : 0;
     const size_t total = off_lrec + (lrec_bytes ? lrec_bytes : 4);
     char *dev = NULL;
@@ -593,9 +551,8 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     if (err == hipSuccess) err = hipMemcpy(dev + off_src, tb->tap_src, n_t * sizeof(int), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(dev + off_tap, tb->taps, n_t * sizeof(float), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(dev + off_foot, foot, sizeof(int) * 2 * (size_t)(tiles ? tiles : 1), hipMemcpyHostToDevice);
-    if (err == hipSuccess && rec_bytes) err = hipMemcpy(dev + off_rec, rec, rec_bytes, hipMemcpyHostToDevice);
     if (err == hipSuccess && lrec_bytes) err = hipMemcpy(dev + off_lrec, lrec, lrec_bytes, hipMemcpyHostToDevice);
-    free(foot); free(ntaps); free(rec); free(lrec);
+    free(foot); free(ntaps); free(lrec);
     if (err != hipSuccess) { if (dev) hipFree(dev); cvs_set_error("FIR table upload: %s", hipGetErrorString(err)); return -1; }
     e->dev = dev;
     e->axis.ntaps = (const int *)dev;
@@ -604,9 +561,6 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     e->axis.foot = (const int *)(dev + off_foot);
     e->axis.stride = tb->stride;
     e->axis.max_taps = max_taps; e->axis.wide_foot = wide_foot; e->axis.max_active = max_active; e->axis.streamable = streamable;
-    e->axis.rec = rec_bytes ? (const uint32_t *)(dev + off_rec) : NULL;
-    e->axis.rec_s0 = rec_s0; e->axis.rec_n = rec_bytes ? rec_n : 0; e->axis.nacc = nacc;
-    e->axis.rec_zero_weight = rec_zero_weight;
     e->axis.lrec = lrec_bytes ? (const uint32_t *)(dev + off_lrec) : NULL;
     e->max_foot = max_foot;
     return 0;
@@ -660,7 +614,7 @@ static int axis_get_ex(const axis_key *key, const axis_plan *pl, cvk_fir_axis *o
     tap_table tb;
     int rc = key->kind == 1 ? plan_blur(&tb, key->t0, key->t1, key->s0, key->s1, pl->taps, key->ksize)
            : key->kind == 2 ? plan_lanczos(&tb, key->t0, key->t1, key->s0, key->s1, pl->factor, key->ksize)
-                            : plan_triangle(&tb, pl->tmin, pl->smin, pl->factor, key->s0, key->s1, key->t0, key->t1, key->ksize != 0);
+                            : plan_triangle(&tb, pl->tmin, pl->smin, pl->factor, key->s0, key->s1, key->t0, key->t1, key->ksize != 0, pl->contracted);
     if (rc != 0) { cvs_set_error("FIR planning: out of memory"); return -1; }
     axis_entry fresh;
     memset(&fresh, 0, sizeof fresh);
@@ -716,7 +670,7 @@ static void axis_done(int pin, hipStream_t s) {
 }
 
 static int axis_get(const axis_key *key, const float *taps, float factor, cvk_fir_axis *out, int *max_foot, int *pin) {
-    const axis_plan pl = { taps, factor, 0.0f, 0.0f };
+    const axis_plan pl = { taps, factor, 0.0f, 0.0f, 0 };
     return axis_get_ex(key, &pl, out, max_foot, NULL, NULL, pin);
 }
 
@@ -724,8 +678,11 @@ static int triangle_table_cached(float tmin, float smin, float factor, int s0, i
                                  cvk_fir_axis *axis, int *used_lo, int *used_hi, int *pin, int *max_foot) {
     uint32_t fb, tb, sb;
     memcpy(&fb, &factor, 4); memcpy(&tb, &tmin, 4); memcpy(&sb, &smin, 4);
-    const axis_key key = make_key(3, fb, count_touch ? 1 : 0, ((uint64_t)tb << 32) | sb, t0, t1, s0, s1, CVK_FIR2D_TILE_X);
-    const axis_plan pl = { NULL, factor, tmin, smin };
+    axis_key key = make_key(3, fb, count_touch ? 1 : 0, ((uint64_t)tb << 32) | sb, t0, t1, s0, s1, CVK_FIR2D_TILE_X);
+    /* only the enlarging form has a product and a sum in one expression (the reducing form divides, video_scale.c:95) */
+    const int contracted = factor > 1.0f && cvs_arith() == CVS_ARITH_CONTRACTED;
+    key.flavour = contracted;
+    const axis_plan pl = { NULL, factor, tmin, smin, contracted };
     int foot;
     int rc = axis_get_ex(&key, &pl, axis, &foot, used_lo, used_hi, pin);
     if (max_foot) *max_foot = foot;
@@ -747,7 +704,7 @@ static int gather_pass(void *tdata, const box2i *tfull, int out_half, const void
     fp.t0 = t0; fp.t1 = t1; fp.lo = lo; fp.hi = hi;
     fp.ntaps = tab->ntaps; fp.tap_src = tab->src; fp.taps = tab->taps; fp.stride = tab->stride;
     fp.in_half = in_half; fp.out_half = out_half;
-    return cvk_fir_gather(&fp, s);
+    return CVK(cvk_fir_gather)(&fp, s);
 }
 
 static int fir_two_launches(void *tdata, const box2i *tfull, int out_half, const void *sdata, const box2i *sfull, const box2i *sw, int in_half,
@@ -784,25 +741,18 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
     const int force = atomic_load(&g_fir_path);
     /* First choice: the gather per target line (sweep_hv_ops.hip), whenever first taps never decrease down the vertical
      * table and the lists fit an instance. */
-    const bool pinned = (force & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_LANES | CVS_FIR_PATH_HV)) != 0;
-    if ((force & CVS_FIR_PATH_HV) || (!pinned && (hv_goes_first(&fp) || !cvk_fir_lanes_supported(&fp)))) {
+    const bool pinned = (force & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_HV)) != 0;
+    const bool plain = cvs_arith() == CVS_ARITH_SEPARATE;      /* the two sweeps below exist in the plain flavour only; the tiles and the passes in both */
+    if (plain) {
+    if ((force & CVS_FIR_PATH_HV) || !pinned) {
         if (cvk_fir_hv_supported(&fp)) {
             int rc = cvk_fir_hv(&fp, cvs_cus(), s);
             if (rc == 0) { t_fir_kernel = CVS_FIR_KERNEL_HV; return 0; }
             fir_launch_fell_through("k_fir_hv", rc);          /* did not launch: the older kernels decide */
         }
     }
-    /* Second: the sweep with one lane per target column and channel pair (sweep_ops.hip), whenever the vertical table
-     * could be turned round for it and the lists fit. */
-    if ((force & CVS_FIR_PATH_LANES) || !(force & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED))) {
-        if (cvk_fir_lanes_supported(&fp)) {
-            int rc = cvk_fir_lanes(&fp, cvs_cus(), s);
-            if (rc == 0) { t_fir_kernel = CVS_FIR_KERNEL_LANES; return 0; }
-            fir_launch_fell_through("k_fir_lanes", rc);       /* did not launch: the older kernels decide */
-        }
-    }
     const bool can_stream = v->streamable && h->max_taps >= 1 && v->max_active >= 1 && cvk_fir_stream_supported(h->max_taps, v->max_active);
-    const bool want_stream = (force & CVS_FIR_PATH_SWEEP) ? true : cvk_fir2d_lds_bytes(&fp) > 64 * 1024;
+    const bool want_stream = (force & CVS_FIR_PATH_SWEEP) ? true : CVK(cvk_fir2d_lds_bytes)(&fp) > 64 * 1024;
     if (can_stream && want_stream && !(force & CVS_FIR_PATH_TILED)) {
         cvk_fir2d_params sp = fp;
         sp.max_sw = h->wide_foot > 0 ? h->wide_foot : 1;
@@ -811,8 +761,9 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
         if (rc == 0) { t_fir_kernel = CVS_FIR_KERNEL_STREAM; return 0; }
         fir_launch_fell_through("k_fir_stream", rc);          /* did not fit: the tiled kernel decides */
     }
-    if (cvk_fir2d_lds_bytes(&fp) > 150 * 1024 || h->stride > 64 || v->stride > 64) return 1;
-    int rc = cvk_fir2d(&fp, s);
+    }
+    if (CVK(cvk_fir2d_lds_bytes)(&fp) > 150 * 1024 || h->stride > 64 || v->stride > 64) return 1;
+    int rc = CVK(cvk_fir2d)(&fp, s);
     if (rc != 0) { cvs_set_error("fused FIR launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
     t_fir_kernel = CVS_FIR_KERNEL_TILED;
     return 0;
@@ -827,7 +778,7 @@ static int blur_column_pins(void) {
 static bool blur_has_fast_kernel(const float *taps, int ntaps) {
     bool finite = true;
     for (int k = 0; k < ntaps; k++) finite = finite && isfinite(taps[k]);
-    return finite && cvk_blur_supported(ntaps, 1) && !(atomic_load(&g_fir_path) & CVS_FIR_PATH_TABLES);
+    return finite && CVK(cvk_blur_supported)(ntaps, 1) && !(atomic_load(&g_fir_path) & CVS_FIR_PATH_TABLES);
 }
 
 /* `over`: nover f16 buffers with the target's layout, blended over the blur result before the store (f16 in/out only) */
@@ -852,9 +803,9 @@ static int blur_fused_over_batch(void *tdata, const box2i *tfull, int out_half, 
             bp.batch = *batch;
         }
         bp.flags = blur_column_pins();
-        int rc = cvk_blur(&bp, cvs_cus(), s);
+        int rc = CVK(cvk_blur)(&bp, cvs_cus(), s);
         if (rc != 0) { cvs_set_error("blur launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
-        t_fir_kernel = cvk_blur_takes_pairs(&bp) ? CVS_FIR_KERNEL_WINDOW_PAIR : CVS_FIR_KERNEL_WINDOW;
+        t_fir_kernel = CVK(cvk_blur_takes_pairs)(&bp) ? CVS_FIR_KERNEL_WINDOW_PAIR : CVS_FIR_KERNEL_WINDOW;
         return 0;
     }
     if (nover > 0 || batch) return 1;   /* the gather kernel has no epilogue and takes one frame: the caller goes node by node / frame by frame */
@@ -899,7 +850,7 @@ static int lanczos_fused(void *tdata, const box2i *tfull, int out_half, const vo
     if (fx == 0.5f && fy == 0.5f && !(atomic_load(&g_fir_path) & CVS_FIR_PATH_TABLES)) {
         fir_filter f = { NULL, 0, 0 };
         filter_createLanczos(0.5f, ksize, 0.0f, &f);
-        bool usable = f.coeff && cvk_blur_supported(f.width, 2) && f.center == f.width / 2 &&
+        bool usable = f.coeff && CVK(cvk_blur_supported)(f.width, 2) && f.center == f.width / 2 &&
                       tfull->min.x > -(1 << 22) && tfull->max.x < (1 << 22) && tfull->min.y > -(1 << 22) && tfull->max.y < (1 << 22);
         for (int k = 0; usable && k < f.width; k++) usable = isfinite(f.coeff[k]);
         if (usable && in_half && out_half && f.width <= 16) {
@@ -915,9 +866,9 @@ static int lanczos_fused(void *tdata, const box2i *tfull, int out_half, const vo
             hp.taps1[0] = 1.0f;
             memcpy(hp.taps2, f.coeff, sizeof(float) * (size_t)f.width);
             hp.flags = blur_column_pins();
-            if (cvk_blur_halve_takes_pairs(&hp)) {
+            if (CVK(cvk_blur_halve_takes_pairs)(&hp)) {
                 filter_free(&f);
-                int rc = cvk_blur_halve_pair(&hp, cvs_cus(), s);
+                int rc = CVK(cvk_blur_halve_pair)(&hp, cvs_cus(), s);
                 if (rc != 0) { cvs_set_error("resample launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
                 t_fir_kernel = CVS_FIR_KERNEL_HALVE_PAIR;
                 return 0;
@@ -934,7 +885,7 @@ static int lanczos_fused(void *tdata, const box2i *tfull, int out_half, const vo
             bp.ntaps = f.width; bp.step = 2;
             memcpy(bp.taps, f.coeff, sizeof(float) * (size_t)f.width);
             filter_free(&f);
-            int rc = cvk_blur(&bp, cvs_cus(), s);
+            int rc = CVK(cvk_blur)(&bp, cvs_cus(), s);
             if (rc != 0) { cvs_set_error("resample launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
             t_fir_kernel = CVS_FIR_KERNEL_WINDOW;
             return 0;
@@ -1080,7 +1031,7 @@ CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame
         fir_filter f = { NULL, 0, 0 };
         filter_createLanczos(0.5f, ksize, 0.0f, &f);
         const box2i *tf = &target->full_window;
-        bool usable = f.coeff && f.center == f.width / 2 && cvk_blur_halve_supported(ntaps, f.width) &&
+        bool usable = f.coeff && f.center == f.width / 2 && CVK(cvk_blur_halve_supported)(ntaps, f.width) &&
                       tf->min.x > -(1 << 22) && tf->max.x < (1 << 22) && tf->min.y > -(1 << 22) && tf->max.y < (1 << 22);
         for (int k = 0; usable && k < f.width; k++) usable = isfinite(f.coeff[k]);
         for (int k = 0; usable && k < ntaps; k++) usable = isfinite(taps[k]);
@@ -1097,10 +1048,10 @@ CVS_EXPORT int cvs_blur_lanczos_f16_dev(rgba_frame_f16 *target, const rgba_frame
             memcpy(bp.taps2, f.coeff, sizeof(float) * (size_t)f.width);
             filter_free(&f);
             bp.flags = blur_column_pins();
-            int rc = cvk_blur_halve(&bp, cvs_cus(), s);
+            int rc = CVK(cvk_blur_halve)(&bp, cvs_cus(), s);
             if (rc != 0) { cvs_set_error("blur + halving launch failed: %s", hipGetErrorString((hipError_t)rc)); box2i_set_empty(&target->current_window); return -1; }
             target->current_window = target->full_window;
-            t_fir_kernel = cvk_blur_halve_takes_pairs(&bp) ? CVS_FIR_KERNEL_HALVE_PAIR : CVS_FIR_KERNEL_HALVE;
+            t_fir_kernel = CVK(cvk_blur_halve_takes_pairs)(&bp) ? CVS_FIR_KERNEL_HALVE_PAIR : CVS_FIR_KERNEL_HALVE;
             return 0;
         }
         filter_free(&f);
@@ -1124,6 +1075,17 @@ CVS_EXPORT int cvs_blur_over_f16_batch_dev(rgba_frame_f16 *const *outs, const rg
                                            const rgba_frame_f16 *const *overlays, int noverlays, int count, cvs_stream_t stream) {
     if (count <= 0) return 0;
     if (!outs || !sources || ntaps < 1 || !taps || noverlays < 0 || (noverlays > 0 && !overlays)) { cvs_set_error("blur+over batch: bad arguments"); return -1; }
+    for (int i = 0; i < count; i++) {
+        if (!outs[i] || !sources[i]) { cvs_set_error("blur+over batch: frame %d of %d is a null pointer", i, count); return -1; }
+        for (int l = 0; l < noverlays; l++)
+            if (!overlays[(size_t)i * noverlays + l]) { cvs_set_error("blur+over batch: layer %d of frame %d is a null pointer", l, i); return -1; }
+    }
+    for (int i = 0; i < count; i++)
+        if (!cvs_box_contains(&sources[i]->full_window, &sources[i]->current_window)) {
+            cvs_set_error("cvs_blur_over_f16_batch_dev: the input's current_window lies outside its buffer (frame %d)", i);
+            for (int k = 0; k < count; k++) box2i_set_empty(&outs[k]->current_window);
+            return -1;
+        }
     if (cvs_enter() != 0) { for (int i = 0; i < count; i++) box2i_set_empty(&outs[i]->current_window); return -1; }
     hipStream_t s = cvs_pick_stream(stream);
     const box2i *full = &outs[0]->full_window;
@@ -1168,6 +1130,16 @@ CVS_EXPORT int cvs_blur_lanczos_f16_batch_dev(rgba_frame_f16 *const *targets, co
                                               const float *taps, int ntaps, float fx, float fy, int ksize, cvs_stream_t stream) {
     if (count <= 0) return 0;
     if (!targets || !sources || ntaps < 1 || !taps || !(fx > 0.0f) || !(fy > 0.0f) || ksize < 1) { cvs_set_error("blur+lanczos batch: bad arguments"); return -1; }
+    for (int i = 0; i < count; i++)
+        if (!targets[i] || !sources[i]) { cvs_set_error("blur+lanczos batch: frame %d of %d is a null pointer", i, count); return -1; }
+    /* what count single calls would refuse, the batch refuses -- before any launch: a source window that reaches outside its
+     * own buffer would send the sweep's row descriptors out of bounds */
+    for (int i = 0; i < count; i++)
+        if (!cvs_box_contains(&sources[i]->full_window, &sources[i]->current_window)) {
+            cvs_set_error("cvs_blur_lanczos_f16_batch_dev: the input's current_window lies outside its buffer (frame %d)", i);
+            for (int k = 0; k < count; k++) box2i_set_empty(&targets[k]->current_window);
+            return -1;
+        }
     if (cvs_enter() != 0) { for (int i = 0; i < count; i++) box2i_set_empty(&targets[i]->current_window); return -1; }
     hipStream_t s = cvs_pick_stream(stream);
     int rc = 0, done = 0;
@@ -1180,7 +1152,7 @@ CVS_EXPORT int cvs_blur_lanczos_f16_batch_dev(rgba_frame_f16 *const *targets, co
         fir_filter f = { NULL, 0, 0 };
         filter_createLanczos(0.5f, ksize, 0.0f, &f);
         const box2i *tf = &targets[0]->full_window, *sw = &sources[0]->current_window;
-        bool usable = f.coeff && f.center == f.width / 2 && cvk_blur_halve_supported(ntaps, f.width) &&
+        bool usable = f.coeff && f.center == f.width / 2 && CVK(cvk_blur_halve_supported)(ntaps, f.width) &&
                       tf->min.x > -(1 << 22) && tf->max.x < (1 << 22) && tf->min.y > -(1 << 22) && tf->max.y < (1 << 22);
         for (int k = 0; usable && k < f.width; k++) usable = isfinite(f.coeff[k]);
         for (int k = 0; usable && k < ntaps; k++) usable = isfinite(taps[k]);
@@ -1202,10 +1174,10 @@ CVS_EXPORT int cvs_blur_lanczos_f16_batch_dev(rgba_frame_f16 *const *targets, co
             memcpy(bp.taps1, taps, sizeof(float) * (size_t)ntaps);
             memcpy(bp.taps2, f.coeff, sizeof(float) * (size_t)f.width);
             bp.flags = blur_column_pins();
-            int krc = cvk_blur_halve(&bp, cvs_cus(), s);
+            int krc = CVK(cvk_blur_halve)(&bp, cvs_cus(), s);
             if (krc != 0) { cvs_set_error("blur + halving launch failed: %s", hipGetErrorString((hipError_t)krc)); rc = -1; break; }
             for (int i = 0; i < n; i++) targets[done + i]->current_window = targets[done + i]->full_window;
-            t_fir_kernel = cvk_blur_halve_takes_pairs(&bp) ? CVS_FIR_KERNEL_HALVE_PAIR : CVS_FIR_KERNEL_HALVE;
+            t_fir_kernel = CVK(cvk_blur_halve_takes_pairs)(&bp) ? CVS_FIR_KERNEL_HALVE_PAIR : CVS_FIR_KERNEL_HALVE;
             done += n;
         }
         filter_free(&f);

@@ -68,6 +68,16 @@ constexpr int CH = 6;
 template <int NT, class At>
 __device__ __forceinline__ Px fir(const float (&w)[NT], At at) {
     Px o = { f32x2{ 0.0f, 0.0f }, f32x2{ 0.0f, 0.0f } };
+    if constexpr (cvs::kContract) {
+        // the clang build's t += s * c: one fused multiply-add per tap, the first (fma(s, c, 0)) the plain product
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            const Px v = at(k);
+            if (k == 0) { o.rg = v.rg * w[0]; o.ba = v.ba * w[0]; }
+            else { o.rg = cvs::madd(v.rg, w[k], o.rg); o.ba = cvs::madd(v.ba, w[k], o.ba); }
+        }
+        return o;
+    }
 #pragma unroll
     for (int k0 = 0; k0 < NT; k0 += CH) {
         f32x2 prg[CH], pba[CH];
@@ -91,6 +101,11 @@ __device__ __forceinline__ Px fir(const float (&w)[NT], At at) {
 template <int NT, class At>
 __device__ __forceinline__ f32x2 fir1(const float (&w)[NT], At at) {
     f32x2 o = { 0.0f, 0.0f };
+    if constexpr (cvs::kContract) {
+#pragma unroll
+        for (int k = 0; k < NT; k++) o = (k == 0) ? at(0) * w[0] : cvs::madd(at(k), w[k], o);
+        return o;
+    }
 #pragma unroll
     for (int k0 = 0; k0 < NT; k0 += 2 * CH) {
         f32x2 p[2 * CH];
@@ -103,6 +118,7 @@ __device__ __forceinline__ f32x2 fir1(const float (&w)[NT], At at) {
     return o;
 }
 
+#ifdef CVS_DIAG       /* the one-row-per-barrier form: superseded by k_blur_halve2 below, kept for A/B runs of the diagnostic build only */
 template <int NT1, int NT2, int W, bool INH>
 __global__ __launch_bounds__(W) void k_blur_halve(cvk_blur_halve_params bp) {
     static_assert(NT1 % 2 == 1 && NT2 % 2 == 1 && NT1 <= RL && NT2 < RL && RL % 2 == 0, "ring layout");
@@ -223,6 +239,7 @@ __global__ __launch_bounds__(W) void k_blur_halve(cvk_blur_halve_params bp) {
         each_slot(step, std::make_integer_sequence<int, RL>{});
     }
 }
+#endif
 
 // The same sweep with TWO source rows per barrier.  A row step is a latency chain (row -> LDS -> barrier -> H1 -> ring ->
 // V1 -> LDS -> barrier -> H2 -> ring -> V2) that three waves per SIMD do not hide, and a good part of it is the barrier
@@ -371,6 +388,9 @@ inline bool two_rows_per_barrier() {
     static std::atomic<int> cached{ -1 };
     int v = cached.load(std::memory_order_relaxed);
     if (v < 0) { const char *e = CVS_DIAG_ENV("CVS_BLUR_HALVE_FORM"); v = e ? (atoi(e) == 2) : kTwoRowsDefault; cached.store(v, std::memory_order_relaxed); }
+#ifndef CVS_DIAG
+    return true;                      // the product has the two-row form only
+#endif
     return v != 0;
 }
 
@@ -385,7 +405,9 @@ int launch(cvk_blur_halve_params bp, int cus, hipStream_t s) {
     int mine = cached.load(std::memory_order_relaxed);
     if (!mine) {
         if (two) mine = bp.in_half ? resident_per_cu(k_blur_halve2<NT1, NT2, W, true>, W) : resident_per_cu(k_blur_halve2<NT1, NT2, W, false>, W);
+#ifdef CVS_DIAG
         else     mine = bp.in_half ? resident_per_cu(k_blur_halve<NT1, NT2, W, true>, W) : resident_per_cu(k_blur_halve<NT1, NT2, W, false>, W);
+#endif
         cached.store(mine, std::memory_order_relaxed);
     }
 #ifdef CVS_DIAG
@@ -407,10 +429,13 @@ int launch(cvk_blur_halve_params bp, int cus, hipStream_t s) {
     if (two) {
         if (bp.in_half) hipLaunchKernelGGL((k_blur_halve2<NT1, NT2, W, true>), grid, dim3(W), 0, s, bp);
         else            hipLaunchKernelGGL((k_blur_halve2<NT1, NT2, W, false>), grid, dim3(W), 0, s, bp);
-    } else {
+    }
+#ifdef CVS_DIAG
+    else {
         if (bp.in_half) hipLaunchKernelGGL((k_blur_halve<NT1, NT2, W, true>), grid, dim3(W), 0, s, bp);
         else            hipLaunchKernelGGL((k_blur_halve<NT1, NT2, W, false>), grid, dim3(W), 0, s, bp);
     }
+#endif
     return (int)hipGetLastError();
 }
 

@@ -140,8 +140,14 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
                 f32x2 hrg, hba;
 #pragma unroll
                 for (int k = 0; k < NT2; k++) {
+                    // t += s * c: product and sum rounded apart, or (the clang build, CVS_CONTRACT) as one fused multiply-add
+                    if constexpr (cvs::kContract) {
+                        if (k == 0) { hrg = f32x2{ u[0].x, u[0].y } * w2[0]; hba = f32x2{ u[0].z, u[0].w } * w2[0]; }
+                        else { hrg = cvs::madd(f32x2{ u[k].x, u[k].y }, w2[k], hrg); hba = cvs::madd(f32x2{ u[k].z, u[k].w }, w2[k], hba); }
+                    } else {
                     const f32x2 p = f32x2{ u[k].x, u[k].y } * w2[k], q = f32x2{ u[k].z, u[k].w } * w2[k];
                     if (k == 0) { hrg = p; hba = q; } else { hrg = hrg + p; hba = hba + q; }
+                    }
                 }
                 win2[NT2 - 1 + par].rg = hrg;                  // even step: slot NT2 - 1, odd step: slot NT2
                 win2[NT2 - 1 + par].ba = hba;
@@ -152,8 +158,13 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
                     f32x2 org, oba;
 #pragma unroll
                     for (int k = 0; k < NT2; k++) {
+                        if constexpr (cvs::kContract) {
+                            if (k == 0) { org = win2[1].rg * w2[0]; oba = win2[1].ba * w2[0]; }
+                            else { org = cvs::madd(win2[1 + k].rg, w2[k], org); oba = cvs::madd(win2[1 + k].ba, w2[k], oba); }
+                        } else {
                         const f32x2 p = win2[1 + k].rg * w2[k], q = win2[1 + k].ba * w2[k];
                         if (k == 0) { org = p; oba = q; } else { org = org + p; oba = oba + q; }
+                        }
                     }
                     // truncation to half: |x| >= 65536 must become an infinity, which only waves that hold such a value pay for
                     float big;
@@ -182,10 +193,18 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
                 if constexpr (NT1 == 1) { rg0 = f32x2{ v[0].x, v[0].y }; ba0 = f32x2{ v[0].z, v[0].w }; rg1 = f32x2{ v[1].x, v[1].y }; ba1 = f32x2{ v[1].z, v[1].w }; }
 #pragma unroll
                 for (int k = 0; k < (NT1 == 1 ? 0 : NT1); k++) {
+                    if constexpr (cvs::kContract) {
+                        if (k == 0) { rg0 = f32x2{ v[0].x, v[0].y } * w1[0]; ba0 = f32x2{ v[0].z, v[0].w } * w1[0]; rg1 = f32x2{ v[1].x, v[1].y } * w1[0]; ba1 = f32x2{ v[1].z, v[1].w } * w1[0]; }
+                        else {
+                            rg0 = cvs::madd(f32x2{ v[k].x, v[k].y }, w1[k], rg0); ba0 = cvs::madd(f32x2{ v[k].z, v[k].w }, w1[k], ba0);
+                            rg1 = cvs::madd(f32x2{ v[k + 1].x, v[k + 1].y }, w1[k], rg1); ba1 = cvs::madd(f32x2{ v[k + 1].z, v[k + 1].w }, w1[k], ba1);
+                        }
+                    } else {
                     const f32x2 p0 = f32x2{ v[k].x, v[k].y } * w1[k], q0 = f32x2{ v[k].z, v[k].w } * w1[k];
                     const f32x2 p1 = f32x2{ v[k + 1].x, v[k + 1].y } * w1[k], q1 = f32x2{ v[k + 1].z, v[k + 1].w } * w1[k];
                     if (k == 0) { rg0 = p0; ba0 = q0; rg1 = p1; ba1 = q1; }
                     else { rg0 = rg0 + p0; ba0 = ba0 + q0; rg1 = rg1 + p1; ba1 = ba1 + q1; }
+                    }
                 }
                 ring1[j1][0].rg = rg0; ring1[j1][0].ba = ba0;
                 ring1[j1][1].rg = rg1; ring1[j1][1].ba = ba1;
@@ -195,9 +214,14 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
 #pragma unroll
                     for (int k = 0; k < (NT1 == 1 ? 0 : NT1); k++) {
                         const Px &a = ring1[(j1 + 1 + k) % NT1][0], &b = ring1[(j1 + 1 + k) % NT1][1];
+                        if constexpr (cvs::kContract) {
+                            if (k == 0) { b0.rg = a.rg * w1[0]; b0.ba = a.ba * w1[0]; b1.rg = b.rg * w1[0]; b1.ba = b.ba * w1[0]; }
+                            else { b0.rg = cvs::madd(a.rg, w1[k], b0.rg); b0.ba = cvs::madd(a.ba, w1[k], b0.ba); b1.rg = cvs::madd(b.rg, w1[k], b1.rg); b1.ba = cvs::madd(b.ba, w1[k], b1.ba); }
+                        } else {
                         const f32x2 p0 = a.rg * w1[k], q0 = a.ba * w1[k], p1 = b.rg * w1[k], q1 = b.ba * w1[k];
                         if (k == 0) { b0.rg = p0; b0.ba = q0; b1.rg = p1; b1.ba = q1; }
                         else { b0.rg = b0.rg + p0; b0.ba = b0.ba + q0; b1.rg = b1.rg + p1; b1.ba = b1.ba + q1; }
+                        }
                     }
                     const int by = ys0 + i - C1;               // the blurred row just completed
                     const bool row_in = by >= bp.sy0 && by <= bp.sy1;       // uniform

@@ -181,6 +181,14 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
                 float4 v[CH];
 #pragma unroll
                 for (int c = 0; c < CH; c++) if (k0 + c < NT) v[c] = buf[(k0 + c) % STEP][lane + (k0 + c) / STEP];
+                if constexpr (cvs::kContract) {
+                    // the clang build's t += s * c: one fused multiply-add per tap (the first: fma(s, c, 0) = the product)
+#pragma unroll
+                    for (int c = 0; c < CH; c++) if (k0 + c < NT) {
+                        if (k0 + c == 0) { rg = f32x2{ v[c].x, v[c].y } * w[0]; ba = f32x2{ v[c].z, v[c].w } * w[0]; }
+                        else { rg = cvs::madd(f32x2{ v[c].x, v[c].y }, w[k0 + c], rg); ba = cvs::madd(f32x2{ v[c].z, v[c].w }, w[k0 + c], ba); }
+                    }
+                } else {
                 f32x2 prg[CH], pba[CH];
 #pragma unroll
                 for (int c = 0; c < CH; c++) if (k0 + c < NT) {
@@ -194,6 +202,7 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
                     if (k0 + c == 0) { rg = prg[c]; ba = pba[c]; }
                     else { rg = rg + prg[c]; ba = ba + pba[c]; }
                 }
+                }
             }
             ring[j].rg = rg;
             ring[j].ba = ba;
@@ -202,6 +211,14 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
                 f32x2 org = { 0.0f, 0.0f }, oba = { 0.0f, 0.0f };
 #pragma unroll
                 for (int k0 = 0; k0 < NT; k0 += CH) {
+                    if constexpr (cvs::kContract) {
+#pragma unroll
+                        for (int c = 0; c < CH; c++) if (k0 + c < NT) {
+                            const Px &p = ring[(j + 1 + k0 + c) % NT];
+                            if (k0 + c == 0) { org = p.rg * w[0]; oba = p.ba * w[0]; }
+                            else { org = cvs::madd(p.rg, w[k0 + c], org); oba = cvs::madd(p.ba, w[k0 + c], oba); }
+                        }
+                    } else {
                     f32x2 qrg[CH], qba[CH];
 #pragma unroll
                     for (int c = 0; c < CH; c++) if (k0 + c < NT) {
@@ -214,6 +231,7 @@ __global__ __launch_bounds__(W) void k_blur(cvk_blur_params bp) {
                     for (int c = 0; c < CH; c++) if (k0 + c < NT) {
                         if (k0 + c == 0) { org = qrg[c]; oba = qba[c]; }
                         else { org = org + qrg[c]; oba = oba + qba[c]; }
+                    }
                     }
                 }
                 if constexpr (EPI) {

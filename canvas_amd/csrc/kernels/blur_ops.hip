@@ -30,16 +30,22 @@ int pick(const cvk_blur_params *bp, int cus, hipStream_t s) {
     case 13: return launch<13, W, 1>(*bp, cus, s);
     case 15: return launch<15, W, 1>(*bp, cus, s);
     }
+#ifndef CVS_CONTRACT
     if constexpr (W == 256) {
         if (!(bp->ntaps & 1)) return cvk_blur_even(bp, cus, s);         // blur_even_ops.hip
         if (bp->ntaps > 15) return cvk_blur_long(bp, cus, s);           // blur_long_ops.hip
     }
+#endif
     return (int)hipErrorInvalidValue;
 }
 
 }  // namespace
 
 extern "C" int cvk_blur_supported(int ntaps, int step) {
+#ifdef CVS_CONTRACT
+    // the contracted build has the instances of this file only (3..15 odd); longer and even lists go to the table kernels
+    if (step == 1) return ntaps >= 3 && ntaps <= 15 && (ntaps & 1);
+#endif
     if (step == 1) return (ntaps >= 3 && ntaps <= 31 && (ntaps & 1)) || (ntaps >= 4 && ntaps <= 16);
     if (step == 2) return ntaps == 3 || ntaps == 7 || ntaps == 11 || ntaps == 15;
     return 0;

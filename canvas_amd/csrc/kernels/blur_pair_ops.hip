@@ -134,10 +134,19 @@ __global__ __launch_bounds__(W) void k_blur_pair(cvk_blur_params bp) {
             f32x2 rg0, ba0, rg1, ba1;
 #pragma unroll
             for (int k = 0; k < NT; k++) {
+                if constexpr (cvs::kContract) {
+                    // the clang build's t += s * c: one fused multiply-add per tap, the first a plain product
+                    if (k == 0) { rg0 = f32x2{ v[0].x, v[0].y } * w[0]; ba0 = f32x2{ v[0].z, v[0].w } * w[0]; rg1 = f32x2{ v[1].x, v[1].y } * w[0]; ba1 = f32x2{ v[1].z, v[1].w } * w[0]; }
+                    else {
+                        rg0 = cvs::madd(f32x2{ v[k].x, v[k].y }, w[k], rg0); ba0 = cvs::madd(f32x2{ v[k].z, v[k].w }, w[k], ba0);
+                        rg1 = cvs::madd(f32x2{ v[k + 1].x, v[k + 1].y }, w[k], rg1); ba1 = cvs::madd(f32x2{ v[k + 1].z, v[k + 1].w }, w[k], ba1);
+                    }
+                } else {
                 const f32x2 p0 = f32x2{ v[k].x, v[k].y } * w[k], q0 = f32x2{ v[k].z, v[k].w } * w[k];
                 const f32x2 p1 = f32x2{ v[k + 1].x, v[k + 1].y } * w[k], q1 = f32x2{ v[k + 1].z, v[k + 1].w } * w[k];
                 if (k == 0) { rg0 = p0; ba0 = q0; rg1 = p1; ba1 = q1; }
                 else { rg0 = rg0 + p0; ba0 = ba0 + q0; rg1 = rg1 + p1; ba1 = ba1 + q1; }
+                }
             }
             ring[j][0].rg = rg0; ring[j][0].ba = ba0;
             ring[j][1].rg = rg1; ring[j][1].ba = ba1;
@@ -147,9 +156,14 @@ __global__ __launch_bounds__(W) void k_blur_pair(cvk_blur_params bp) {
 #pragma unroll
                 for (int k = 0; k < NT; k++) {
                     const Px &a = ring[(j + 1 + k) % NT][0], &b = ring[(j + 1 + k) % NT][1];
+                    if constexpr (cvs::kContract) {
+                        if (k == 0) { org0 = a.rg * w[0]; oba0 = a.ba * w[0]; org1 = b.rg * w[0]; oba1 = b.ba * w[0]; }
+                        else { org0 = cvs::madd(a.rg, w[k], org0); oba0 = cvs::madd(a.ba, w[k], oba0); org1 = cvs::madd(b.rg, w[k], org1); oba1 = cvs::madd(b.ba, w[k], oba1); }
+                    } else {
                     const f32x2 p0 = a.rg * w[k], q0 = a.ba * w[k], p1 = b.rg * w[k], q1 = b.ba * w[k];
                     if (k == 0) { org0 = p0; oba0 = q0; org1 = p1; oba1 = q1; }
                     else { org0 = org0 + p0; oba0 = oba0 + q0; org1 = org1 + p1; oba1 = oba1 + q1; }
+                    }
                 }
                 u32x4 codes;
                 if constexpr (NOV > 0) {

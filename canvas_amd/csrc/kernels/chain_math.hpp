@@ -113,12 +113,12 @@ __device__ __forceinline__ void div3_pair(f32x2 &n0, f32x2 &n1, f32x2 &n2, f32x2
 // video_mix.c:323-337 with mix_b == 1.0f (workspace.c:543)
 __device__ __forceinline__ px32x2 over_pair(px32x2 lo, px32x2 b) {
     const f32x2 alpha_b = b.a;                       // b.a * 1.0f
-    const f32x2 alpha_a = lo.a * (1.0f - b.a);
+    const f32x2 alpha_a = lo.a * (1.0f - b.a);       // (contracted build: fma(-b.a, 1.0f, 1.0f), the same value)
     const f32x2 a = alpha_a + alpha_b;
     px32x2 o;
-    o.r = lo.r * alpha_a + b.r * alpha_b;
-    o.g = lo.g * alpha_a + b.g * alpha_b;
-    o.b = lo.b * alpha_a + b.b * alpha_b;
+    o.r = madd(lo.r, alpha_a, b.r * alpha_b);
+    o.g = madd(lo.g, alpha_a, b.g * alpha_b);
+    o.b = madd(lo.b, alpha_a, b.b * alpha_b);
     o.a = a;
     if (!(a.x == 1.0f && a.y == 1.0f)) {             // x / 1.0f == x: nothing to do for unit alpha
         div3_pair(o.r, o.g, o.b, a);
@@ -134,9 +134,9 @@ __device__ __forceinline__ px32x2 cross_pair(px32x2 p, px32x2 q, float wa, float
     const f32x2 alpha_b = q.a * wb;
     const f32x2 a = alpha_a + alpha_b;
     px32x2 o;
-    o.r = p.r * alpha_a + q.r * alpha_b;
-    o.g = p.g * alpha_a + q.g * alpha_b;
-    o.b = p.b * alpha_a + q.b * alpha_b;
+    o.r = madd(p.r, alpha_a, q.r * alpha_b);
+    o.g = madd(p.g, alpha_a, q.g * alpha_b);
+    o.b = madd(p.b, alpha_a, q.b * alpha_b);
     o.a = a;
     if (!(a.x == 1.0f && a.y == 1.0f)) {
         div3_pair(o.r, o.g, o.b, a);
@@ -154,8 +154,8 @@ __device__ __forceinline__ px1 over_px(px1 lo, px1 up) {
     const float alpha_b = up.a;                      // up.a * 1.0f
     const float alpha_a = lo.a * (1.0f - up.a);
     const float a = alpha_a + alpha_b;
-    f32x2 nrg = lo.rg * alpha_a + up.rg * alpha_b;
-    float nb = lo.b * alpha_a + up.b * alpha_b;
+    f32x2 nrg = madd(lo.rg, alpha_a, up.rg * alpha_b);
+    float nb = madd(lo.b, alpha_a, up.b * alpha_b);
     if (a != 1.0f) {
         const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(nrg.x), __builtin_fabsf(nrg.y)), __builtin_fmaxf(__builtin_fabsf(nb), __builtin_fabsf(a)));
         const float lw = __builtin_fminf(__builtin_fminf(__builtin_fabsf(nrg.x), __builtin_fabsf(nrg.y)), __builtin_fminf(__builtin_fabsf(nb), __builtin_fabsf(a)));
@@ -246,14 +246,23 @@ __device__ __forceinline__ px32x2 over_pair_uniform(px32x2 lo, u32x4 up) {
     f32x2 r = { __builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y) };
     const f32x2 nd = -a;
     px32x2 o;
-    const f32x2 pr = lo.r * alpha_a, pg = lo.g * alpha_a, pb = lo.b * alpha_a;
+    f32x2 pr, pg, pb;
+    if constexpr (!kContract) { pr = lo.r * alpha_a; pg = lo.g * alpha_a; pb = lo.b * alpha_a; }
     f32x2 qr, qg, qb;
     halves_times(up, alpha_b, qr, qg, qb);
     const f32x2 r1 = fma2(nd, r, f32x2{ 1.0f, 1.0f });
-    o.r = pr + qr; o.g = pg + qg;
-    r = fma2(r1, r, r);
-    asm volatile("" : "+v"(r));                      // (keeps the chain up here: hipcc would sink it into the branch that uses it)
-    o.b = pb + qb;
+    if constexpr (kContract) {
+        // clang's build: fma(lower, alpha_a, upper * alpha_b) -- the upper product rounded, the lower one fused
+        o.r = fma2(lo.r, alpha_a, qr); o.g = fma2(lo.g, alpha_a, qg);
+        r = fma2(r1, r, r);
+        asm volatile("" : "+v"(r));
+        o.b = fma2(lo.b, alpha_a, qb);
+    } else {
+        o.r = pr + qr; o.g = pg + qg;
+        r = fma2(r1, r, r);
+        asm volatile("" : "+v"(r));                  // (keeps the chain up here: hipcc would sink it into the branch that uses it)
+        o.b = pb + qb;
+    }
     o.a = a;
     if (wave_any(!(a.x == 1.0f && a.y == 1.0f))) {
         // the quotients are formed without asking first (outside the band they are garbage, never a trap) and replaced on

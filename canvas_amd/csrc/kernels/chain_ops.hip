@@ -27,7 +27,8 @@
 #include "chain_kernel.hpp"
 #include <stdlib.h>
 
-// chain_deep_ops.hip: the same kernel for 5..8 layers (one launch of up to 48 frames; *taken = frames consumed)
+// chain_deep_ops.hip: the same kernel for 5..8 layers (one launch of up to 48 frames; *taken = frames consumed).  Plain build
+// only: in the contracted build (CVS_CONTRACT) stacks of more than four layers take the first-version kernel below.
 extern "C" int cvk_chain_deep(const cvk_chain_job *jobs, int njobs, int nlayers, const cvs::Mat *mat, const uint16_t *pre, const uint16_t *post,
                               unsigned grid, unsigned block, int lshift, int diag, uint64_t bytes_per_launch, void *stream, int *taken);
 
@@ -35,7 +36,11 @@ namespace {
 
 // Job records travel as kernel arguments (<= 4 KiB per launch).  The production kernel takes up to four layers, so
 // its records are compact (48 B) and a launch can carry 64 frames; the first version keeps the full 8-layer record.
+#ifdef CVS_CONTRACT
+constexpr int kJobsPerLaunchV0 = 32, kFusedLayers = 4;
+#else
 constexpr int kJobsPerLaunchV0 = 32, kFusedLayers = 8;
+#endif
 typedef BatchT<4> Batch;
 // bytes (read + written) one launch of the production kernel moves before the host starts the next one:
 // eight 4K two-layer frames.  See "SHORT LAUNCHES" above; tools/chainlab.hip and profiles/r02/launch_split.txt.
@@ -139,10 +144,13 @@ int chain_dispatch(const cvk_chain_job *jobs, int njobs, int uniform_layers, con
     int first = 0;
     while (first < njobs) {
         int n = 0, rc;
+#ifndef CVS_CONTRACT
         if (fused_kernel && uniform_layers > 4) {
             const int diag = t.variant == 10 ? DIAG_MEMORY_ONLY : t.variant == 12 ? DIAG_COMPUTE_ONLY : DIAG_NONE;
             rc = cvk_chain_deep(jobs + first, njobs - first, uniform_layers, &mat, pre, post, grid, t.block, t.lshift, diag, t.bytes_per_launch, stream, &n);
-        } else if (fused_kernel) {
+        } else
+#endif
+        if (fused_kernel) {
             Batch b;
             n = fill_batch(b, jobs + first, njobs - first, uniform_layers, t.bytes_per_launch);
 #ifdef CVS_DIAG

@@ -28,7 +28,8 @@ using namespace cvs;
 namespace {
 
 // ---------------------------------------------------------------- half_lookup on a flat array (half.c:82-85)
-
+// (no arithmetic: exists once, in the plain build of this file)
+#ifndef CVS_CONTRACT
 __global__ __launch_bounds__(kWG) void k_lookup(const uint16_t *__restrict__ table, uint16_t *__restrict__ out,
                                                 const uint16_t *__restrict__ in, size_t count, int vec_ok) {
     __shared__ uint16_t lut[kLutHalfs];
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(kWG) void k_lookup(const uint16_t *__restrict__ tab
     }
 }
 
+#endif
 // ---------------------------------------------------------------- colour matrix on a window (dst may be src)
 
 template <bool PRE, bool POST>
@@ -103,12 +105,14 @@ __global__ __launch_bounds__(kWG) void k_color_flat(uint16_t *__restrict__ dst, 
 
 }  // namespace
 
+#ifndef CVS_CONTRACT
 extern "C" int cvk_half_lookup(const uint16_t *table, uint16_t *out, const uint16_t *in, size_t count, int cus, void *stream) {
     if (!count) return 0;
     int vec_ok = ((((uintptr_t)out | (uintptr_t)in) & 15u) == 0) ? 1 : 0;
     hipLaunchKernelGGL(k_lookup, dim3(persistent_grid(cus, count / 8 + 1)), dim3(kWG), 0, (hipStream_t)stream, table, out, in, count, vec_ok);
     return (int)hipGetLastError();
 }
+#endif
 
 extern "C" int cvk_color_matrix(cvk_view dst, cvk_view src, cvk_rect r, const float m[9], const uint16_t *pre, const uint16_t *post,
                                 int cus, void *stream) {

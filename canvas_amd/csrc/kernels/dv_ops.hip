@@ -37,13 +37,13 @@ __global__ __launch_bounds__(kBlock) void k_dv_reconstruct(cvk_view frame, cvk_r
     float cb = 0.0f, cr = 0.0f;
     for (int xs = lo; xs <= hi; xs++) {
         const float c = tri.coeff[x - xs * kSub + tri.center];
-        cb = cb + (((float)cbrow[xs] - 128.0f) / 224.0f) * c;
-        cr = cr + (((float)crrow[xs] - 128.0f) / 224.0f) * c;
+        cb = cvs::madd(((float)cbrow[xs] - 128.0f) / 224.0f, c, cb);
+        cr = cvs::madd(((float)crrow[xs] - 128.0f) / 224.0f, c, cr);
     }
     const float yy = ((float)pl.y[(size_t)row * pl.sy + x] - 16.0f) / 219.0f;
-    const float r = yy * 1.0f + cb * 0.0f + cr * 1.5748f;
-    const float g = yy * 1.0f + cb * -0.187324f + cr * -0.468124f;
-    const float b = yy * 1.0f + cb * 1.8556f + cr * 0.0f;
+    const float r = cvs::madd(cr, 1.5748f, cvs::madd(yy, 1.0f, cb * 0.0f));
+    const float g = cvs::madd(cr, -0.468124f, cvs::madd(yy, 1.0f, cb * -0.187324f));
+    const float b = cvs::madd(cr, 0.0f, cvs::madd(yy, 1.0f, cb * 1.8556f));
     const uint32_t rg = cvs::f2h_rz2(r, g), ba = cvs::f2h_rz2(b, 1.0f);
     *px16(frame, x, y) = make_uint2((uint32_t)lut[rg & 0xFFFFu] | ((uint32_t)lut[rg >> 16] << 16),
                                     (uint32_t)lut[ba & 0xFFFFu] | ((uint32_t)lut[ba >> 16] << 16));
@@ -54,9 +54,9 @@ struct Ypbpr { float y, pb, pr; };
 __device__ __forceinline__ Ypbpr encode(uint2 p, const uint16_t *lut) {
     const float r = cvs::h2f(lut[p.x & 0xFFFFu]), g = cvs::h2f(lut[p.x >> 16]), b = cvs::h2f(lut[p.y & 0xFFFFu]);
     Ypbpr o;
-    o.y = r * 0.2126f + g * 0.7152f + b * 0.0722f;
-    o.pb = r * -0.114572f + g * -0.385428f + b * 0.5f;
-    o.pr = r * 0.5f + g * -0.454153f + b * -0.045847f;
+    o.y = cvs::madd(b, 0.0722f, cvs::madd(r, 0.2126f, g * 0.7152f));
+    o.pb = cvs::madd(b, 0.5f, cvs::madd(r, -0.114572f, g * -0.385428f));
+    o.pr = cvs::madd(b, -0.045847f, cvs::madd(r, 0.5f, g * -0.454153f));
     return o;
 }
 
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void k_dv_luma(cvk_dv_planes pl, cvk_view f
     const int x = w.x0 + (int)(blockIdx.x * kBlock + threadIdx.x), y = w.y0 + (int)blockIdx.y;
     if (x > w.x1) return;
     const Ypbpr e = encode(*px16(frame, x, y), lut);
-    pl.y[(size_t)(y - kOffY) * pl.sy + x] = low_byte(e.y * 219.0f + 16.0f);
+    pl.y[(size_t)(y - kOffY) * pl.sy + x] = low_byte(cvs::madd(e.y, 219.0f, 16.0f));
 }
 
 __global__ __launch_bounds__(kBlock) void k_dv_chroma(cvk_dv_planes pl, cvk_view frame, cvk_rect w, cvk_dv_taps tri, const uint16_t *__restrict__ lut) {
@@ -79,12 +79,12 @@ __global__ __launch_bounds__(kBlock) void k_dv_chroma(cvk_dv_planes pl, cvk_view
     for (int sx = lo; sx <= hi; sx++) {
         const Ypbpr e = encode(*px16(frame, sx, y), lut);
         const float c = tri.coeff[sx - tx * kSub + tri.center];
-        cb = cb + e.pb * c;
-        cr = cr + e.pr * c;
+        cb = cvs::madd(e.pb, c, cb);
+        cr = cvs::madd(e.pr, c, cr);
     }
     const int row = y - kOffY;
-    pl.cb[(size_t)row * pl.scb + tx] = low_byte(cb * 224.0f + 128.0f);
-    pl.cr[(size_t)row * pl.scr + tx] = low_byte(cr * 224.0f + 128.0f);
+    pl.cb[(size_t)row * pl.scb + tx] = low_byte(cvs::madd(cb, 224.0f, 128.0f));
+    pl.cr[(size_t)row * pl.scr + tx] = low_byte(cvs::madd(cr, 224.0f, 128.0f));
 }
 
 __global__ __launch_bounds__(kBlock) void k_dv_encode(cvk_view frame, cvk_rect w, const uint16_t *__restrict__ lut) {

@@ -53,10 +53,10 @@ __global__ __launch_bounds__(kBlock) void k_fir(cvk_fir_params fp) {
         const int s = src[k];
         const float w = c[k];
         const float4 v = fp.axis == 0 ? px_in(fp.source, fp.in_half != 0, other, s) : px_in(fp.source, fp.in_half != 0, s, other);
-        r = r + v.x * w;
-        g = g + v.y * w;
-        b = b + v.z * w;
-        a = a + v.w * w;
+        r = cvs::madd(v.x, w, r);        // t += s * coeff (video_scale.c:82-85)
+        g = cvs::madd(v.y, w, g);
+        b = cvs::madd(v.z, w, b);
+        a = cvs::madd(v.w, w, a);
     }
     const int ox = fp.axis == 0 ? other : line, oy = fp.axis == 0 ? line : other;
     if (fp.out_half) {       // the consumer pulls f16: truncate here (main.c:43-71) instead of in a pass of its own
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(kTX * kRows) void k_fir2d(cvk_fir2d_params fp) {
             for (int k = 0; k < MAXT; k++) v[k] = row[sidx[k]];
 #pragma unroll
             for (int k = 0; k < MAXT; k++) {
-                const cvs::f32x2 nrg = rg + cvs::f32x2{ v[k].x, v[k].y } * wt[k];
-                const cvs::f32x2 nba = ba + cvs::f32x2{ v[k].z, v[k].w } * wt[k];
+                const cvs::f32x2 nrg = cvs::madd(cvs::f32x2{ v[k].x, v[k].y }, wt[k], rg);
+                const cvs::f32x2 nba = cvs::madd(cvs::f32x2{ v[k].z, v[k].w }, wt[k], ba);
                 const bool live = k < n;
                 rg = live ? nrg : rg;
                 ba = live ? nba : ba;
@@ -190,8 +190,8 @@ __global__ __launch_bounds__(kTX * kRows) void k_fir2d(cvk_fir2d_params fp) {
 #pragma unroll
             for (int k = 0; k < MAXT; k++) {
                 const float c = k < n ? w[k] : 0.0f;
-                const cvs::f32x2 nrg = rg + cvs::f32x2{ v[k].x, v[k].y } * c;
-                const cvs::f32x2 nba = ba + cvs::f32x2{ v[k].z, v[k].w } * c;
+                const cvs::f32x2 nrg = cvs::madd(cvs::f32x2{ v[k].x, v[k].y }, c, rg);
+                const cvs::f32x2 nba = cvs::madd(cvs::f32x2{ v[k].z, v[k].w }, c, ba);
                 const bool live = k < n;
                 rg = live ? nrg : rg;
                 ba = live ? nba : ba;

@@ -9,7 +9,7 @@
 //   widen frame  : 8 + 16 B per pixel                       (A4, main.c:115-139)
 //   narrow frame : 16 + 8 B per pixel                       (A4, main.c:43-71)
 //   fill         : 8 / 16 B written per pixel               (A16, SolidColorVideoSource.c:52-101)
-//   gain/offset  : 8 + 8 B per pixel                        (A15, video_filter.c:34-39)
+//   (gain/offset, the one kernel of this family with arithmetic, lives in gain_ops.hip: built in both flavours)
 #include "kernels.h"
 #include "pixel_math.hpp"
 
@@ -152,16 +152,6 @@ __global__ __launch_bounds__(kBlock) void k_fill32(cvk_view out, cvk_rect r, flo
     *at<float4>(out, x, y) = c;
 }
 
-// video_filter.c:34-39: rgb * gain + offset, alpha untouched.  mul then add, separately rounded.
-__global__ __launch_bounds__(kBlock) void k_gain_offset(cvk_view out, cvk_view in, cvk_rect r, float gain, float offset) {
-    CVK_PIXEL_XY(r)
-    px32 v = widen(*at<const uint2>(in, x, y));
-    v.r = v.r * gain + offset;
-    v.g = v.g * gain + offset;
-    v.b = v.b * gain + offset;
-    *at<uint2>(out, x, y) = narrow(v);
-}
-
 __global__ __launch_bounds__(kBlock) void k_zero32(float4 *p, size_t n) {
     size_t stride = (size_t)gridDim.x * kBlock;
     for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -242,11 +232,6 @@ extern "C" int cvk_fill_f16(cvk_view out, cvk_rect r, const float c[4], void *st
 extern "C" int cvk_fill_f32(cvk_view out, cvk_rect r, const float c[4], void *stream) {
     if (rect_empty(r)) return 0;
     LAUNCH(k_fill32, rect_grid(r), out, r, make_float4(c[0], c[1], c[2], c[3]))
-}
-
-extern "C" int cvk_gain_offset_f16(cvk_view out, cvk_view in, cvk_rect r, float gain, float offset, void *stream) {
-    if (rect_empty(r)) return 0;
-    LAUNCH(k_gain_offset, rect_grid(r), out, in, r, gain, offset)
 }
 
 extern "C" int cvk_zero_f32(cvk_view v, void *stream) {

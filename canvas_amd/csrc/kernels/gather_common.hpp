@@ -27,9 +27,8 @@ __device__ __forceinline__ Px vsum(const Px (&win)[W], const float (&w)[W]) {
 #pragma unroll
     for (int k = 1; k < N; k++) {
         const f32x2 wk = { w[k], w[k] };
-        const f32x2 plo = win[k].lo * wk, phi = win[k].hi * wk;
-        t.lo = t.lo + plo;
-        t.hi = t.hi + phi;
+        t.lo = cvs::madd(win[k].lo, wk, t.lo);          // t += s * coeff: two roundings, or one in the contracted build
+        t.hi = cvs::madd(win[k].hi, wk, t.hi);
     }
     return t;
 }
@@ -58,9 +57,8 @@ __device__ __forceinline__ Px vsum_any(const Px (&win)[W], const float (&w)[W], 
         const bool has = k < n;                          // uniform
         const f32x2 wk = { w[k], w[k] };
         const f32x2 xlo = { has ? win[k].lo.x : 0.0f, has ? win[k].lo.y : 0.0f }, xhi = { has ? win[k].hi.x : 0.0f, has ? win[k].hi.y : 0.0f };
-        const f32x2 plo = xlo * wk, phi = xhi * wk;
-        t.lo = t.lo + plo;
-        t.hi = t.hi + phi;
+        t.lo = cvs::madd(xlo, wk, t.lo);
+        t.hi = cvs::madd(xhi, wk, t.hi);
     }
     return t;
 }

@@ -20,6 +20,37 @@
 #define CVS_DIAG_ENV(name) ((const char *)0)
 #endif
 
+/* Arithmetic flavours (pixel_math.hpp): the translation units that hold f32 arithmetic are compiled twice, plain and with
+ * -DCVS_CONTRACT (a * b + c inside one expression of the reference's C becomes ONE fused multiply-add, as the reference's
+ * preferred clang build computes it).  The contracted objects export the same launchers under *_fma names; the host picks per
+ * call (internal.h CVK()).  Units without arithmetic (conversions, copies, table look-ups, the display edge) exist once. */
+#ifdef CVS_CONTRACT
+#define cvk_gain_offset_f16          cvk_gain_offset_f16_fma
+#define cvk_mix                      cvk_mix_fma
+#define cvk_color_matrix             cvk_color_matrix_fma
+#define cvk_chain_color_over         cvk_chain_color_over_fma
+#define cvk_chain_cross              cvk_chain_cross_fma
+#define cvk_chain_count_reset        cvk_chain_count_reset_fma
+#define cvk_chain_count              cvk_chain_count_fma
+#define cvk_fir_gather               cvk_fir_gather_fma
+#define cvk_fir2d_lds_bytes          cvk_fir2d_lds_bytes_fma
+#define cvk_fir2d                    cvk_fir2d_fma
+#define cvk_fir_vh_supported         cvk_fir_vh_supported_fma
+#define cvk_fir_vh                   cvk_fir_vh_fma
+#define cvk_blur_supported           cvk_blur_supported_fma
+#define cvk_blur_takes_pairs         cvk_blur_takes_pairs_fma
+#define cvk_blur                     cvk_blur_fma
+#define cvk_blur_pair_supported      cvk_blur_pair_supported_fma
+#define cvk_blur_pair                cvk_blur_pair_fma
+#define cvk_blur_halve_pair_supported cvk_blur_halve_pair_supported_fma
+#define cvk_blur_halve_pair          cvk_blur_halve_pair_fma
+#define cvk_blur_halve_supported     cvk_blur_halve_supported_fma
+#define cvk_blur_halve_takes_pairs   cvk_blur_halve_takes_pairs_fma
+#define cvk_blur_halve               cvk_blur_halve_fma
+#define cvk_dv_reconstruct           cvk_dv_reconstruct_fma
+#define cvk_dv_subsample             cvk_dv_subsample_fma
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -119,14 +150,6 @@ typedef struct {
     int wide_foot;             /* widest source footprint of any run of 128 lines starting at a multiple of 128 */
     int max_active;            /* as the vertical axis: the longest run of lines i..j such that line j starts at or before line i's last tap */
     int streamable;            /* every list is consecutive source lines, first and last taps never decrease from line to line */
-    /* the table turned round for the channel-pair sweep (sweep_ops.hip), present when streamable and max_active <= 32:
-     * one record of (2 * nacc + 4) dwords per SOURCE line rec_s0 .. rec_s0 + rec_n - 1.  A target line's accumulator slot is
-     * its index & (nacc - 1).  [0] slots that take this source line, [1] slots for which it is the last tap, [2] index of
-     * the first target line that ends here, [3] 0, [4 + 2 * slot] and [5 + 2 * slot] the slot's weight for this source line,
-     * twice (0 for the slots that do not take it).  One spare all-zero record follows the last. */
-    const uint32_t *rec;
-    int rec_s0, rec_n, nacc;
-    int rec_zero_weight;       /* some tap of the table has weight +-0 (the sweep tells "no tap" by weight 0: not for this table) */
     /* the table by TARGET line, one record of CVK_FIR_LREC dwords per line (present when streamable and no list is longer
      * than CVK_FIR_LREC - 2): [0] tap count, [1] first source line (INT_MIN for a line without taps), [2 + k] weight of
      * tap k; unused entries 0.  One spare all-zero record (count 0) follows the last.  sweep_vh_ops.hip reads one per line. */
@@ -145,10 +168,7 @@ typedef struct {
 /* the same tables, swept down the frame (resample_ops.hip): fp->max_sw = h.wide_foot; needs v.streamable */
 int cvk_fir_stream_supported(int h_taps, int v_active);
 int cvk_fir_stream(const cvk_fir2d_params *fp, int h_taps, int v_active, int cus, void *stream);
-/* the same tables again, one lane per target column and channel pair (sweep_ops.hip): needs h tap lists <= 32, v.rec */
-int cvk_fir_lanes_supported(const cvk_fir2d_params *fp);
-int cvk_fir_lanes(const cvk_fir2d_params *fp, int cus, void *stream);
-/* the same tables once more, horizontal pass first, as a gather per target line (sweep_hv_ops.hip): needs v.streamable and
+/* the same tables, horizontal pass first, as a gather per target line (sweep_hv_ops.hip): needs v.streamable and
  * v.lrec (vertical lists <= CVK_FIR_LREC - 2), horizontal lists <= 24; first choice for these tables */
 int cvk_fir_hv_supported(const cvk_fir2d_params *fp);
 int cvk_fir_hv(const cvk_fir2d_params *fp, int cus, void *stream);
@@ -230,6 +250,34 @@ typedef struct { uint8_t *y, *cb, *cr; int sy, scb, scr; } cvk_dv_planes;
 typedef struct { float coeff[16]; int width, center; } cvk_dv_taps;
 int cvk_dv_reconstruct(cvk_view frame, cvk_rect cur, const cvk_dv_planes *pl, const cvk_dv_taps *tri, const uint16_t *lut, void *stream);
 int cvk_dv_subsample(const cvk_dv_planes *pl, cvk_view frame, cvk_rect w, const cvk_dv_taps *tri, const uint16_t *lut, int encode_in_place, void *stream);
+
+/* the contracted twins, as the host sees them (same signatures; built from the same sources with -DCVS_CONTRACT) */
+#ifndef CVS_CONTRACT
+int cvk_gain_offset_f16_fma(cvk_view out, cvk_view in, cvk_rect r, float gain, float offset, void *stream);
+int cvk_mix_fma(const cvk_mix_params *mp, void *stream);
+int cvk_color_matrix_fma(cvk_view dst, cvk_view src, cvk_rect r, const float m[9], const uint16_t *pre_lut, const uint16_t *post_lut, int cus, void *stream);
+int cvk_chain_color_over_fma(const cvk_chain_job *jobs, int njobs, int uniform_layers, const float *m, const uint16_t *pre_lut, const uint16_t *post_lut, int cus, void *stream);
+int cvk_chain_cross_fma(const cvk_chain_job *jobs, int njobs, float wa, float wb, int cus, void *stream);
+void cvk_chain_count_reset_fma(void);
+int cvk_chain_count_fma(void);
+int cvk_fir_gather_fma(const cvk_fir_params *fp, void *stream);
+size_t cvk_fir2d_lds_bytes_fma(const cvk_fir2d_params *fp);
+int cvk_fir2d_fma(const cvk_fir2d_params *fp, void *stream);
+int cvk_fir_vh_supported_fma(const cvk_fir2d_params *fp);
+int cvk_fir_vh_fma(const cvk_fir2d_params *fp, int line0, int cus, void *stream);
+int cvk_blur_supported_fma(int ntaps, int step);
+int cvk_blur_takes_pairs_fma(const cvk_blur_params *bp);
+int cvk_blur_fma(const cvk_blur_params *bp, int cus, void *stream);
+int cvk_blur_pair_supported_fma(const cvk_blur_params *bp);
+int cvk_blur_pair_fma(const cvk_blur_params *bp, int cus, void *stream);
+int cvk_blur_halve_pair_supported_fma(const cvk_blur_halve_params *bp);
+int cvk_blur_halve_pair_fma(const cvk_blur_halve_params *bp, int cus, void *stream);
+int cvk_blur_halve_supported_fma(int ntaps1, int ntaps2);
+int cvk_blur_halve_takes_pairs_fma(const cvk_blur_halve_params *bp);
+int cvk_blur_halve_fma(const cvk_blur_halve_params *bp, int cus, void *stream);
+int cvk_dv_reconstruct_fma(cvk_view frame, cvk_rect cur, const cvk_dv_planes *pl, const cvk_dv_taps *tri, const uint16_t *lut, void *stream);
+int cvk_dv_subsample_fma(const cvk_dv_planes *pl, cvk_view frame, cvk_rect w, const cvk_dv_taps *tri, const uint16_t *lut, int encode_in_place, void *stream);
+#endif
 
 #ifdef __cplusplus
 }

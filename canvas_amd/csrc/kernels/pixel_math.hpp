@@ -7,8 +7,17 @@
 //                                   `base + (mantissa >> shift)` computes; the one difference is
 //                                   finite overflow: RTZ saturates at 65504 where the table gives
 //                                   +-Inf for |x| >= 65536 (genhalf.py:36-37), fixed below.
-// All f32 arithmetic is written as separate mul / add / div (the translation unit is built with
-// -ffp-contract=off) to match the reference's gcc -std=c99 build, which does not fuse.
+// Arithmetic flavours.  The reference has two builds (SConstruct:46-48,75-83): gcc -std=c99 rounds every multiply and every
+// add on its own; clang -- preferred when installed -- contracts a * b + c INSIDE ONE EXPRESSION into a fused multiply-add
+// (-ffp-contract=on).  Every translation unit here is built with -ffp-contract=off, so nothing fuses by accident; the
+// places where the reference's C has a product and a sum in one expression go through madd() / nmadd() below, and the units
+// that hold arithmetic are compiled twice: plain (kContract == false: bit-equal to the reference's gcc build) and
+// with -DCVS_CONTRACT (kContract == true: bit-equal to its clang build; launchers renamed *_fma in
+// kernels.h).  Which product of an expression clang fuses was read off its IR (llvm.fmuladd operands) for the same C expressions:
+//   a*b + c*d        -> fma(a, b, c*d)                 (left product fused, right one rounded)
+//   a*b + c*d + e*f  -> fma(e, f, fma(a, b, c*d))
+//   t += s*c         -> fma(s, c, t)
+//   1 - a*b          -> fma(-a, b, 1)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -16,6 +25,29 @@
 namespace cvs {
 
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#ifdef CVS_CONTRACT
+constexpr bool kContract = true;
+#else
+constexpr bool kContract = false;
+#endif
+
+// a * b + c written in one expression by the reference: rounded twice (gcc build) or once (clang build)
+__device__ __forceinline__ float madd(float a, float b, float c) {
+    if constexpr (kContract) return __builtin_fmaf(a, b, c); else return a * b + c;
+}
+__device__ __forceinline__ f32x2 madd(f32x2 a, f32x2 b, f32x2 c) {
+    if constexpr (kContract) return __builtin_elementwise_fma(a, b, c); else return a * b + c;
+}
+__device__ __forceinline__ f32x2 madd(f32x2 a, float b, f32x2 c) { return madd(a, f32x2{ b, b }, c); }
+// c - a * b in one expression
+__device__ __forceinline__ float nmadd(float a, float b, float c) {
+    if constexpr (kContract) return __builtin_fmaf(-a, b, c); else return c - a * b;
+}
+__device__ __forceinline__ f32x2 nmadd(f32x2 a, f32x2 b, f32x2 c) {
+    if constexpr (kContract) return __builtin_elementwise_fma(-a, b, c); else return c - a * b;
+}
 
 __device__ __forceinline__ float h2f(uint32_t code) {
     return (float)__builtin_bit_cast(_Float16, (uint16_t)code);
@@ -60,9 +92,9 @@ __device__ __forceinline__ uint2 narrow(px32 v) {
 template <class M>
 __device__ __forceinline__ px32 mat3(px32 v, const M &mat) {
     px32 o;
-    o.r = v.r * mat.m0 + v.g * mat.m3 + v.b * mat.m6;
-    o.g = v.r * mat.m1 + v.g * mat.m4 + v.b * mat.m7;
-    o.b = v.r * mat.m2 + v.g * mat.m5 + v.b * mat.m8;
+    o.r = madd(v.b, mat.m6, madd(v.r, mat.m0, v.g * mat.m3));
+    o.g = madd(v.b, mat.m7, madd(v.r, mat.m1, v.g * mat.m4));
+    o.b = madd(v.b, mat.m8, madd(v.r, mat.m2, v.g * mat.m5));
     o.a = v.a;
     return o;
 }
@@ -70,13 +102,13 @@ __device__ __forceinline__ px32 mat3(px32 v, const M &mat) {
 // video_mix.c:323-337
 __device__ __forceinline__ px32 blend_over(px32 lo, px32 b, float mix_b) {
     float alpha_b = b.a * mix_b;
-    float alpha_a = lo.a * (1.0f - b.a * mix_b);
+    float alpha_a = lo.a * nmadd(b.a, mix_b, 1.0f);
     float a = alpha_a + alpha_b;
     px32 o = { 0.0f, 0.0f, 0.0f, 0.0f };
     if (a != 0.0f) {
-        o.r = (lo.r * alpha_a + b.r * alpha_b) / a;
-        o.g = (lo.g * alpha_a + b.g * alpha_b) / a;
-        o.b = (lo.b * alpha_a + b.b * alpha_b) / a;
+        o.r = madd(lo.r, alpha_a, b.r * alpha_b) / a;
+        o.g = madd(lo.g, alpha_a, b.g * alpha_b) / a;
+        o.b = madd(lo.b, alpha_a, b.b * alpha_b) / a;
         o.a = a;
     }
     return o;
@@ -89,9 +121,9 @@ __device__ __forceinline__ px32 blend_cross(px32 a, px32 b, float mix_a, float m
     float oa = alpha_a + alpha_b;
     px32 o = { 0.0f, 0.0f, 0.0f, 0.0f };
     if (oa != 0.0f) {
-        o.r = (a.r * alpha_a + b.r * alpha_b) / oa;
-        o.g = (a.g * alpha_a + b.g * alpha_b) / oa;
-        o.b = (a.b * alpha_a + b.b * alpha_b) / oa;
+        o.r = madd(a.r, alpha_a, b.r * alpha_b) / oa;
+        o.g = madd(a.g, alpha_a, b.g * alpha_b) / oa;
+        o.b = madd(a.b, alpha_a, b.b * alpha_b) / oa;
         o.a = oa;
     }
     return o;
@@ -105,8 +137,6 @@ __device__ __forceinline__ px32 blend_cross(px32 a, px32 b, float mix_a, float m
 // v_pk_add_f32 (2 f32 results per instruction, full rate on CDNA3/4): same operations, same
 // rounding, half the VALU issue slots.  Conversions, gathers and the divides stay per channel.
 namespace cvs {
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct px32x2 { f32x2 r, g, b, a; };   // .x = first pixel of the pair, .y = second
 
@@ -134,9 +164,9 @@ __device__ __forceinline__ uint4 narrow2(px32x2 v) {
 template <class M>
 __device__ __forceinline__ px32x2 mat3x2(px32x2 v, const M &mat) {
     px32x2 o;
-    o.r = v.r * mat.m0 + v.g * mat.m3 + v.b * mat.m6;
-    o.g = v.r * mat.m1 + v.g * mat.m4 + v.b * mat.m7;
-    o.b = v.r * mat.m2 + v.g * mat.m5 + v.b * mat.m8;
+    o.r = madd(v.b, mat.m6, madd(v.r, mat.m0, v.g * mat.m3));
+    o.g = madd(v.b, mat.m7, madd(v.r, mat.m1, v.g * mat.m4));
+    o.b = madd(v.b, mat.m8, madd(v.r, mat.m2, v.g * mat.m5));
     o.a = v.a;
     return o;
 }
@@ -146,9 +176,9 @@ __device__ __forceinline__ px32x2 blend_over2_mix1(px32x2 lo, px32x2 b) {
     f32x2 alpha_b = b.a;
     f32x2 alpha_a = lo.a * (1.0f - b.a);
     f32x2 a = alpha_a + alpha_b;
-    f32x2 nr = lo.r * alpha_a + b.r * alpha_b;
-    f32x2 ng = lo.g * alpha_a + b.g * alpha_b;
-    f32x2 nb = lo.b * alpha_a + b.b * alpha_b;
+    f32x2 nr = madd(lo.r, alpha_a, b.r * alpha_b);
+    f32x2 ng = madd(lo.g, alpha_a, b.g * alpha_b);
+    f32x2 nb = madd(lo.b, alpha_a, b.b * alpha_b);
     px32x2 o;
     // IEEE divides, per pixel; a == 0 selects the zero pixel afterwards (x/0 is never used)
     o.r = f32x2{ nr.x / a.x, nr.y / a.y };

@@ -209,9 +209,8 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
 #pragma unroll
                 for (int k = 1; k < MAXTH; k++) {
                     const f32x2 wk = { wt[p][k], wt[p][k] };
-                    const f32x2 plo = f32x2{ t[p][k].x, t[p][k].y } * wk, phi = f32x2{ t[p][k].z, t[p][k].w } * wk;
-                    hlo[p] = hlo[p] + plo;
-                    hhi[p] = hhi[p] + phi;
+                    hlo[p] = cvs::madd(f32x2{ t[p][k].x, t[p][k].y }, wk, hlo[p]);          // t += s * coeff (video_scale.c:82-85)
+                    hhi[p] = cvs::madd(f32x2{ t[p][k].z, t[p][k].w }, wk, hhi[p]);
                 }
             }
             __builtin_amdgcn_wave_barrier();

@@ -22,8 +22,24 @@ static PyObject *frame16_capsule, *frame32_capsule;
 static void frame16_as_source16(py_frame16 *self, int frame_index, rgba_frame_f16 *out) { video_copy_frame_f16(out, &self->frame); }
 static void frame32_as_source32(py_frame32 *self, int frame_index, rgba_frame_f32 *out) { video_copy_frame_alpha_f32(out, &self->frame, 1.0f); }
 
-static video_frame_source_funcs frame16_funcs = { .flags = 0, .get_frame = (video_get_frame_func)frame16_as_source16 };
-static video_frame_source_funcs frame32_funcs = { .flags = 0, .get_frame_32 = (video_get_frame_32_func)frame32_as_source32 };
+/* Slot 3 (the device slot) of a result frame: its host pixels re-windowed and uploaded -- video_get_frame_dev's own path for a
+ * host-only source, reached through a vtable that has only the host slot.  It exists so that frame.get_frame_f32(...,
+ * force_gl=True) yields pixels, as the reference's test expects (tests/process/video/SolidColorVideoSource.py:27-29), while
+ * video_get_frame_f16_gl / _f32_gl keep the reference's rule for sources without slot 3 (an empty window, main.c:99-102). */
+static video_frame_source_funcs frame16_host_funcs = { .flags = 0, .get_frame = (video_get_frame_func)frame16_as_source16 };
+static video_frame_source_funcs frame32_host_funcs = { .flags = 0, .get_frame_32 = (video_get_frame_32_func)frame32_as_source32 };
+static void frame16_as_source_dev(py_frame16 *self, int frame_index, rgba_frame_dev *out) {
+    video_source host = { (void *)self, &frame16_host_funcs };
+    video_get_frame_dev(&host, frame_index, out);
+}
+static void frame32_as_source_dev(py_frame32 *self, int frame_index, rgba_frame_dev *out) {
+    video_source host = { (void *)self, &frame32_host_funcs };
+    video_get_frame_dev(&host, frame_index, out);
+}
+static video_frame_source_funcs frame16_funcs = { .flags = VIDEO_SOURCE_FLAG_DEVICE, .get_frame = (video_get_frame_func)frame16_as_source16,
+                                                  .get_frame_dev = (video_get_frame_dev_func)frame16_as_source_dev };
+static video_frame_source_funcs frame32_funcs = { .flags = VIDEO_SOURCE_FLAG_DEVICE, .get_frame_32 = (video_get_frame_32_func)frame32_as_source32,
+                                                  .get_frame_dev = (video_get_frame_dev_func)frame32_as_source_dev };
 
 static void frame16_dealloc(py_frame16 *self) { PyMem_Free(self->frame.data); Py_TYPE(self)->tp_free((PyObject *)self); }
 static void frame32_dealloc(py_frame32 *self) { PyMem_Free(self->frame.data); Py_TYPE(self)->tp_free((PyObject *)self); }

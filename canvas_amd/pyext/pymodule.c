@@ -346,6 +346,19 @@ static PyObject *mod_check_context(PyObject *self, PyObject *args) { return PyBo
 static PyObject *mod_last_error(PyObject *self, PyObject *args) { return PyUnicode_FromString(cvs_last_error()); }
 static PyObject *mod_device_name(PyObject *self, PyObject *args) { return PyUnicode_FromString(cvs_device_name()); }
 
+/* set_arithmetic("separate" | "contracted") -> previous; get_arithmetic(): which of the reference's two builds the pixels
+ * follow -- gcc -std=c99 (every multiply and add rounded on its own; the default) or clang (a * b + c inside an expression
+ * fused, SConstruct:46-48,75-83).  Added beside the reference's surface (canvas_hip.h cvs_set_arithmetic). */
+static PyObject *arith_name(int mode) { return PyUnicode_FromString(mode == CVS_ARITH_CONTRACTED ? "contracted" : "separate"); }
+static PyObject *mod_get_arithmetic(PyObject *self, PyObject *args) { return arith_name(cvs_get_arithmetic()); }
+static PyObject *mod_set_arithmetic(PyObject *self, PyObject *args) {
+    const char *name;
+    if (!PyArg_ParseTuple(args, "s", &name)) return NULL;
+    int mode = strcmp(name, "separate") == 0 ? CVS_ARITH_SEPARATE : strcmp(name, "contracted") == 0 ? CVS_ARITH_CONTRACTED : -1;
+    if (mode < 0) { PyErr_SetString(PyExc_ValueError, "arithmetic must be 'separate' or 'contracted'"); return NULL; }
+    return arith_name(cvs_set_arithmetic(mode));
+}
+
 static PyMethodDef module_methods[] = {
     { "get_frame_time", mod_get_frame_time, METH_VARARGS, "get_frame_time(rate, frame) -> time in ns" },
     { "get_time_frame", mod_get_time_frame, METH_VARARGS, "get_time_frame(rate, time_ns) -> frame" },
@@ -355,6 +368,8 @@ static PyMethodDef module_methods[] = {
     { "create_offscreen_gl_context", mod_gl_stub, METH_VARARGS, "No-op: there is no GL path." },
     { "set_current_gl_context", mod_gl_stub, METH_VARARGS, "No-op: there is no GL path." },
     { "check_context_supported", mod_check_context, METH_VARARGS, "True when a HIP device is available." },
+    { "set_arithmetic", mod_set_arithmetic, METH_VARARGS, "set_arithmetic('separate' | 'contracted') -> previous mode: follow the reference's gcc build (default) or its clang build (fused multiply-adds)." },
+    { "get_arithmetic", mod_get_arithmetic, METH_NOARGS, "The arithmetic mode in force: 'separate' or 'contracted'." },
     { "last_error", mod_last_error, METH_NOARGS, "Last error message of the calling thread." },
     { "device_name", mod_device_name, METH_NOARGS, "Name of the HIP device in use." },
     { NULL }

@@ -225,6 +225,20 @@ typedef void *cvs_stream_t;            /* hipStream_t */
 enum { CVS_LUT_NONE = -1, CVS_LUT_REC709_TO_LINEAR_SCENE = 0, CVS_LUT_REC709_TO_LINEAR_DISPLAY = 1,
        CVS_LUT_LINEAR_TO_REC709 = 2, CVS_LUT_LINEAR_TO_SRGB = 3, CVS_LUT_COUNT = 4 };
 
+/* Arithmetic flavour.  The reference has two builds (SConstruct:46-48,75-83): gcc -std=c99, which rounds every multiply and
+ * every add on its own, and clang -- preferred when it is installed -- which contracts a * b + c inside one expression into
+ * a fused multiply-add: the matrix rows (src/cprocess/color.c:34-42), the blend numerators (src/cprocess/video_mix.c:193-205,
+ * 323-337), every FIR accumulation t += s * coeff (src/cprocess/video_scale.c:82-85), the scaler's line centres (:65) and
+ * intermediate window (:257-277), two of the transfer functions (src/cprocess/gammatab.c:58-66,201-211).
+ *   CVS_ARITH_SEPARATE   (default)  bit-equal to the gcc build;
+ *   CVS_ARITH_CONTRACTED            bit-equal to the clang build (half the FIR instructions: the faster of the two).
+ * Process-wide; every entry point reads it once on entry, so change it between calls, not while other threads are inside the
+ * library.  Tables that depend on it are cached per flavour.  The environment variable CVS_ARITHMETIC=contracted selects the
+ * second flavour at start-up.  cvs_set_arithmetic returns the previous mode, or -1 for an unknown one (nothing changes). */
+enum { CVS_ARITH_SEPARATE = 0, CVS_ARITH_CONTRACTED = 1 };
+CVS_EXPORT int cvs_set_arithmetic(int mode);
+CVS_EXPORT int cvs_get_arithmetic(void);
+
 CVS_EXPORT int cvs_init(int device);                   /* 0 on success; idempotent per device */
 CVS_EXPORT int cvs_device_count(void);
 CVS_EXPORT int cvs_current_device(void);
@@ -376,22 +390,22 @@ CVS_EXPORT int cvs_blur_over_f16_batch_dev(rgba_frame_f16 *const *outs, const rg
 CVS_EXPORT int cvs_blur_lanczos_f16_batch_dev(rgba_frame_f16 *const *targets, const rgba_frame_f16 *const *sources, int count,
                                               const float *taps_host, int ntaps, float fx, float fy, int ksize, cvs_stream_t stream);
 
-/* The separable FIR entry points choose among four kernels (DESIGN.md 4.2): the register-window kernel (one tap list for
- * every line), and for per-line tables the sweep with a lane per channel, tiles in LDS, and the sweep with a lane per pixel.
+/* The separable FIR entry points choose among four kernels (DESIGN.md): the register-window kernel (one tap list for
+ * every line), and for per-line tables the gather per target line, tiles in LDS, and the sweep with a lane per pixel.
  * All compute the same sums in the same order -- results are bit-equal, which the parity tests show by pinning each kernel
  * in turn through this call.  It changes speed only, never pixels; process-wide; 0 restores the automatic choice. */
 enum { CVS_FIR_PATH_AUTO = 0, CVS_FIR_PATH_SWEEP = 1 /* lane per pixel */, CVS_FIR_PATH_TILED = 2, CVS_FIR_PATH_TABLES = 4 /* skip the register-window kernel */,
-       CVS_FIR_PATH_LANES = 8 /* lane per channel */, CVS_FIR_PATH_HV = 16 /* per-line gather, horizontal pass first (the automatic first choice) */,
+       CVS_FIR_PATH_HV = 16 /* per-line gather, horizontal pass first (the automatic first choice) */,
        CVS_FIR_PATH_ONE_COLUMN = 32 /* the register-window kernels (blur, blur + halving) with one column per lane, never two */,
        CVS_FIR_PATH_TWO_COLUMNS = 64 /* ... with two columns per lane wherever that form takes the launch, narrow frames included */ };
 CVS_EXPORT void cvs_fir_path_override(int mode);
 /* Which kernel the calling thread's last FIR launch (scaler, blur, Lanczos resample, blur + resample) went to -- what a
  * test pinned to one kernel asserts, and what tells a silent fallback from the intended kernel.  A fused kernel that was
- * chosen and then failed to launch is reported through cvs_last_error() / the log handler before the next one is tried. */
+ * chosen and then failed to launch is reported through the log handler before the next one is tried. */
 enum { CVS_FIR_KERNEL_NONE = 0,
        CVS_FIR_KERNEL_WINDOW = 1,      /* k_blur: one tap list for every line, vertical window in registers */
        CVS_FIR_KERNEL_HALVE = 2,       /* k_blur_halve: blur + Lanczos halving in one sweep */
-       CVS_FIR_KERNEL_LANES = 3,       /* k_fir_lanes: per-line tables, horizontal pass first */
+       /* 3: the channel-pair sweep of rounds 2-3 (k_fir_lanes), retired in round 4 in favour of k_fir_hv */
        CVS_FIR_KERNEL_VH = 4,          /* k_fir_vh: the triangle scaler with the vertical pass first */
        CVS_FIR_KERNEL_TILED = 5,       /* k_fir2d: LDS tiles */
        CVS_FIR_KERNEL_STREAM = 6,      /* k_fir_stream: lane-per-pixel sweep */
@@ -401,6 +415,10 @@ enum { CVS_FIR_KERNEL_NONE = 0,
        CVS_FIR_KERNEL_WINDOW_PAIR = 10,    /* k_blur_pair: the register-window blur with two columns per lane (f16, up to 13 taps) */
        CVS_FIR_KERNEL_HALVE_PAIR = 11 };   /* k_blur_halve_pair: blur + Lanczos halving with two source columns per lane (f16) */
 CVS_EXPORT int cvs_fir_last_kernel(void);
+/* How many FIR launches of the calling thread were chosen for a fused kernel that then did not launch and went to the next
+ * kernel in line (same pixels, slower): each is also reported to the log handler as a warning.  A successful call leaves
+ * cvs_last_error() empty either way. */
+CVS_EXPORT int cvs_fir_fell_through_count(void);
 
 /* ------------------------------------------------------------------ (3) fused chain: BASELINE config 2
  * out = f16( over-stack_{k=0..n-1}( f32( colour(layer_k) ) ) ), i.e. what the reference computes with

@@ -8,6 +8,9 @@ with the committed hashes, so a libm or generator drift shows up as a mismatch r
     python tests/golden/make_checksums.py            # takes about a minute
     python tests/golden/make_checksums.py --stream 8 # frames 0..7 of every config -> stream_frames_sha256.json (minutes)
     python tests/golden/make_checksums.py --stream 8 lanczos3_3840x2160_x0.40 ...   # only the named cases, merged into the file
+    python tests/golden/make_checksums.py --flavour contracted [--stream 8 [names]]  # the same through the checker's OTHER build
+        (clang, a * b + c fused: the reference's preferred build, SConstruct:46-48); keys get the suffix "@contracted" and are
+        merged into the same files -- what the library's CVS_ARITH_CONTRACTED flavour is held to
 """
 import ctypes as C
 import hashlib
@@ -95,38 +98,69 @@ STREAM_ONLY = {"lanczos3_3840x2160_x0.40": lanczos3(0.4), "lanczos3_3840x2160_x0
                "scaler_1920x1080_x2.00": scaler(1920, 1080, 2.0)}       # (reducing, the reference covers only part of the target: video_scale.c:256-262)
 
 
-def checksums(only=None):
+CONTRACTED = "@contracted"          # key suffix of the digests made by the checker's clang / contraction-on build
+
+
+def _in_flavour(flavour):
     import oracle
     oracle.lib()
+    return oracle.flavour("fma" if flavour == "contracted" else "gcc")
+
+
+def checksums(only=None, flavour="separate"):
+    import oracle
     out = {}
-    for name, fn in CASES.items():
-        if only and name not in only:
-            continue
-        t0 = time.perf_counter()
-        arr = fn(oracle)
-        out[name] = {"shape": list(arr.shape), "sha256": canon_sha256(arr)}
-        print("%-34s %s  (%.1f s)" % (name, out[name]["sha256"][:16], time.perf_counter() - t0), file=sys.stderr)
+    sfx = CONTRACTED if flavour == "contracted" else ""
+    with _in_flavour(flavour):
+        for name, fn in CASES.items():
+            if only and name not in only:
+                continue
+            t0 = time.perf_counter()
+            arr = fn(oracle)
+            out[name + sfx] = {"shape": list(arr.shape), "sha256": canon_sha256(arr)}
+            print("%-34s %s  (%.1f s)" % (name + sfx, out[name + sfx]["sha256"][:16], time.perf_counter() - t0), file=sys.stderr)
     return out
 
 
-def stream_checksums(nframes=8, only=None):
+def stream_checksums(nframes=8, only=None, flavour="separate"):
     """Digests of stream frames 0..nframes-1 of every config: what rank r of an N-GPU bench run proves its first frame
     (global frame r) against -> tests/golden/stream_frames_sha256.json."""
     import oracle
-    oracle.lib()
     out = {}
-    for name, fn in list(CASES.items()) + list(STREAM_ONLY.items()):
-        if only and name not in only:
-            continue
-        out[name] = {}
-        for g in range(nframes):
-            t0 = time.perf_counter()
-            out[name][str(g)] = canon_sha256(fn(oracle, g))
-            print("%-34s frame %d %s  (%.1f s)" % (name, g, out[name][str(g)][:16], time.perf_counter() - t0), file=sys.stderr)
+    sfx = CONTRACTED if flavour == "contracted" else ""
+    with _in_flavour(flavour):
+        for name, fn in list(CASES.items()) + list(STREAM_ONLY.items()):
+            if only and name not in only:
+                continue
+            out[name + sfx] = {}
+            for g in range(nframes):
+                t0 = time.perf_counter()
+                out[name + sfx][str(g)] = canon_sha256(fn(oracle, g))
+                print("%-34s frame %d %s  (%.1f s)" % (name + sfx, g, out[name + sfx][str(g)][:16], time.perf_counter() - t0), file=sys.stderr)
     return out
 
 
+def _merge_into(path, new):
+    merged = json.load(open(path)) if os.path.exists(path) else {}
+    merged.update(new)
+    with open(path, "w") as f:
+        json.dump(merged, f, indent=1, sort_keys=True)
+        f.write("\n")
+    print("wrote", path)
+
+
 if __name__ == "__main__":
+    flavour = "separate"
+    if "--flavour" in sys.argv:
+        k = sys.argv.index("--flavour")
+        flavour = sys.argv[k + 1]
+        assert flavour in ("separate", "contracted")
+        del sys.argv[k:k + 2]
+        if len(sys.argv) > 1 and sys.argv[1] == "--stream":
+            _merge_into(os.path.join(HERE, "stream_frames_sha256.json"), stream_checksums(int(sys.argv[2]) if len(sys.argv) > 2 else 8, sys.argv[3:] or None, flavour))
+        else:
+            _merge_into(os.path.join(HERE, "full_size_sha256.json"), checksums(sys.argv[1:] or None, flavour))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "--stream":
         path = os.path.join(HERE, "stream_frames_sha256.json")
         only = sys.argv[3:] or None                # names after the count: only those cases, merged into the file

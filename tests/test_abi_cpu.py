@@ -202,7 +202,8 @@ def test_hot_kernels_keep_their_state_in_registers():
     import tempfile
     checked = hand = 0
     with tempfile.TemporaryDirectory(dir=build) as tmp:
-        for obj in ("blur_ops.hip.o", "blur_pair_ops.hip.o", "blur_halve_pair_ops.hip.o", "blur_long_ops.hip.o", "blur_even_ops.hip.o", "chain_ops.hip.o", "chain_deep_ops.hip.o", "color_ops.hip.o", "display_ops.hip.o", "resample_ops.hip.o", "sweep_ops.hip.o", "sweep_vh_ops.hip.o", "sweep_hv_ops.hip.o", "blur_halve_ops.hip.o"):
+        for obj in ("blur_ops.hip.o", "blur_pair_ops.hip.o", "blur_halve_pair_ops.hip.o", "blur_long_ops.hip.o", "blur_even_ops.hip.o", "chain_ops.hip.o", "chain_deep_ops.hip.o", "color_ops.hip.o", "display_ops.hip.o", "resample_ops.hip.o", "sweep_vh_ops.hip.o", "sweep_hv_ops.hip.o", "blur_halve_ops.hip.o",
+                    "blur_ops.fma.hip.o", "blur_pair_ops.fma.hip.o", "blur_halve_pair_ops.fma.hip.o", "blur_halve_ops.fma.hip.o", "chain_ops.fma.hip.o", "color_ops.fma.hip.o", "sweep_vh_ops.fma.hip.o"):
             src = os.path.join(build, obj)
             if not os.path.exists(src):
                 continue
@@ -230,7 +231,7 @@ def _asm_checker():
 
 
 def test_no_kernel_touches_a_register_with_a_load_in_flight():
-    """The hand-pipelined kernels (k_chain, k_fir_lanes) issue loads from inline asm and wait by hand; hipcc believes the
+    """The hand-pipelined kernel (k_chain, in both arithmetic flavours) issues loads from inline asm and wait by hand; hipcc believes the
     loaded value exists when the asm statement ends and may copy or reuse its register before the wait (round 2: wrong
     pixels, then a fault; round 3: the checker found sixteen such copies in k_chain<6 layers, pre-LUT>).  The rule is
     checked on the disassembly of EVERY kernel of the library -- the same check the Makefile runs as a build step."""
@@ -245,7 +246,7 @@ def test_no_kernel_touches_a_register_with_a_load_in_flight():
     assert checked >= 250, checked
     assert not problems, "\n".join(problems[:10])
     # the hand-pipelined ones were among them
-    hand, _ = chk.check_paths([o for o in objs if os.path.basename(o) in ("chain_ops.hip.o", "sweep_ops.hip.o")], only=r"k_chainILi2ELi0ELb1ELb0|k_fir_lanesILi8ELi8ELi1ELb1ELb1")
+    hand, _ = chk.check_paths([o for o in objs if os.path.basename(o) in ("chain_ops.hip.o", "chain_ops.fma.hip.o")], only=r"k_chainILi2ELi0ELb1ELb0")
     assert hand >= 2
 
 
@@ -316,3 +317,81 @@ def test_the_checker_finds_a_copy_in_front_of_the_wait():
     leaky = flagged.replace("s_and_b64 vcc, exec, s[10:11]", "s_and_b64 vcc, exec, s[12:13]").replace("k_flag", "k_leaky")
     problems = chk.check_function("k_leaky", chk.parse(leaky)["k_leaky"])
     assert len(problems) == 1 and "v_add_f32_e32 v6, v4, v5" in problems[0], problems
+
+
+# ---------------------------------------------------------------- round 4: arithmetic flavours, refusals that need no device
+
+def test_every_contracted_launcher_has_its_twin():
+    """kernels.h renames the launchers of the units built with -DCVS_CONTRACT to *_fma: every name of that list must be defined
+    by the library in both forms, and the host must know both (a missing twin would be a link error at best)."""
+    header = open(os.path.join(ROOT, "canvas_amd", "csrc", "kernels", "kernels.h")).read()
+    renamed = re.findall(r"#define\s+(cvk_\w+)\s+(cvk_\w+_fma)\b", header)
+    assert len(renamed) >= 20
+    assert all(b == a + "_fma" for a, b in renamed)
+    out = subprocess.run(["nm", "--defined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    defined = set(re.findall(r"\b[Tt]\s+(cvk_\w+)", out))
+    for a, b in renamed:
+        assert a in defined and b in defined, (a, b)
+        assert re.search(r"\b%s\s*\(" % b, header), "kernels.h does not declare " + b
+
+
+def test_arithmetic_mode_is_a_process_wide_switch(lib):
+    assert lib.cvs_get_arithmetic() in (_lib.ARITH_SEPARATE, _lib.ARITH_CONTRACTED)
+    before = lib.cvs_set_arithmetic(_lib.ARITH_CONTRACTED)
+    try:
+        assert lib.cvs_get_arithmetic() == _lib.ARITH_CONTRACTED
+        assert lib.cvs_set_arithmetic(7) == -1 and "unknown mode" in _lib.last_error()
+        assert lib.cvs_get_arithmetic() == _lib.ARITH_CONTRACTED              # a refused mode changes nothing
+        assert lib.cvs_set_arithmetic(_lib.ARITH_SEPARATE) == _lib.ARITH_CONTRACTED
+    finally:
+        lib.cvs_set_arithmetic(before)
+
+
+def test_batch_entries_refuse_what_the_single_calls_refuse(lib):
+    """the batch of cvs_blur_lanczos_f16_dev skipped the window check of the single entry -- a source whose
+    current_window reaches outside its buffer must be refused before anything is launched (here: before a device is even
+    looked for), every target marked empty; null entries of the arrays likewise."""
+    from canvas_amd.abi import rgba_frame_f16
+    fp16 = C.POINTER(rgba_frame_f16)
+    taps = np.array([0.25, 0.5, 0.25], np.float32)
+    tp = taps.ctypes.data_as(C.POINTER(C.c_float))
+    good = [HostFrame((0, 0, 63, 35), np.uint16) for _ in range(2)]
+    bad = HostFrame((0, 0, 63, 35), np.uint16, current_window=(0, 0, 64, 35))        # one column beyond the buffer
+    outs = [HostFrame((0, 0, 31, 17), np.uint16) for _ in range(3)]
+    srcs = (fp16 * 3)(C.pointer(good[0].c), C.pointer(bad.c), C.pointer(good[1].c))
+    dsts = (fp16 * 3)(*[C.pointer(o.c) for o in outs])
+    assert lib.cvs_blur_lanczos_f16_batch_dev(dsts, srcs, 3, tp, 3, C.c_float(0.5), C.c_float(0.5), 3, None) == -1
+    assert "outside its buffer (frame 1)" in _lib.last_error()
+    assert all(o.current_window.is_empty() for o in outs)
+    holes = (fp16 * 3)(C.pointer(good[0].c), None, C.pointer(good[1].c))
+    assert lib.cvs_blur_lanczos_f16_batch_dev(dsts, holes, 3, tp, 3, C.c_float(0.5), C.c_float(0.5), 3, None) == -1
+    assert "null pointer" in _lib.last_error()
+    # the blur + over batch: same two rules
+    full = [HostFrame((0, 0, 63, 35), np.uint16) for _ in range(3)]
+    fdst = (fp16 * 3)(*[C.pointer(o.c) for o in full])
+    layers = (fp16 * 3)(*[C.pointer(g.c) for g in (good[0], good[1], good[0])])
+    assert lib.cvs_blur_over_f16_batch_dev(fdst, srcs, tp, 3, layers, 1, 3, None) == -1
+    assert "outside its buffer (frame 1)" in _lib.last_error()
+    assert all(o.current_window.is_empty() for o in full)
+    assert lib.cvs_blur_over_f16_batch_dev(fdst, holes, tp, 3, layers, 1, 3, None) == -1 and "null pointer" in _lib.last_error()
+
+
+def test_forced_pull_of_a_source_without_a_device_slot_is_empty(lib):
+    """src/cprocess/main.c:78-103: video_get_frame_f16_gl on a source with no slot-3 entry leaves the window empty.  Slot 3 is
+    the device slot here; a host-only source pulled with force_gl=True must come back empty too, its pixel
+    callback never called."""
+    from canvas_amd.abi import GET_FRAME_F16, GET_FRAME_F32, video_frame_source_funcs, video_source
+    called = []
+
+    def get16(obj, idx, frame):
+        called.append(idx)
+    funcs = video_frame_source_funcs()
+    funcs.flags = 0
+    keep = GET_FRAME_F16(get16)
+    funcs.get_frame = keep
+    src = video_source(None, C.pointer(funcs))
+    for dtype, fn in ((np.uint16, lib.video_get_frame_f16_gl), (np.float32, lib.video_get_frame_f32_gl)):
+        out = HostFrame((0, 0, 7, 7), dtype)
+        fn(C.byref(src), 3, out.ref())
+        assert out.current_window.is_empty()
+    assert called == []

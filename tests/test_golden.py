@@ -49,12 +49,17 @@ def test_oracle_reproduces_full_size_checksums(orc, full_size_sums):
     fresh = make_checksums.checksums(only=names)
     for n in names:
         assert fresh[n] == full_size_sums[n], n
+    # the checker's other build (clang, a * b + c fused): what the library's contracted flavour is held to
+    fresh = make_checksums.checksums(only=names[:1], flavour="contracted")
+    assert fresh[names[0] + "@contracted"] == full_size_sums[names[0] + "@contracted"]
+    assert full_size_sums[names[0] + "@contracted"]["sha256"] != full_size_sums[names[0]]["sha256"]
 
 
 @pytest.mark.gpu
-def test_library_reproduces_full_size_checksums(full_size_sums):
-    """Every BASELINE config at its full size, frame 0: the library's output hashes to the committed value (no oracle run
-    on the GPU box: the fixture was made by the oracle in the build container)."""
+@pytest.mark.parametrize("flavour", ["separate", "contracted"])
+def test_library_reproduces_full_size_checksums(full_size_sums, flavour):
+    """Every BASELINE config at its full size, frame 0, in both arithmetic flavours: the library's output hashes to the
+    committed value (no oracle run on the GPU box: the fixtures were made by the oracle's two builds in the build container)."""
     import sys
     sys.path.insert(0, os.path.join(HERE, "golden"))
     from make_checksums import canon_sha256
@@ -66,6 +71,22 @@ def test_library_reproduces_full_size_checksums(full_size_sums):
     lib.init_half()
     m = np.array(REC709_RGB_TO_YPBPR, np.float32)
     f32p = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    sfx = "@contracted" if flavour == "contracted" else ""
+    lib.cvs_set_arithmetic(_lib.ARITH_CONTRACTED if sfx else _lib.ARITH_SEPARATE)
+    try:
+        got = _render_every_config(lib, _lib, m, f32p)
+    finally:
+        lib.cvs_set_arithmetic(_lib.ARITH_SEPARATE)
+    assert sorted(n + sfx for n in got) == sorted(n for n in full_size_sums if n.endswith("@contracted") == bool(sfx))
+    for name, arr in got.items():
+        assert list(arr.shape) == full_size_sums[name + sfx]["shape"], name
+        assert canon_sha256(arr) == full_size_sums[name + sfx]["sha256"], name + sfx
+
+
+def _render_every_config(lib, _lib, m, f32p):
+    from canvas_amd import synth
+    from canvas_amd.device import DeviceFrame, chain_color_over
+    from canvas_amd.stream import GraphStream
 
     def chain(w, h, n, matrix, pre):
         dl = [DeviceFrame.from_host(synth.layer_frame(w, h, k, 0)) for k in range(n)]
@@ -90,10 +111,7 @@ def test_library_reproduces_full_size_checksums(full_size_sums):
     out = g.render(0)
     _lib.check(lib.cvs_stream_sync(None))
     got["config5_3840x2160"] = out.download().array
-    assert sorted(got) == sorted(full_size_sums)
-    for name, arr in got.items():
-        assert list(arr.shape) == full_size_sums[name]["shape"], name
-        assert canon_sha256(arr) == full_size_sums[name]["sha256"], name
+    return got
 
 
 @pytest.mark.gpu

@@ -18,6 +18,21 @@ from tests.util import (assert_same_f16, assert_same_f32, f32p, rand_f16_frame, 
 
 pytestmark = pytest.mark.gpu
 
+
+def test_the_arithmetic_flavour_of_this_run_is_in_force(cvs, orc, arithmetic):
+    """Every test of this module runs twice (tests/conftest.py): the library in one arithmetic flavour against the checker's
+    build of the same flavour.  This one holds the plumbing itself: the library reports the flavour the test was given, and the
+    checker in use is the matching build (the two builds differ on this input)."""
+    assert cvs.cvs_get_arithmetic() == (_lib.ARITH_CONTRACTED if arithmetic == "contracted" else _lib.ARITH_SEPARATE)
+    layers = [synth.layer_frame(256, 144, k, 0) for k in range(2)]
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    mine = orc.chain_color_over(layers, m, orc.transfer_table(0), None).array
+    with orc.flavour("fma" if arithmetic == "contracted" else "gcc"):
+        same = orc.chain_color_over(layers, m, orc.transfer_table(0), None).array
+    with orc.flavour("gcc" if arithmetic == "contracted" else "fma"):
+        other = orc.chain_color_over(layers, m, orc.transfer_table(0), None).array
+    assert np.array_equal(mine, same) and not np.array_equal(mine, other)
+
 ALL_CODES = np.arange(65536, dtype=np.uint16)
 
 
@@ -615,7 +630,7 @@ def test_forced_pull_goes_through_the_device_slot(cvs, orc):
     """video_get_frame_f16_gl / _f32_gl (main.c:78-103,146-172; what force_gl=True calls, RgbaFrameF16.c:247-249): the
     pull through vtable slot 3 even when the source also fills a host slot.  Slot 3 is the device slot here: a vtable
     whose host slots would paint junk, with the workspace's device entry in slot 3, must yield the workspace's pixels;
-    a source with no device slot is pulled the ordinary way."""
+    a source with no device slot yields an empty window, as the reference's does without a get_frame_gl (main.c:99-102)."""
     rng = np.random.default_rng(77)
     full = (0, 0, 23, 11)
     frames = [rand_f16_frame(rng, full, full, alpha="one"), rand_f16_frame(rng, full, (3, 2, 20, 9))]
@@ -647,9 +662,8 @@ def test_forced_pull_goes_through_the_device_slot(cvs, orc):
     assert_same_f32(got32.window_view(), want32.window_view(), "forced f32")
 
     plain = HostFrame(full, np.uint16)
-    cvs.video_get_frame_f16_gl(C.byref(sources[1][0]), 0, plain.ref())              # no device slot: ordinary pull
-    assert plain.current_window.tuple() == (3, 2, 20, 9)
-    assert np.array_equal(plain.window_view(), frames[1].window_view())
+    cvs.video_get_frame_f16_gl(C.byref(sources[1][0]), 0, plain.ref())              # no device slot: nothing, as in the reference
+    assert plain.current_window.is_empty()
     cvs.video_get_frame_f16_gl(None, 0, plain.ref())
     assert plain.current_window.is_empty()
     cvs.workspace_free(ws)
@@ -825,8 +839,6 @@ def force_fir(request):
             mode |= _lib.FIR_PATH_SWEEP
         elif which == "tiled":
             mode |= _lib.FIR_PATH_TILED
-        elif which == "lanes":
-            mode |= _lib.FIR_PATH_LANES
         elif which == "hv":
             mode |= _lib.FIR_PATH_HV
 
@@ -840,7 +852,7 @@ def force_fir(request):
             json.dump(_FIR_SEEN, f, indent=0, sort_keys=True)
 
 
-_KERNEL_NAMES = {_lib.FIR_KERNEL_NONE: "none", _lib.FIR_KERNEL_WINDOW: "window", _lib.FIR_KERNEL_HALVE: "halve", _lib.FIR_KERNEL_LANES: "lanes",
+_KERNEL_NAMES = {_lib.FIR_KERNEL_NONE: "none", _lib.FIR_KERNEL_WINDOW: "window", _lib.FIR_KERNEL_HALVE: "halve",
                  _lib.FIR_KERNEL_VH: "vh", _lib.FIR_KERNEL_TILED: "tiled", _lib.FIR_KERNEL_STREAM: "stream",
                  _lib.FIR_KERNEL_TWO_PASS: "two-pass", _lib.FIR_KERNEL_PASS: "pass", _lib.FIR_KERNEL_HV: "hv",
                  _lib.FIR_KERNEL_WINDOW_PAIR: "window-pair", _lib.FIR_KERNEL_HALVE_PAIR: "halve-pair"}
@@ -849,27 +861,33 @@ _FIR_SEEN = {}
 
 def ran_on(cvs, forced, fallback=None, note=None):
     """cvs_fir_last_kernel() after a launch pinned with force_fir(forced): the pinned kernel, or -- for a table pair that
-    kernel does not take -- the documented fallback named by the caller (host/scale.c fir2d_launch: lanes -> stream when
-    the tiles would need more than 64 KiB of LDS and the vertical table streams -> tiled -> two passes)."""
+    kernel does not take -- the documented fallback named by the caller (host/scale.c fir2d_launch: hv -> stream when
+    the tiles would need more than 64 KiB of LDS and the vertical table streams -> tiled -> two passes).
+    The two sweeps (hv, stream) exist in the default arithmetic flavour only: in the contracted one a table pair goes to the
+    tiles, or to the two passes when its footprint does not fit them -- same sums, and that is what the test then checks."""
     got = _KERNEL_NAMES[cvs.cvs_fir_last_kernel()]
+    contracted = cvs.cvs_get_arithmetic() == _lib.ARITH_CONTRACTED
     if note is not None:
-        _FIR_SEEN[note] = got
+        _FIR_SEEN[note + (" [contracted]" if contracted else "")] = got
     want = fallback or forced
-    assert got == want, "pinned to %r (expected to run on %r), ran on %r" % (forced, want, got)
-    assert _lib.last_error() == "", _lib.last_error()      # a fused kernel that failed to launch says so (fir_launch_fell_through)
+    if contracted and want in ("hv", "stream"):
+        assert got in ("tiled", "two-pass"), "contracted flavour, pinned to %r: expected the tiles or the two passes, ran on %r" % (forced, got)
+    else:
+        assert got == want, "pinned to %r (expected to run on %r), ran on %r" % (forced, want, got)
+    assert _lib.last_error() == "", _lib.last_error()
+    assert cvs.cvs_fir_fell_through_count() == 0            # a fused kernel that was chosen and failed to launch is counted (and logged)
     return got
 
 
 # cases of the tests below that the pinned kernel does NOT take, and where they go instead
 _FALLBACK = {
-    ("lanes", (0.3, 3.0)): "tiled",        # 3x enlargement: 39 accumulator slots, the sweep has 32; small footprint -> tiles
     # the lane-per-pixel sweep keeps one accumulator per active target row and has instances up to 16 of them
     # (cvk_fir_stream_supported): a 2x enlargement has 26 active rows, 2.1x and 3x more -> tiles
     ("stream", (2.0, 2.0)): "tiled", ("stream", (1.5625, 2.1)): "tiled", ("stream", (0.3, 3.0)): "tiled",
 }
 
 
-@pytest.mark.parametrize("kernel", ["hv", "lanes", "stream", "tiled"])
+@pytest.mark.parametrize("kernel", ["hv", "stream", "tiled"])
 @pytest.mark.parametrize("ssize,scur,tsize,fx,fy", [
     ((64, 36), None, (32, 18), 0.5, 0.5),
     ((400, 300), None, (160, 120), 0.4, 0.4),                # several strips of 128 columns, several row segments
@@ -881,8 +899,8 @@ _FALLBACK = {
     ((130, 70), None, (40, 200), 0.3, 3.0),                  # more target rows than the source covers: lines without taps
 ])
 def test_lanczos_resample_both_kernels(cvs, orc, force_fir, kernel, ssize, scur, tsize, fx, fy):
-    """The general resampler has four kernels (the per-line gather, the channel-pair sweep, tiles in LDS, the lane-per-pixel
-    sweep); whichever a table pair would get, all must give the gather's sums bit for bit."""
+    """The general resampler has three kernels (the per-line gather, tiles in LDS, the lane-per-pixel sweep); whichever a
+    table pair would get, all must give the gather's sums bit for bit."""
     rng = np.random.default_rng(62)
     sfull = (0, 0, ssize[0] - 1, ssize[1] - 1)
     src = rand_f32_frame(rng, sfull, scur, lo=-0.5, hi=1.5)
@@ -906,7 +924,7 @@ def test_lanczos_resample_both_kernels(cvs, orc, force_fir, kernel, ssize, scur,
     assert_same_f16(o16.download().array, want16.array, "lanczos f16 (%s)" % kernel)
 
 
-@pytest.mark.parametrize("kernel", ["hv", "lanes", "stream", "tiled"])
+@pytest.mark.parametrize("kernel", ["hv", "stream", "tiled"])
 @pytest.mark.parametrize("ssize,tsize,fx,fy", [((400, 300), (160, 120), 0.4, 0.4), ((96, 54), (144, 81), 1.5, 1.5), ((300, 200), (225, 150), 0.75, 0.75),
                                                ((96, 54), (192, 108), 2.0, 2.0)])
 def test_lanczos_resample_with_inf_and_nan_pixels(cvs, orc, force_fir, kernel, ssize, tsize, fx, fy):
@@ -934,7 +952,7 @@ def test_lanczos_resample_with_inf_and_nan_pixels(cvs, orc, force_fir, kernel, s
     assert_same_f32(got.array, want.array, "lanczos with non-finite pixels (%s)" % kernel)
 
 
-@pytest.mark.parametrize("kernel", ["hv", "lanes", "stream", "tiled"])
+@pytest.mark.parametrize("kernel", ["hv", "stream", "tiled"])
 @pytest.mark.parametrize("ntaps", [1, 2, 4, 10, 16])
 def test_even_and_short_blurs_both_kernels(cvs, orc, force_fir, kernel, ntaps):
     rng = np.random.default_rng(63)
@@ -956,11 +974,9 @@ def test_even_and_short_blurs_both_kernels(cvs, orc, force_fir, kernel, ntaps):
 @pytest.mark.parametrize("f,fmt", [(0.4, "f16"), (0.4, "f32"), (0.75, "f16"), (0.75, "f32"), (1.5, "f16"), (1.5, "f32"),
                                    (1.0 / 3.0, "f16"), (1.0 / 3.0, "f32"), (2.0, "f16")])
 def test_full_size_resample_agrees_between_the_kernels(cvs, force_fir, f, fmt):
-    """3840x2160 Lanczos3 at factors that take different instances of the channel-pair sweep (16 / 12 taps with 8 slots, 12
-    taps with 16 slots, 24 taps, 16 taps with 32 slots), f16 and f32 frames: the tiled kernel and the lane-per-pixel sweep -- independent code --
-    must produce the same frame bit for bit (each is checked against the oracle at small sizes, and bench.py proves the f16
-    frames at 0.4x / 0.75x / 1.5x against SHA-256 fixtures of the oracle).  This is also the full-size check of the
-    hand-written load pipeline of sweep_ops.hip."""
+    """3840x2160 Lanczos3 at factors that take different instances of the per-line gather, f16 and f32 frames: the tiled
+    kernel and the gather -- independent code -- must produce the same frame bit for bit (each is checked against the oracle at
+    small sizes, and bench.py proves the f16 frames at 0.4x / 0.75x / 1.5x against SHA-256 fixtures of the oracle)."""
     w, h = 3840, 2160
     tw, th = int(w * f), int(h * f)
     src16 = synth.layer_frame(w, h, 1, 0)
@@ -971,15 +987,15 @@ def test_full_size_resample_agrees_between_the_kernels(cvs, force_fir, f, fmt):
         d_src, dtype = DeviceFrame.from_host(HostFrame(src16.full_window, np.float32, h2f_ieee(src16.array).astype(np.float32))), np.float32
     outs = []
     cvs.cvs_clear_last_error()
-    for kernel in (None, "tiled", "lanes", "hv"):
+    for kernel in (None, "tiled", "hv"):
         force_fir(kernel)
         d_out = DeviceFrame((0, 0, tw - 1, th - 1), dtype)
         if fmt == "f16":
             _lib.check(cvs.cvs_resample_lanczos_f16_dev(d_out.ref(), d_src.ref(), C.c_float(f), C.c_float(f), 3, None))
         else:
             _lib.check(cvs.cvs_resample_lanczos_f32_dev(d_out.ref(), d_src.ref(), C.c_float(f), C.c_float(f), 3, None))
-        # the automatic choice (host/scale.c hv_goes_first): the per-line gather when enlarging, the channel-pair sweep when reducing
-        ran_on(cvs, kernel or ("hv" if f > 1.0 else "lanes"), note="full size %s %r %s" % (kernel, f, fmt))
+        # the automatic choice (host/scale.c fir2d_launch): the per-line gather
+        ran_on(cvs, kernel or "hv", note="full size %s %r %s" % (kernel, f, fmt))
         got = d_out.download()
         assert got.current_window.tuple() == (0, 0, tw - 1, th - 1)
         outs.append(got.array.copy())
@@ -1592,7 +1608,7 @@ def test_blur_over_node_by_node(cvs, orc, case):
     assert_same_f16(got.window_view(), want.window_view(), "blur+over %s" % case)
 
 
-@pytest.mark.parametrize("kernel", ["hv", "lanes", "stream", "tiled"])
+@pytest.mark.parametrize("kernel", ["hv", "stream", "tiled"])
 @pytest.mark.parametrize("ntaps", [9, 10])
 def test_blur_over_node_by_node_through_the_table_kernels(cvs, orc, force_fir, kernel, ntaps):
     """The node-by-node form blurs an f16 source into an f32 frame; with the register-window kernels out of the way that is
@@ -2209,7 +2225,7 @@ def test_scale_bilinear_random_geometry(cvs, orc):
 @pytest.mark.parametrize("fac,fmt", [((1.5, 1.5), "f32"), ((2.0, 2.0), "f16"), ((0.75, 0.75), "f16"), ((1.25, 1.125), "f32"), ((0.8, 0.6), "f32"), ((0.75, 1.5), "f16"), ((1.25, 2.0), "f32"), ((0.5, 0.5), "f16"), ((0.4, 0.35), "f32")])
 def test_scaler_in_one_launch_agrees_with_the_two_passes(cvs, force_fir, fac, fmt):
     """1920x1080 through the triangle scaler: the automatic choice runs both passes in one launch (vertical pass first:
-    sweep_vh_ops.hip; horizontal factor smaller, so horizontal first: sweep_ops.hip); pinned to the older kernels it runs the reference's two passes through an f32 frame.
+    sweep_vh_ops.hip; horizontal factor smaller, so horizontal first: sweep_hv_ops.hip); pinned to the older kernels it runs the reference's two passes through an f32 frame.
     Same tables, same order of roundings: the frames must be equal bit for bit (each form is checked against the oracle at
     small sizes by the tests above)."""
     w, h = 1920, 1080
@@ -2231,11 +2247,14 @@ def test_scaler_in_one_launch_agrees_with_the_two_passes(cvs, force_fir, fac, fm
         fused.append(cvs.cvs_scale_last_was_fused())
         # video_scale.c:252: the smaller factor's pass first -- horizontal first is the channel-pair sweep, else k_fir_vh
         # ... and when the horizontal pass goes first: the per-line gather unless the horizontal axis reduces (hv_goes_first)
-        assert _KERNEL_NAMES[cvs.cvs_fir_last_kernel()] == ("pass" if kernel else ("hv" if fac[0] >= 1.0 else "lanes") if fac[0] < fac[1] else "vh")
+        # (the horizontal-first gather exists in the default arithmetic flavour only: the contracted one runs the two passes)
+        contracted = cvs.cvs_get_arithmetic() == _lib.ARITH_CONTRACTED
+        assert _KERNEL_NAMES[cvs.cvs_fir_last_kernel()] == ("pass" if kernel or (contracted and fac[0] < fac[1]) else "hv" if fac[0] < fac[1] else "vh")
         got = d_out.download()
         outs.append((got.current_window.tuple(), got.array.copy()))
         d_src.free(); d_out.free()
-    assert fused == [1, 0]
+    contracted = cvs.cvs_get_arithmetic() == _lib.ARITH_CONTRACTED
+    assert fused == [0 if contracted and fac[0] < fac[1] else 1, 0]
     assert outs[0][0] == outs[1][0]
     a, b = outs[0][1], outs[1][1]
     if fmt == "f16":
@@ -2326,7 +2345,7 @@ def test_lanczos_random_factors_every_sweep_against_the_oracle(cvs, orc, force_f
         want = HostFrame(tfull, np.float32)
         orc.lib().orc_resample_lanczos_f32(want.ref(), src32.ref(), C.c_float(fx), C.c_float(fy), 3)
         d_src = DeviceFrame.from_host(src)
-        for kernel in (None, "hv", "lanes"):
+        for kernel in (None, "hv", "tiled"):
             force_fir(kernel)
             if half:
                 d_out = DeviceFrame(tfull, np.uint16)

@@ -116,3 +116,34 @@ def test_library_is_bit_equal_to_gcc_build_and_within_one_code_of_clang_build(cv
     got = out.download().array
     assert np.array_equal(canon_f16(got), canon_f16(gcc)), "not bit-equal to the gcc / no-contraction build of the reference"
     assert_within_build_spread(orc, got, fma, "library vs the clang / contraction build")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["baseline", "translucent", "wide"])
+@pytest.mark.parametrize("config,w,h", [(2, 256, 144), (4, 256, 144), (2, 3840, 2160), (4, 7680, 4320)])
+def test_contracted_library_is_bit_equal_to_clang_build_and_not_to_gcc_build(cvs, orc, case, config, w, h):
+    """cvs_set_arithmetic(CVS_ARITH_CONTRACTED): the mirror image of the test above -- bit-equal to the contraction-on build
+    of the reference, and (on inputs where the two builds differ at all) NOT equal to the other one: the flavour is in force."""
+    from canvas_amd import _lib
+    from canvas_amd.device import DeviceFrame, chain_color_over
+    if w > 256:
+        if case != "baseline":
+            pytest.skip("full size: the BASELINE input only")
+        h = 256 if config == 2 else 128
+    layers = layers_for(case, w, h)[:2 if config == 2 else 3]
+    gcc, fma = both_flavours(orc, layers, M if config == 2 else None, orc.transfer_table(0) if config == 2 else None)
+    dl = [DeviceFrame.from_host(l) for l in layers]
+    out = DeviceFrame((0, 0, w - 1, h - 1), np.uint16)
+    assert cvs.cvs_set_arithmetic(_lib.ARITH_CONTRACTED) == _lib.ARITH_SEPARATE
+    try:
+        assert cvs.cvs_get_arithmetic() == _lib.ARITH_CONTRACTED
+        chain_color_over([(out, dl)], M if config == 2 else None, _lib.LUT_REC709_TO_LINEAR_SCENE if config == 2 else _lib.LUT_NONE, _lib.LUT_NONE)
+        _lib.check(cvs.cvs_stream_sync(None))
+        assert cvs.cvs_chain_last_was_fused() == 1
+    finally:
+        cvs.cvs_set_arithmetic(_lib.ARITH_SEPARATE)
+    got = out.download().array
+    assert np.array_equal(canon_f16(got), canon_f16(fma)), "not bit-equal to the clang / contraction-on build of the reference"
+    if not np.array_equal(canon_f16(gcc), canon_f16(fma)):
+        assert not np.array_equal(canon_f16(got), canon_f16(gcc)), "the contracted flavour computed the gcc build's pixels"
+    assert_within_build_spread(orc, got, gcc, "contracted library vs the gcc build")

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Disassembly-level guard for the hand-pipelined loads (chain_kernel.hpp, sweep_ops.hip, sweep_vh_ops.hip).
+"""Disassembly-level guard for the hand-pipelined loads (chain_kernel.hpp; until round 4 also the channel-pair sweep, retired).
 
 Those kernels issue `global_load_*` from inline asm a trip or a row group ahead and wait with a hand-written
 `s_waitcnt vmcnt(0)`.  An asm statement's output operand tells hipcc the value EXISTS when the statement ends, so under
 register pressure it may copy the "value" elsewhere (a v_mov, a v_accvgpr_write) or reuse the register while the load is
-still in flight: wrong pixels, then a load landing on a register that by now holds an address -- the fault recorded in
-sweep_ops.hip.  The property that rules this out is checked here on the machine code itself, for EVERY vector-memory load
+still in flight: wrong pixels, then a load landing on a register that by now holds an address -- the fault of round 2.
+The property that rules this out is checked here on the machine code itself, for EVERY vector-memory load
 of every kernel in the given code objects (the compiler's own loads satisfy it by construction, so checking all of them
 costs nothing and needs no way to tell the two kinds apart):
 
@@ -34,9 +34,9 @@ IDX_SPAN = 32           # registers a GPR-indexed operand may reach from its bas
 # Kernels that issue loads from inline asm.  A jump table (s_setpc_b64, hipcc's code for a dense switch) cannot be
 # followed; in a kernel of this list that is an error, elsewhere the blocks behind it are simply not walked (every load
 # there is the compiler's own, waited for by the compiler).
-HAND_PIPELINED = re.compile(r"k_chainILi|k_fir_lanesILi")
-# kernels whose indexed register vector is shorter: k_fir_lanes<MAXT, NACC, ...> indexes ONE vector of 2 * NACC floats
-IDX_SPAN_OF = [(re.compile(r"k_fir_lanesILi\d+ELi(\d+)E"), lambda m: 2 * int(m.group(1)))]
+HAND_PIPELINED = re.compile(r"k_chainILi")
+# kernels whose indexed register vector is shorter than IDX_SPAN: (name pattern, span from the match); none at present
+IDX_SPAN_OF = []
 VMCNT_MAX = 63
 
 _reg_re = re.compile(r"\b([va])(?:(\d+)|\[(\d+):(\d+)\])")
