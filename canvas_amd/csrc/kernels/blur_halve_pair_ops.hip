@@ -47,8 +47,14 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
     typedef Strip<NT1, NT2, WG> G;
     constexpr int W = G::W, C1 = G::C1, C2 = G::C2, D = G::D, OUTW = G::OUTW, PITCH = G::PITCH;
     static_assert(NT1 % 2 == 1 && NT2 % 2 == 1 && NT1 >= 1, "odd tap counts");
-    constexpr int U = 2 * NT1;                                 // steps per copy of the loop body: ring slot and step parity are its index
-    constexpr int WL = NT2 + 1;                                // rows of the second stage's window
+    // Steps per copy of the loop body: the first ring's slot (jj % NT1), the step's parity and the SECOND stage's ring slot
+    // are its index.  The second stage keeps the last NT2 + 1 rows it filtered in a ring of UB slots -- as long as the body, so
+    // that a row's slot (row % UB) is a compile-time fact of the step that writes or reads it and the ring looks the same at
+    // the end of a body as at its start: no row ever moves.  (Until round 4 this was a window of NT2 + 1 rows shifted down by
+    // two every second step: 22 register moves per target row, a tenth of the contracted build's vector instructions.)
+    constexpr int WL = NT2 + 1;                                // rows of the second stage that are alive at any time
+    constexpr int UB = 2 * NT1 * ((WL + 2 * NT1 - 1) / (2 * NT1));
+    static_assert(UB % NT1 == 0 && UB % 2 == 0 && UB >= WL, "body length");
     __shared__ float4 rowS[2][2][PITCH];                       // source row, widened: [step parity][column parity][column / 2]
     __shared__ float4 rowB[2][2][PITCH];                       // blurred row, the same way
     const int lane = threadIdx.x;
@@ -101,11 +107,11 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
     __syncthreads();
 
     Px ring1[NT1][2];
-    Px win2[WL];
+    Px ring2[UB];
 #pragma unroll
     for (int k = 0; k < NT1; k++) ring1[k][0].rg = ring1[k][0].ba = ring1[k][1].rg = ring1[k][1].ba = f32x2{ 0.0f, 0.0f };
 #pragma unroll
-    for (int k = 0; k < WL; k++) win2[k].rg = win2[k].ba = f32x2{ 0.0f, 0.0f };
+    for (int k = 0; k < UB; k++) ring2[k].rg = ring2[k].ba = f32x2{ 0.0f, 0.0f };
 
     auto fetch_row = [&](int ys, bool wanted) -> u32x4 {
         const bool live = wanted && ys >= bp.sy0 && ys <= bp.sy1;           // uniform: a dead row is a descriptor without records
@@ -122,10 +128,11 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
     // step i: source row ys0 + i is filtered; blurred row rb = i - (NT1 - 1) leaves the first ring (rb >= 0) and is handed over
     // through LDS; in step i + 1 it enters the second stage as rb2 = (i + 1) - NT1; an EVEN rb2 >= NT2 - 1 completes target row
     // ta + (rb2 - (NT2 - 1)) / 2 -- rb2 is even exactly in the odd steps (NT1 odd).  One step past the last row drains the hand-over.
-    for (int i0 = 0; i0 <= steps; i0 += U) {
+    for (int i0 = 0; i0 <= steps; i0 += UB) {
         auto step = [&](auto jc) -> bool {
-            constexpr int jj = decltype(jc)::value;            // == i % U: ring slot jj % NT1, step parity jj & 1
+            constexpr int jj = decltype(jc)::value;            // == i % UB: first ring's slot jj % NT1, step parity jj & 1
             constexpr int j1 = jj % NT1, par = jj & 1;
+            constexpr int s2 = ((jj - NT1) % UB + UB) % UB;    // second ring's slot of blurred row rb2 = i - NT1
             const int i = i0 + jj;
             if (i > steps) return false;                       // uniform over the workgroup
             const u32x4 far = fetch_row(ys0 + i + 3, i + 3 < steps);
@@ -149,8 +156,8 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
                     if (k == 0) { hrg = p; hba = q; } else { hrg = hrg + p; hba = hba + q; }
                     }
                 }
-                win2[NT2 - 1 + par].rg = hrg;                  // even step: slot NT2 - 1, odd step: slot NT2
-                win2[NT2 - 1 + par].ba = hba;
+                ring2[s2].rg = hrg;
+                ring2[s2].ba = hba;
             }
             if constexpr (par == 1) {
                 if (rb2 >= NT2 - 1) {
@@ -158,11 +165,12 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
                     f32x2 org, oba;
 #pragma unroll
                     for (int k = 0; k < NT2; k++) {
+                        const Px &row = ring2[(s2 + UB - (NT2 - 1) + k) % UB];       // blurred row rb2 - (NT2 - 1) + k
                         if constexpr (cvs::kContract) {
-                            if (k == 0) { org = win2[1].rg * w2[0]; oba = win2[1].ba * w2[0]; }
-                            else { org = cvs::madd(win2[1 + k].rg, w2[k], org); oba = cvs::madd(win2[1 + k].ba, w2[k], oba); }
+                            if (k == 0) { org = row.rg * w2[0]; oba = row.ba * w2[0]; }
+                            else { org = cvs::madd(row.rg, w2[k], org); oba = cvs::madd(row.ba, w2[k], oba); }
                         } else {
-                        const f32x2 p = win2[1 + k].rg * w2[k], q = win2[1 + k].ba * w2[k];
+                        const f32x2 p = row.rg * w2[k], q = row.ba * w2[k];
                         if (k == 0) { org = p; oba = q; } else { org = org + p; oba = oba + q; }
                         }
                     }
@@ -173,9 +181,6 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
                     const u32x2 codes = { cvs::pkrtz(org.x, org.y), cvs::pkrtz(oba.x, oba.y) };
                     __builtin_amdgcn_raw_buffer_store_b64(codes, row_rsrc(dst_data, (size_t)((ptrdiff_t)(t - bp.target.fy0) * (ptrdiff_t)trow + trect0), t <= tb ? trect : 0u), (int)toff, 0, 0);
                 }
-                // the window moves down by two rows
-#pragma unroll
-                for (int k = 0; k + 2 < WL; k++) win2[k] = win2[k + 2];
             }
 
             // ---- first stage: H1 of this source row, then the blurred row it completes
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(WG) void k_blur_halve_pair(cvk_blur_halve_params bp
             __syncthreads();                                   // (one wave: a compiler fence; the hardware keeps the wave's LDS accesses in order)
             return true;
         };
-        each_slot(step, std::make_integer_sequence<int, U>{});
+        each_slot(step, std::make_integer_sequence<int, UB>{});
     }
 }
 

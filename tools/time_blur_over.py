@@ -15,8 +15,11 @@ from canvas_amd.device import DeviceFrame  # noqa: E402
 if os.environ.get("CANVAS_DIAG") == "1":                   # the diagnostic build: CVS_BLUR_WIDTH / CVS_BLUR_ROWS / CVS_BLUR_WGS_PER_CU are read there only
     from tools._diag import use_diag_library
     use_diag_library()
+if os.environ.get("CANVAS_LIB"):                      # A/B runs: another build of the library (never set by the package)
+    _lib.LIB_PATH = os.environ["CANVAS_LIB"]
 lib = _lib.load()
 _lib.check(lib.cvs_init(0))
+print("library %s, arithmetic %s" % (os.path.basename(_lib.LIB_PATH), "contracted" if lib.cvs_get_arithmetic() else "separate"), flush=True)
 lib.init_half()
 stream = lib.cvs_stream_create()
 w, h = 3840, 2160

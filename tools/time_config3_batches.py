@@ -9,7 +9,10 @@ if os.environ.get("CANVAS_DIAG") == "1":
     use_diag_library()
 from canvas_amd import _lib, synth
 from canvas_amd.device import DeviceFrame
+if os.environ.get("CANVAS_LIB"):                      # A/B runs: another build of the library (never set by the package)
+    _lib.LIB_PATH = os.environ["CANVAS_LIB"]
 lib = _lib.load(); _lib.check(lib.cvs_init(0)); lib.init_half()
+print("library %s, arithmetic %s" % (os.path.basename(_lib.LIB_PATH), "contracted" if lib.cvs_get_arithmetic() else "separate"), flush=True)
 w, h = 3840, 2160
 N = 24
 srcs = [DeviceFrame.from_host(synth.layer_frame(w, h, 1, g % 2)) for g in range(N)]
