@@ -100,6 +100,12 @@ SIGNATURES = {
     "cvs_init": (C.c_int, [C.c_int]),
     "cvs_device_count": (C.c_int, []),
     "cvs_current_device": (C.c_int, []),
+    "cvs_context_open": (C.c_int, [C.c_int]),
+    "cvs_context_count": (C.c_int, []),
+    "cvs_context_device": (C.c_int, [C.c_int]),
+    "cvs_set_context": (C.c_int, [C.c_int]),
+    "cvs_current_context": (C.c_int, []),
+    "cvs_frame_owner": (C.c_int, [C.c_int64, C.c_int]),
     "cvs_last_error": (C.c_char_p, []),
     "cvs_clear_last_error": (None, []),
     "cvs_set_log_handler": (None, [C.c_void_p, C.c_void_p]),

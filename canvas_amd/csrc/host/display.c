@@ -19,10 +19,12 @@ const float *cvs_codes_as_float(void);        /* halfconv.c */
 
 enum { RAMP_GAMMA45 = 0, RAMP_INTENT = 1 };
 typedef struct { bool have; int pre_lut, kind, pins; unsigned gen; uint32_t intent_bits; uint64_t stamp; uint8_t *dev; } disp_entry;     /* pins: captured graphs whose kernels read the table */
+/* one cache per device context (runtime.c): the tables live on the device */
 #define DISP_CACHE 8
 static pthread_mutex_t disp_lock = PTHREAD_MUTEX_INITIALIZER;
-static disp_entry disp_cache[DISP_CACHE];
+static disp_entry disp_cache_of[CVS_MAX_CONTEXTS][DISP_CACHE];
 static uint64_t disp_clock;
+#define disp_cache (disp_cache_of[cvs_ctx()])
 
 /* Call with disp_lock held, and keep it until the kernel that reads the table has been enqueued: an eviction waits for
  * the device (under the same lock) before it overwrites a slot, so a table is never rewritten under a launch that was
@@ -64,9 +66,11 @@ static const uint8_t *display_table(int pre_lut, int kind, float intent, int *sl
     return result;
 }
 
+/* `slot`: context * DISP_CACHE + entry */
 static void display_unpin(void *slot) {
+    const int id = (int)(intptr_t)slot;
     pthread_mutex_lock(&disp_lock);
-    disp_cache[(int)(intptr_t)slot].pins--;
+    disp_cache_of[id / DISP_CACHE][id % DISP_CACHE].pins--;
     pthread_mutex_unlock(&disp_lock);
 }
 
@@ -78,7 +82,7 @@ static int to_bytes_dev(void *dst_dev, const rgba_frame_f16 *frame, int pre_lut,
     const uint8_t *table = display_table(pre_lut, ramp, intent, &slot);
     int rc = table ? cvk_display(dst_dev, cvs_view(frame->data, &frame->full_window), cvs_rect(&frame->current_window), table, kmode, cvs_cus(), s) : -1;
     /* recorded into a graph: the table stays where it is until the graph is destroyed */
-    if (table && rc == 0 && cvs_capture_hold(s, display_unpin, (void *)(intptr_t)slot)) disp_cache[slot].pins++;
+    if (table && rc == 0 && cvs_capture_hold(s, display_unpin, (void *)(intptr_t)(cvs_ctx() * DISP_CACHE + slot))) disp_cache[slot].pins++;
     pthread_mutex_unlock(&disp_lock);
     if (table && rc != 0) { cvs_set_error("frame to bytes: launch failed: %s", hipGetErrorString((hipError_t)rc)); return -1; }
     return rc;

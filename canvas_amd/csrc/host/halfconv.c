@@ -127,10 +127,13 @@ static float tf_linear_to_srgb(float in, int fl) {                    /* gammata
 /* the slot of a table: [flavour][which], the flavour-independent tables always in flavour 0's row */
 static inline int lut_row(int which) { return (which == CVS_LUT_LINEAR_TO_REC709 || which == CVS_LUT_LINEAR_TO_SRGB) && cvs_arith() == CVS_ARITH_CONTRACTED; }
 
+/* The tables themselves are host values (one copy per flavour row, built once); every device context gets its own copy in HBM
+ * the first time it asks -- lut_dev_gen records which generation of the host table that copy holds. */
 static pthread_mutex_t lut_lock = PTHREAD_MUTEX_INITIALIZER;
 static half *lut_host2[2][CVS_LUT_COUNT];
-static half *lut_dev2[2][CVS_LUT_COUNT];
-static unsigned lut_gen2[2][CVS_LUT_COUNT];
+static unsigned lut_gen2[2][CVS_LUT_COUNT];                            /* bumped whenever the host table changes (0: not built yet) */
+static half *lut_dev3[CVS_MAX_CONTEXTS][2][CVS_LUT_COUNT];
+static unsigned lut_dev_gen[CVS_MAX_CONTEXTS][2][CVS_LUT_COUNT];
 static uint8_t *ramp45;
 static float *codes_as_float;       /* h2f of 0..65535, computed once on the GPU */
 
@@ -147,14 +150,23 @@ static int ensure_codes(void) {
     return 0;
 }
 
+/* lut_lock held: a new host table (every context's device copy is now stale) */
 static int install_locked(int row, int which, const half *table) {
-    half **lut_host = lut_host2[row], **lut_dev = lut_dev2[row];
+    half **lut_host = lut_host2[row];
     if (!lut_host[which]) lut_host[which] = malloc(HALF_COUNT * sizeof(half));
     if (!lut_host[which]) return -1;
     if (table != lut_host[which]) memcpy(lut_host[which], table, HALF_COUNT * sizeof(half));
-    if (!lut_dev[which]) CVS_HIP(hipMalloc((void **)&lut_dev[which], HALF_COUNT * sizeof(half)));
-    CVS_HIP(hipMemcpy(lut_dev[which], lut_host[which], HALF_COUNT * sizeof(half), hipMemcpyHostToDevice));
     lut_gen2[row][which]++;
+    return 0;
+}
+
+/* lut_lock held, cvs_enter() done: the calling thread's context holds the current host table */
+static int upload_locked(int row, int which) {
+    const int c = cvs_ctx();
+    if (lut_dev3[c][row][which] && lut_dev_gen[c][row][which] == lut_gen2[row][which]) return 0;
+    if (!lut_dev3[c][row][which]) CVS_HIP(hipMalloc((void **)&lut_dev3[c][row][which], HALF_COUNT * sizeof(half)));
+    CVS_HIP(hipMemcpy(lut_dev3[c][row][which], lut_host2[row][which], HALF_COUNT * sizeof(half), hipMemcpyHostToDevice));
+    lut_dev_gen[c][row][which] = lut_gen2[row][which];
     return 0;
 }
 
@@ -178,7 +190,7 @@ static int ensure_lut(int which) {
     const int row = lut_row(which);
     pthread_mutex_lock(&lut_lock);
     int rc = 0;
-    if (!lut_dev2[row][which]) {
+    if (!lut_gen2[row][which]) {
         float (*fn[CVS_LUT_COUNT])(float, int) = { tf_rec709_to_linear, tf_rec709_display, tf_linear_to_rec709, tf_linear_to_srgb };
         rc = ensure_codes();
         if (rc == 0) {
@@ -193,11 +205,12 @@ static int ensure_lut(int which) {
             free(g); free(t);
         }
     }
+    if (rc == 0) rc = upload_locked(row, which);
     pthread_mutex_unlock(&lut_lock);
     return rc;
 }
 
-CVS_EXPORT const half *cvs_lut_device(int which) { return ensure_lut(which) == 0 ? lut_dev2[lut_row(which)][which] : NULL; }
+CVS_EXPORT const half *cvs_lut_device(int which) { return ensure_lut(which) == 0 ? lut_dev3[cvs_ctx()][lut_row(which)][which] : NULL; }
 CVS_EXPORT const half *cvs_lut_host(int which) { return ensure_lut(which) == 0 ? lut_host2[lut_row(which)][which] : NULL; }
 
 const half *cvs_lut_dev_or_null(int which) { return which == CVS_LUT_NONE ? NULL : cvs_lut_device(which); }
@@ -221,7 +234,7 @@ static void host_transfer(int which, half *out, const half *in, size_t count) {
     int rc = cvs_stage_in(&din, in, count * 2, 1, s);
     if (rc == 0) rc = cvs_stage_in(&dout, NULL, count * 2, 0, s);
     if (rc == 0) {
-        rc = cvk_half_lookup(lut_dev2[lut_row(which)][which], (uint16_t *)dout.dev, (const uint16_t *)din.dev, count, cvs_cus(), s);
+        rc = cvk_half_lookup(lut_dev3[cvs_ctx()][lut_row(which)][which], (uint16_t *)dout.dev, (const uint16_t *)din.dev, count, cvs_cus(), s);
         if (rc != 0) cvs_set_error("transfer kernel launch failed: %s", hipGetErrorString((hipError_t)rc));
     }
     if (rc == 0) cvs_stage_out(&dout, out, s);

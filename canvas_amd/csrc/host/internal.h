@@ -46,8 +46,14 @@ int cvs_capture_hold(hipStream_t st, void (*release)(void *), void *arg);
 int cvs_arith(void);
 #define CVK(name) (cvs_arith() ? name##_fma : name)
 
-/* binds the calling thread to the library's device; lazily initialises with CVS_DEVICE (default 0).
- * 0 on success. */
+/* Device contexts (runtime.c): the id of the context the calling thread's current call runs in -- set by cvs_enter().
+ * Whatever a file keeps ON the device for the library's own use (cached tables) is kept per context: arrays of
+ * CVS_MAX_CONTEXTS, indexed with cvs_ctx(). */
+#define CVS_MAX_CONTEXTS 64
+int cvs_ctx(void);
+
+/* binds the calling thread to its context's device (cvs_set_context, else the default context; lazily opens context 0 on
+ * CVS_DEVICE, default 0) and takes the snapshots of the call: context id, arithmetic flavour.  0 on success. */
 int cvs_enter(void);
 /* the stream to enqueue on: the caller's, or this thread's own when NULL */
 hipStream_t cvs_pick_stream(cvs_stream_t s);

@@ -13,16 +13,38 @@
 #include <stdarg.h>
 #include <time.h>
 
+/* ---- device contexts.  A context = one HIP device + everything the library keeps ON that device for its own use: the
+ * scratch pool (below), the transfer tables (halfconv.c), the FIR tap tables (scale.c), the byte tables (display.c), and one
+ * stream per calling thread.  A process starts with none; cvs_init(device) -- or the first entry point, with CVS_DEVICE --
+ * opens context 0 and makes it the DEFAULT: what every thread runs in that never chose another.  cvs_context_open(device)
+ * opens further ones (another GPU of the node -- or the same one again: two contexts on one device share nothing but the
+ * device), cvs_set_context() binds the calling thread.  One pull-queue worker per context is how an editor process uses the
+ * eight GPUs of a node (the reference's only frame-parallel consumer is its thread pool, src/process/VideoPullQueue.c:99-113):
+ * frames are independent, tables are small and rebuilt per context on first use, nothing is exchanged between devices.
+ * Device pointers belong to the context (device) they were allocated in; handing them to a call made in a context on another
+ * device is the caller's error. */
+#define POOL_SLOTS 256
+typedef struct { void *ptr; size_t bytes; hipStream_t stream; hipEvent_t ev; int live; uint64_t stamp; } pool_slot;
+typedef struct {
+    int device;                        /* HIP device ordinal */
+    int cus;
+    char name[640];
+    pool_slot pool[POOL_SLOTS];        /* the scratch pool of this context (see below) */
+    uint64_t pool_clock;
+    size_t pool_parked;                /* bytes sitting idle in the pool */
+} cvs_context;
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
-static int g_device = -1;
-static int g_cus = 256;
-static char g_name[640];
+static cvs_context g_ctx[CVS_MAX_CONTEXTS];
+static int g_nctx;                     /* contexts opened so far (ids 0 .. g_nctx - 1; never closed) */
+static int g_default_ctx = -1;         /* the context of threads that never called cvs_set_context */
+static __thread int t_ctx_choice = -1; /* this thread's cvs_set_context, -1: the default */
+static __thread int t_ctx = 0;         /* the context of the call this thread is in (snapshot by cvs_enter) */
+int cvs_ctx(void) { return t_ctx; }
 
 static int g_arith = -1;              /* CVS_ARITH_*; -1: not set yet (the environment decides at the first entry) */
 static __thread int t_arith;          /* the flavour of the call this thread is in */
 static __thread char t_error[512];
-static __thread hipStream_t t_stream;
-static __thread int t_stream_device = -1;
+static __thread hipStream_t t_streams[CVS_MAX_CONTEXTS];      /* this thread's own stream in each context it has called into */
 
 /* where diagnostics go besides cvs_last_error(): stderr unless the host installs a handler (the reference routes its
  * g_log domains to Python's logging the same way, src/process/main.c:272-329) */
@@ -66,37 +88,6 @@ CVS_EXPORT int cvs_device_count(void) {
     return n;
 }
 
-CVS_EXPORT int cvs_init(int device) {
-    pthread_mutex_lock(&g_lock);
-    if (g_device == device) { pthread_mutex_unlock(&g_lock); return hipSetDevice(device) == hipSuccess ? 0 : -1; }
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) {
-        pthread_mutex_unlock(&g_lock);
-        cvs_set_error("no HIP device available (%s); this library has no CPU path", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
-        return -1;
-    }
-    if (device < 0 || device >= n) {
-        pthread_mutex_unlock(&g_lock);
-        cvs_set_error("device %d out of range (0..%d)", device, n - 1);
-        return -1;
-    }
-    if ((e = hipSetDevice(device)) != hipSuccess) {
-        pthread_mutex_unlock(&g_lock);
-        cvs_set_error("hipSetDevice(%d): %s", device, hipGetErrorString(e));
-        return -1;
-    }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
-        g_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        /* some boxes report an empty marketing name */
-        snprintf(g_name, sizeof g_name, "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD GPU", prop.gcnArchName, prop.multiProcessorCount);
-    }
-    g_device = device;
-    pthread_mutex_unlock(&g_lock);
-    return 0;
-}
-
 static int arith_now(void) {
     int a = __atomic_load_n(&g_arith, __ATOMIC_RELAXED);
     if (a < 0) {
@@ -118,28 +109,106 @@ CVS_EXPORT int cvs_set_arithmetic(int mode) {
 CVS_EXPORT int cvs_get_arithmetic(void) { return arith_now(); }
 int cvs_arith(void) { return t_arith; }
 
+/* g_lock held.  A new context on `device`; its id, or -1 (message set). */
+static int open_context_locked(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        cvs_set_error("no HIP device available (%s); this library has no CPU path", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+        return -1;
+    }
+    if (device < 0 || device >= n) { cvs_set_error("device %d out of range (0..%d)", device, n - 1); return -1; }
+    if (g_nctx >= CVS_MAX_CONTEXTS) { cvs_set_error("no more than %d device contexts", CVS_MAX_CONTEXTS); return -1; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { cvs_set_error("hipSetDevice(%d): %s", device, hipGetErrorString(e)); return -1; }
+    cvs_context *c = &g_ctx[g_nctx];
+    memset(c, 0, sizeof *c);
+    c->device = device;
+    c->cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        /* some boxes report an empty marketing name */
+        snprintf(c->name, sizeof c->name, "%s (%s, %d CUs)", prop.name[0] ? prop.name : "AMD GPU", prop.gcnArchName, prop.multiProcessorCount);
+    }
+    return g_nctx++;
+}
+
+/* Binds the library (the default context) and the calling thread to HIP device `device`: the first context on that device, or
+ * a new one.  Idempotent per device. */
+CVS_EXPORT int cvs_init(int device) {
+    pthread_mutex_lock(&g_lock);
+    int id = -1;
+    for (int i = 0; i < g_nctx && id < 0; i++) if (g_ctx[i].device == device) id = i;
+    if (id < 0) id = open_context_locked(device);
+    if (id >= 0) g_default_ctx = id;
+    pthread_mutex_unlock(&g_lock);
+    if (id < 0) return -1;
+    t_ctx_choice = -1;
+    t_ctx = id;
+    return hipSetDevice(device) == hipSuccess ? 0 : -1;
+}
+
+CVS_EXPORT int cvs_context_open(int device) {
+    pthread_mutex_lock(&g_lock);
+    const int id = open_context_locked(device);
+    if (id >= 0 && g_default_ctx < 0) g_default_ctx = id;
+    pthread_mutex_unlock(&g_lock);
+    return id;
+}
+
+CVS_EXPORT int cvs_context_count(void) { return __atomic_load_n(&g_nctx, __ATOMIC_ACQUIRE); }
+
+CVS_EXPORT int cvs_context_device(int ctx) {
+    if (ctx < 0 || ctx >= cvs_context_count()) return -1;
+    return g_ctx[ctx].device;
+}
+
+CVS_EXPORT int cvs_current_context(void) { return t_ctx_choice >= 0 ? t_ctx_choice : __atomic_load_n(&g_default_ctx, __ATOMIC_ACQUIRE); }
+
+CVS_EXPORT int cvs_set_context(int ctx) {
+    const int before = cvs_current_context();
+    if (ctx >= cvs_context_count() || ctx < -1) { cvs_set_error("cvs_set_context: no context %d (%d open)", ctx, cvs_context_count()); return -2; }
+    t_ctx_choice = ctx;                                   /* -1: back to the default context */
+    return before;
+}
+
+/* round-robin owner of a frame among `nowners` devices / contexts / ranks: the sharding rule of the whole library
+ * (frames are independent random-access units; canvas_amd/shard.py uses the same rule across processes) */
+CVS_EXPORT int cvs_frame_owner(int64_t frame_index, int nowners) {
+    if (nowners <= 0) return -1;
+    const int64_t m = frame_index % nowners;
+    return (int)(m < 0 ? m + nowners : m);
+}
+
 int cvs_enter(void) {
     t_arith = arith_now();
-    if (g_device < 0) {
-        const char *env = getenv("CVS_DEVICE");
-        if (cvs_init(env ? atoi(env) : 0) != 0) return -1;
+    int id = t_ctx_choice;
+    if (id < 0) {
+        id = __atomic_load_n(&g_default_ctx, __ATOMIC_ACQUIRE);
+        if (id < 0) {
+            const char *env = getenv("CVS_DEVICE");
+            if (cvs_init(env ? atoi(env) : 0) != 0) return -1;
+            id = __atomic_load_n(&g_default_ctx, __ATOMIC_ACQUIRE);
+        }
     }
-    if (hipSetDevice(g_device) != hipSuccess) { cvs_set_error("hipSetDevice(%d) failed", g_device); return -1; }
+    t_ctx = id;
+    if (hipSetDevice(g_ctx[id].device) != hipSuccess) { cvs_set_error("hipSetDevice(%d) failed", g_ctx[id].device); return -1; }
     return 0;
 }
 
-CVS_EXPORT int cvs_current_device(void) { return g_device; }
-CVS_EXPORT const char *cvs_device_name(void) { return cvs_enter() == 0 ? g_name : ""; }
-CVS_EXPORT int cvs_compute_units(void) { return cvs_enter() == 0 ? g_cus : 0; }
-int cvs_cus(void) { return g_cus; }
+CVS_EXPORT int cvs_current_device(void) { const int c = cvs_current_context(); return c >= 0 ? g_ctx[c].device : -1; }
+CVS_EXPORT const char *cvs_device_name(void) { return cvs_enter() == 0 ? g_ctx[t_ctx].name : ""; }
+CVS_EXPORT int cvs_compute_units(void) { return cvs_enter() == 0 ? g_ctx[t_ctx].cus : 0; }
+int cvs_cus(void) { return g_ctx[t_ctx].cus; }
 
+static __thread char t_have_stream[CVS_MAX_CONTEXTS];
 hipStream_t cvs_pick_stream(cvs_stream_t s) {
     if (s) return (hipStream_t)s;
-    if (t_stream_device != g_device) {
-        if (hipStreamCreateWithFlags(&t_stream, hipStreamNonBlocking) != hipSuccess) t_stream = NULL;
-        t_stream_device = g_device;
+    if (!t_have_stream[t_ctx]) {                           /* (the thread is bound to the context's device: cvs_enter) */
+        if (hipStreamCreateWithFlags(&t_streams[t_ctx], hipStreamNonBlocking) != hipSuccess) t_streams[t_ctx] = NULL;
+        t_have_stream[t_ctx] = 1;
     }
-    return t_stream;
+    return t_streams[t_ctx];
 }
 
 CVS_EXPORT void *cvs_malloc(size_t bytes) {
@@ -219,14 +288,13 @@ CVS_EXPORT int cvs_stream_sync(cvs_stream_t s) {
  *     on a non-blocking stream still reads is what faulted.
  * A request is served by the smallest parked block of at least its size and at most 1/8 more (animated windows ask for a
  * slightly different size every frame); when the table is full the least recently parked block is evicted. */
-#define POOL_SLOTS 256
 #define GRAPH_BLOCKS 64
 typedef struct { void (*release)(void *); void *arg; } cvs_hold;
 static __thread struct { int active, overflow; hipStream_t stream; void *blocks[GRAPH_BLOCKS]; int n; cvs_hold holds[GRAPH_BLOCKS]; int nholds; } t_capture;
-typedef struct { void *ptr; size_t bytes; hipStream_t stream; hipEvent_t ev; int live; uint64_t stamp; } pool_slot;
-static pool_slot g_pool[POOL_SLOTS];
-static uint64_t g_pool_clock;
-static size_t g_pool_parked;                         /* bytes sitting idle in the pool */
+/* the pool of the context the calling thread's call runs in (g_lock covers every context's table) */
+#define g_pool (g_ctx[t_ctx].pool)
+#define g_pool_clock (g_ctx[t_ctx].pool_clock)
+#define g_pool_parked (g_ctx[t_ctx].pool_parked)
 static const size_t kPoolParkedMax = (size_t)8 << 30;
 
 static void release_to_driver(void *ptr, hipEvent_t ev) {      /* g_lock NOT held */

@@ -444,9 +444,15 @@ typedef struct {
 
 typedef struct { const float *taps; float factor, tmin, smin; int contracted; } axis_plan;    /* what the planner of the key's kind needs */
 
+/* The tables live on the device: one cache per device context (runtime.c), one lock over all of them. */
 #define AXIS_CACHE 128
-static axis_entry g_axis[AXIS_CACHE];
-static uint64_t g_axis_clock;
+#define AXIS_RETIRED 64
+typedef struct { axis_entry e[AXIS_CACHE]; uint64_t clock; char *retired[AXIS_RETIRED]; int nretired; } axis_cache;
+static axis_cache g_axis_of[CVS_MAX_CONTEXTS];
+#define g_axis (g_axis_of[cvs_ctx()].e)
+#define g_axis_clock (g_axis_of[cvs_ctx()].clock)
+#define g_retired (g_axis_of[cvs_ctx()].retired)
+#define g_nretired (g_axis_of[cvs_ctx()].nretired)
 static pthread_mutex_t g_axis_lock = PTHREAD_MUTEX_INITIALIZER;
 
 /* keys are compared with memcmp: build them from zeroed storage so that padding is defined */
@@ -570,9 +576,6 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
  * its block is parked here instead of freed; when the list is full ONE device-wide wait -- outside every lock -- makes all
  * of them free at once.  (The first version waited for the whole device under the cache lock on every eviction: an
  * animated zoom, which misses on every frame, stalled all streams and all pull-queue workers once per frame.) */
-#define AXIS_RETIRED 64
-static char *g_retired[AXIS_RETIRED];
-static int g_nretired;
 
 static void retire_block(char *dev) {           /* g_axis_lock NOT held */
     if (!dev) return;
@@ -602,7 +605,7 @@ static int axis_get_ex(const axis_key *key, const axis_plan *pl, cvk_fir_axis *o
         if (g_axis[i].valid && memcmp(&g_axis[i].key, key, sizeof *key) == 0) {
             g_axis[i].stamp = ++g_axis_clock;
             g_axis[i].pins++;
-            *pin = i;
+            *pin = cvs_ctx() * AXIS_CACHE + i;
             fill_from_entry(&g_axis[i], out, max_foot, used_lo, used_hi);
             pthread_mutex_unlock(&g_axis_lock);
             return 0;
@@ -636,14 +639,14 @@ static int axis_get_ex(const axis_key *key, const axis_plan *pl, cvk_fir_axis *o
         g_axis[slot].stamp = ++g_axis_clock;
         g_axis[slot].pins++;
         lost = fresh.dev;                                   /* never read by any kernel, still parked like the others */
-        *pin = slot;
+        *pin = cvs_ctx() * AXIS_CACHE + slot;
         fill_from_entry(&g_axis[slot], out, max_foot, used_lo, used_hi);
     } else if (victim >= 0) {
         axis_entry *e = &g_axis[victim];
         if (e->valid) evicted = e->dev;
         fresh.stamp = ++g_axis_clock;
         *e = fresh;
-        *pin = victim;
+        *pin = cvs_ctx() * AXIS_CACHE + victim;
         fill_from_entry(e, out, max_foot, used_lo, used_hi);
     }
     pthread_mutex_unlock(&g_axis_lock);
@@ -657,9 +660,11 @@ static int axis_get_ex(const axis_key *key, const axis_plan *pl, cvk_fir_axis *o
     return 0;
 }
 
+/* `slot`: context * AXIS_CACHE + entry (a graph may be destroyed by a thread bound to another context) */
 static void axis_unpin(void *slot) {
+    const int id = (int)(intptr_t)slot;
     pthread_mutex_lock(&g_axis_lock);
-    g_axis[(int)(intptr_t)slot].pins--;
+    g_axis_of[id / AXIS_CACHE].e[id % AXIS_CACHE].pins--;
     pthread_mutex_unlock(&g_axis_lock);
 }
 

@@ -359,6 +359,14 @@ static PyObject *mod_set_arithmetic(PyObject *self, PyObject *args) {
     return arith_name(cvs_set_arithmetic(mode));
 }
 
+static PyObject *mod_device_count(PyObject *self, PyObject *args) { return PyLong_FromLong(cvs_device_count()); }
+static PyObject *mod_frame_owner(PyObject *self, PyObject *args) {
+    long long frame; int n;
+    if (!PyArg_ParseTuple(args, "Li", &frame, &n)) return NULL;
+    if (n <= 0) { PyErr_SetString(PyExc_ValueError, "frame_owner: the number of owners must be positive"); return NULL; }
+    return PyLong_FromLong(cvs_frame_owner((int64_t)frame, n));
+}
+
 static PyMethodDef module_methods[] = {
     { "get_frame_time", mod_get_frame_time, METH_VARARGS, "get_frame_time(rate, frame) -> time in ns" },
     { "get_time_frame", mod_get_time_frame, METH_VARARGS, "get_time_frame(rate, time_ns) -> frame" },
@@ -370,6 +378,8 @@ static PyMethodDef module_methods[] = {
     { "check_context_supported", mod_check_context, METH_VARARGS, "True when a HIP device is available." },
     { "set_arithmetic", mod_set_arithmetic, METH_VARARGS, "set_arithmetic('separate' | 'contracted') -> previous mode: follow the reference's gcc build (default) or its clang build (fused multiply-adds)." },
     { "get_arithmetic", mod_get_arithmetic, METH_NOARGS, "The arithmetic mode in force: 'separate' or 'contracted'." },
+    { "device_count", mod_device_count, METH_NOARGS, "Number of HIP devices visible to this process (VideoPullQueue(devices=range(device_count())) uses them all)." },
+    { "frame_owner", mod_frame_owner, METH_VARARGS, "frame_owner(frame_index, n) -> which of n devices / contexts / ranks renders the frame: frame_index mod n." },
     { "last_error", mod_last_error, METH_NOARGS, "Last error message of the calling thread." },
     { "device_name", mod_device_name, METH_NOARGS, "Name of the HIP device in use." },
     { NULL }

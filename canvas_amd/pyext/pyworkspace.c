@@ -193,24 +193,31 @@ typedef struct pq_item {
                                      * inside one of its own callbacks) */
     rgba_frame_f16 *frame;
     int frame_index;
+    int owner;                      /* which of the queue's device contexts renders it: cvs_frame_owner(frame_index, ncontexts) */
     volatile int active;
 } py_pq_item;
 
 /* What the worker threads share.  It is NOT the Python object: the object can be deallocated on a worker thread (the last
  * reference dropped in a callback), and a worker must be able to go round its loop once more and leave.  The core is
  * reference-counted by the object and by every worker; the last one out frees it. */
+#define PQ_MAX 16
 typedef struct {
     pthread_mutex_t mutex;
     pthread_cond_t wake;
-    py_pq_item *head, *tail;
+    py_pq_item *head[PQ_MAX], *tail[PQ_MAX];       /* one list per device context of the queue (one in all without `devices`) */
+    int nctx;                                       /* lists in use */
+    int ctx[PQ_MAX];                                /* the library's context id of each (-1: the default context) */
     int quit, refs;
 } pq_core;
+
+typedef struct { pq_core *core; int list; } pq_worker_arg;
 
 typedef struct {
     PyObject_HEAD
     pq_core *core;
-    pthread_t workers[16];
+    pthread_t workers[PQ_MAX];
     int nworkers;
+    int devices[PQ_MAX];                            /* HIP device of each context (as given), for the `devices` attribute */
 } py_pullqueue;
 
 static PyTypeObject py_type_PullQueueItem;
@@ -223,14 +230,17 @@ static void pq_core_unref(pq_core *c) {
 }
 
 static void *pq_worker(void *arg) {
-    pq_core *q = arg;
+    pq_core *q = ((pq_worker_arg *)arg)->core;
+    const int me = ((pq_worker_arg *)arg)->list;                /* the list (= device context of the queue) this worker serves */
+    free(arg);
+    if (q->ctx[me] >= 0) cvs_set_context(q->ctx[me]);           /* every pull of this thread runs on that context's device */
     for (;;) {
         pthread_mutex_lock(&q->mutex);
-        while (!q->head && !q->quit) pthread_cond_wait(&q->wake, &q->mutex);
-        if (!q->head && q->quit) { pthread_mutex_unlock(&q->mutex); pq_core_unref(q); return NULL; }
-        py_pq_item *it = q->head;
-        q->head = it->next;
-        if (!q->head) q->tail = NULL;
+        while (!q->head[me] && !q->quit) pthread_cond_wait(&q->wake, &q->mutex);
+        if (!q->head[me] && q->quit) { pthread_mutex_unlock(&q->mutex); pq_core_unref(q); return NULL; }
+        py_pq_item *it = q->head[me];
+        q->head[me] = it->next;
+        if (!q->head[me]) q->tail[me] = NULL;
         pthread_mutex_unlock(&q->mutex);
 
         if (it->active) {                                   /* the pull itself runs without the GIL (VideoPullQueue.c:99-105) */
@@ -250,28 +260,69 @@ static void *pq_worker(void *arg) {
     }
 }
 
-/* VideoPullQueue(workers=2): each worker thread pulls on its own HIP stream (the library binds one stream per
- * thread), so `workers` frames are in flight on the device at a time; 2 is the reference's pool size
- * (VideoPullQueue.c:110). */
+/* VideoPullQueue(workers=2, devices=None): each worker thread pulls on its own HIP stream (the library binds one stream per
+ * thread), so `workers` frames are in flight at a time; 2 is the reference's pool size (VideoPullQueue.c:110).
+ * devices: a sequence of HIP device ordinals, e.g. range(8) on a node of eight GPUs.  The queue opens one device context of the
+ * library per entry (cvs_context_open: its own scratch pool and table caches; naming a device twice gives two contexts on it),
+ * binds worker w to context w % len(devices) and hands frame g to context g % len(devices) (cvs_frame_owner) -- the
+ * frame-to-GPU rule of the whole build, inside one process.  The graph needs nothing done to it: its parameters are host
+ * values, and every context builds the tables it needs on first use.  workers must be at least len(devices).  Without
+ * `devices` every worker runs in the default context, as before. */
 static int pq_init(py_pullqueue *self, PyObject *args, PyObject *kw) {
-    static char *kwlist[] = { "workers", NULL };
+    static char *kwlist[] = { "workers", "devices", NULL };
     int workers = 2;
-    if (!PyArg_ParseTupleAndKeywords(args, kw, "|i", kwlist, &workers)) return -1;
-    if (workers < 1 || workers > 16) { PyErr_SetString(PyExc_ValueError, "workers must be between 1 and 16"); return -1; }
+    PyObject *devices = NULL;
+    if (!PyArg_ParseTupleAndKeywords(args, kw, "|iO", kwlist, &workers, &devices)) return -1;
+    if (workers < 1 || workers > PQ_MAX) { PyErr_SetString(PyExc_ValueError, "workers must be between 1 and 16"); return -1; }
     if (self->core) { PyErr_SetString(PyExc_RuntimeError, "VideoPullQueue is already initialised"); return -1; }
+    int ndev = 0, dev[PQ_MAX];
+    if (devices && devices != Py_None) {
+        PyObject *seq = PySequence_Fast(devices, "devices must be a sequence of HIP device ordinals");
+        if (!seq) return -1;
+        const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+        if (n < 1 || n > PQ_MAX || n > workers) { Py_DECREF(seq); PyErr_SetString(PyExc_ValueError, "devices: between 1 and `workers` entries (at most 16)"); return -1; }
+        for (Py_ssize_t i = 0; i < n; i++) {
+            const long d = PyLong_AsLong(PySequence_Fast_GET_ITEM(seq, i));
+            if (d == -1 && PyErr_Occurred()) { Py_DECREF(seq); return -1; }
+            dev[ndev++] = (int)d;
+        }
+        Py_DECREF(seq);
+    }
     pq_core *c = calloc(1, sizeof *c);
     if (!c) { PyErr_NoMemory(); return -1; }
+    c->nctx = 1;
+    c->ctx[0] = -1;
+    self->devices[0] = -1;
+    if (ndev) {
+        for (int i = 0; i < ndev; i++) {
+            c->ctx[i] = cvs_context_open(dev[i]);
+            self->devices[i] = dev[i];
+            if (c->ctx[i] < 0) { free(c); PyErr_Format(PyExc_RuntimeError, "VideoPullQueue: no context on device %d: %s", dev[i], cvs_last_error()); return -1; }
+        }
+        c->nctx = ndev;
+    }
     pthread_mutex_init(&c->mutex, NULL);
     pthread_cond_init(&c->wake, NULL);
     c->refs = 1;                                            /* the object's */
     self->core = c;
     for (int i = 0; i < workers; i++) {
+        pq_worker_arg *a = malloc(sizeof *a);
+        if (!a) break;
+        a->core = c; a->list = i % c->nctx;
         pthread_mutex_lock(&c->mutex); c->refs++; pthread_mutex_unlock(&c->mutex);
-        if (pthread_create(&self->workers[self->nworkers], NULL, pq_worker, c) == 0) self->nworkers++;
-        else { pthread_mutex_lock(&c->mutex); c->refs--; pthread_mutex_unlock(&c->mutex); }
+        if (pthread_create(&self->workers[self->nworkers], NULL, pq_worker, a) == 0) self->nworkers++;
+        else { free(a); pthread_mutex_lock(&c->mutex); c->refs--; pthread_mutex_unlock(&c->mutex); }
     }
-    if (!self->nworkers) { PyErr_SetString(PyExc_RuntimeError, "could not start worker threads"); return -1; }
+    if (self->nworkers < c->nctx) { PyErr_SetString(PyExc_RuntimeError, "could not start a worker thread for every device"); return -1; }
     return 0;
+}
+/* .devices: the HIP device of each of the queue's contexts (an empty tuple: the default context); .contexts: their ids */
+static PyObject *pq_get_devices(py_pullqueue *self, void *closure) {
+    const pq_core *c = self->core;
+    const int n = c && c->ctx[0] >= 0 ? c->nctx : 0;
+    PyObject *t = PyTuple_New(n);
+    for (int i = 0; t && i < n; i++) PyTuple_SET_ITEM(t, i, PyLong_FromLong(closure ? c->ctx[i] : self->devices[i]));
+    return t;
 }
 static void pq_dealloc(py_pullqueue *self) {
     pq_core *c = self->core;
@@ -306,10 +357,12 @@ static PyObject *pq_enqueue(py_pullqueue *self, PyObject *args, PyObject *kw) {
     it->callback = callback; it->user_data = user_data; it->queue = (PyObject *)self; it->frame_index = frame_index; it->active = 1;
     Py_INCREF(it);                                          /* one reference for the queue, one for the caller */
     pq_core *c = self->core;
+    const int list = cvs_frame_owner(frame_index, c->nctx);
+    it->owner = list;
     pthread_mutex_lock(&c->mutex);
-    if (c->tail) c->tail->next = it; else c->head = it;
-    c->tail = it;
-    pthread_cond_signal(&c->wake);
+    if (c->tail[list]) c->tail[list]->next = it; else c->head[list] = it;
+    c->tail[list] = it;
+    pthread_cond_broadcast(&c->wake);                       /* (the workers of one list are the ones that can take it) */
     pthread_mutex_unlock(&c->mutex);
     return (PyObject *)it;
 }
@@ -319,20 +372,31 @@ static void pq_item_dealloc(py_pq_item *self) {
     py_video_take_source(NULL, &self->source);
     Py_TYPE(self)->tp_free((PyObject *)self);
 }
+static PyObject *pq_item_get_owner(py_pq_item *self, void *closure) { return PyLong_FromLong(self->owner); }
+static PyGetSetDef pq_item_getset[] = {
+    { "owner", (getter)pq_item_get_owner, NULL, "Index (into the queue's `devices`) of the device context that renders this frame: frame_index % len(devices).", NULL },
+    { NULL }
+};
 static PyMethodDef pq_item_methods[] = { { "cancel", (PyCFunction)pq_item_cancel, METH_NOARGS, "Drop the request: the callback will not run." }, { NULL } };
 static PyTypeObject py_type_PullQueueItem = {
     PyVarObject_HEAD_INIT(NULL, 0)
     .tp_name = "fluggo.media.process.VideoPullQueueItem", .tp_basicsize = sizeof(py_pq_item), .tp_flags = Py_TPFLAGS_DEFAULT,
-    .tp_dealloc = (destructor)pq_item_dealloc, .tp_methods = pq_item_methods,
+    .tp_dealloc = (destructor)pq_item_dealloc, .tp_methods = pq_item_methods, .tp_getset = pq_item_getset,
 };
 static PyMethodDef pq_methods[] = {
     { "enqueue", (PyCFunction)pq_enqueue, METH_VARARGS | METH_KEYWORDS, "enqueue(source, frame_index, window, callback, user_data) -> item" },
+    { NULL }
+};
+static PyGetSetDef pq_getset[] = {
+    { "devices", (getter)pq_get_devices, NULL, "HIP device ordinal of each of the queue's device contexts (empty: the default context).", NULL },
+    { "contexts", (getter)pq_get_devices, NULL, "The library's context id of each entry of `devices`.", (void *)1 },
     { NULL }
 };
 static PyTypeObject py_type_PullQueue = {
     PyVarObject_HEAD_INIT(NULL, 0)
     .tp_name = "fluggo.media.process.VideoPullQueue", .tp_basicsize = sizeof(py_pullqueue), .tp_flags = Py_TPFLAGS_DEFAULT,
     .tp_new = PyType_GenericNew, .tp_init = (initproc)pq_init, .tp_dealloc = (destructor)pq_dealloc, .tp_methods = pq_methods,
+    .tp_getset = pq_getset,
 };
 
 int init_workspace(PyObject *module) {

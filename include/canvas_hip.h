@@ -241,7 +241,25 @@ CVS_EXPORT int cvs_get_arithmetic(void);
 
 CVS_EXPORT int cvs_init(int device);                   /* 0 on success; idempotent per device */
 CVS_EXPORT int cvs_device_count(void);
-CVS_EXPORT int cvs_current_device(void);
+CVS_EXPORT int cvs_current_device(void);               /* HIP device of the calling thread's context, -1 before any */
+
+/* Device contexts: several GPUs in one process.  A context is one HIP device plus everything the library keeps on it (scratch
+ * pool, cached transfer / tap / byte tables, one stream per calling thread).  cvs_init(device) opens -- or finds -- a context
+ * on `device` and makes it the DEFAULT: what every thread runs in that never chose another (and all a single-GPU host ever
+ * needs).  cvs_context_open(device) opens a further one, on another GPU of the node or on the same one again (two contexts on
+ * one device share nothing but the device); its id (0 .. 63) or -1.  cvs_set_context(ctx) binds the calling thread (-1: back to
+ * the default) and returns what it was bound to (-2 for an unknown id, nothing changes).  Every entry point runs in the calling
+ * thread's context; frames, streams and events belong to the context (device) they were created in.
+ * Frames are independent random-access units (docs/sphinx/framework.rst:16-18): a host shards by giving frame g to context
+ * cvs_frame_owner(g, n) -- one thread per context, as the reference's pull queue gives frames to its pool threads
+ * (src/process/VideoPullQueue.c:99-113); the graph's parameters are host values and every context builds the device tables it
+ * needs on first use.  Nothing is exchanged between devices. */
+CVS_EXPORT int cvs_context_open(int device);
+CVS_EXPORT int cvs_context_count(void);
+CVS_EXPORT int cvs_context_device(int ctx);
+CVS_EXPORT int cvs_set_context(int ctx);
+CVS_EXPORT int cvs_current_context(void);
+CVS_EXPORT int cvs_frame_owner(int64_t frame_index, int nowners);        /* frame_index mod nowners (non-negative); -1 for nowners <= 0 */
 CVS_EXPORT const char *cvs_last_error(void);
 CVS_EXPORT void cvs_clear_last_error(void);                                           /* forget the calling thread's message */
 /* Diagnostics: every failure message (the text of cvs_last_error) is also handed to the installed handler, or written to

@@ -395,3 +395,22 @@ def test_forced_pull_of_a_source_without_a_device_slot_is_empty(lib):
         fn(C.byref(src), 3, out.ref())
         assert out.current_window.is_empty()
     assert called == []
+
+
+def test_frame_to_device_rule_and_contexts_without_a_device(lib):
+    """Several GPUs in one process: frame g belongs to context g mod n -- the same rule canvas_amd/shard.py
+    uses across processes -- and a context cannot be chosen before it exists.  No device is needed for either."""
+    from canvas_amd import shard
+    for n in (1, 2, 3, 4, 8):
+        owners = [lib.cvs_frame_owner(g, n) for g in range(-8, 40)]
+        assert owners == [g % n for g in range(-8, 40)]
+        for r in range(n):
+            mine = [g for g in range(40) if lib.cvs_frame_owner(g, n) == r]
+            assert mine == shard.frames_of_rank(r, n, len(mine)) and all(shard.owner_of_frame(g, n) == r for g in mine)
+    assert lib.cvs_frame_owner(5, 0) == -1
+    count = lib.cvs_context_count()
+    assert lib.cvs_set_context(count + 3) == -2 and "no context" in _lib.last_error()
+    if lib.cvs_device_count() == 0:
+        assert count == 0 and lib.cvs_current_context() == -1 and lib.cvs_current_device() == -1
+        assert lib.cvs_context_open(0) == -1 and "no CPU path" in _lib.last_error()
+        assert lib.cvs_context_count() == 0

@@ -2542,3 +2542,109 @@ def test_scratch_memory_comes_back(cvs, orc):
     cvs.cvs_pool_trim()
     after = free_bytes()
     assert before - after < 64 << 20, (before, after)        # the tap-table cache holds at most 16 small tables
+
+
+# ------------------------------------------------------------------ device contexts: several GPUs (or one, several times) in one process
+
+def _every_cached_table_once(cvs, orc, seed):
+    """One call of each kind that builds a table ON the device (transfer table, FIR tap tables, byte table) plus the chain and
+    a pooled intermediate; returns what each produced, checked against the oracle by the caller."""
+    rng = np.random.default_rng(seed)
+    w, h = 96, 54
+    full = (0, 0, w - 1, h - 1)
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    layers = [rand_f16_frame(rng, full, full, alpha="one" if k == 0 else "rand") for k in range(2)]
+    want_chain = orc.chain_color_over(layers, m, orc.transfer_table(0), None)
+    dl = [DeviceFrame.from_host(l) for l in layers]
+    out = DeviceFrame(full, np.uint16)
+    chain_color_over([(out, dl)], m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE)
+    assert_same_f16(out.download().array, want_chain.array, "chain")
+    # the triangle scaler: two cached tap tables
+    src32 = HostFrame(full, np.float32, orc.half_to_float(layers[1].array))
+    want = HostFrame((0, 0, 2 * w - 1, 2 * h - 1), np.float32)
+    orc.lib().orc_scale_bilinear_f32(want.ref(), v2f(0, 0), src32.ref(), v2f(0, 0), v2f(2.0, 2.0))
+    big = DeviceFrame((0, 0, 2 * w - 1, 2 * h - 1), np.uint16)
+    _lib.check(cvs.cvs_scale_bilinear_f16_dev(big.ref(), v2f(0, 0), dl[1].ref(), v2f(0, 0), v2f(2.0, 2.0), None))
+    assert_same_f16(big.download().array, orc.float_to_half(want.array), "scaler")
+    # config 3 (pooled scratch on the fallback paths, the Lanczos taps)
+    taps = synth.gaussian_taps(9, 1.5)
+    want3 = _oracle_config3(orc, layers[1], (w // 2, h // 2), taps, 0.5, 0.5)
+    small = DeviceFrame((0, 0, w // 2 - 1, h // 2 - 1), np.uint16)
+    _lib.check(cvs.cvs_blur_lanczos_f16_dev(small.ref(), dl[1].ref(), f32p(taps), 9, C.c_float(0.5), C.c_float(0.5), 3, None))
+    assert_same_f16(small.download().array, want3.array, "config 3")
+    # the display edge: a byte table composed from a transfer table
+    want_bytes = np.empty((h, w), np.uint32)
+    orc.lib().orc_frame_to_bytes(want_bytes.ctypes.data_as(C.POINTER(C.c_uint32)), layers[1].ref(), u16p(orc.transfer_table(3)), 0)
+    dev_bytes = cvs.cvs_pool_malloc(w * h * 4, None)
+    _lib.check(cvs.cvs_frame_to_bytes_dev(dev_bytes, dl[1].ref(), _lib.LUT_LINEAR_TO_SRGB, _lib.DISPLAY_RGBA8, None))
+    got_bytes = np.empty((h, w), np.uint32)
+    _lib.check(cvs.cvs_memcpy_d2h(got_bytes.ctypes.data, dev_bytes, w * h * 4, None))
+    cvs.cvs_pool_free(dev_bytes, None)
+    assert np.array_equal(got_bytes, want_bytes), "frame to bytes"
+    for d in dl + [out, big, small]:
+        d.free()
+    return cvs.cvs_lut_device(_lib.LUT_REC709_TO_LINEAR_SCENE)
+
+
+def test_device_contexts_keep_their_own_tables_and_pools(cvs, orc):
+    """library state keyed by device.  On a one-GPU box two EXTRA contexts on device 0 stand in for two more
+    GPUs: each must build its own transfer / tap / byte tables and scratch pool on first use (different device addresses), give
+    the oracle's pixels, and leave the default context as it was."""
+    assert cvs.cvs_current_context() >= 0
+    home = cvs.cvs_current_context()
+    table_home = _every_cached_table_once(cvs, orc, 1)
+    a, b = cvs.cvs_context_open(0), cvs.cvs_context_open(0)
+    assert a >= 0 and b >= 0 and len({home, a, b}) == 3, _lib.last_error()
+    assert cvs.cvs_context_device(a) == 0 and cvs.cvs_context_device(b) == 0 and cvs.cvs_context_count() >= 3
+    seen = {home: table_home}
+    try:
+        for ctx, seed in ((a, 2), (b, 3), (a, 4)):
+            assert cvs.cvs_set_context(ctx) in (home, a, b)
+            assert cvs.cvs_current_context() == ctx and cvs.cvs_current_device() == 0
+            table = _every_cached_table_once(cvs, orc, seed)
+            assert seen.setdefault(ctx, table) == table          # the same context: the same table, built once
+        assert len(set(seen.values())) == 3                      # three contexts: three copies in HBM
+    finally:
+        assert cvs.cvs_set_context(-1) in (a, b)
+    assert cvs.cvs_current_context() == home
+    assert _every_cached_table_once(cvs, orc, 5) == table_home
+
+
+def test_one_thread_per_context_renders_its_own_frames(cvs, orc):
+    """Frame g belongs to context cvs_frame_owner(g, n); one thread per context (what VideoPullQueue(devices=...) does): the
+    threads run at the same time, each in its own pool, caches and stream, and every frame equals the oracle's."""
+    import threading
+    ctxs = [cvs.cvs_context_open(0) for _ in range(2)]
+    assert min(ctxs) >= 0
+    frames = list(range(12))
+    m = np.array(REC709_RGB_TO_YPBPR, np.float32)
+    w, h = 160, 90
+    want = {g: orc.chain_color_over([synth.layer_frame(w, h, k, g) for k in range(2)], m, orc.transfer_table(0), None).array for g in frames}
+    arith = cvs.cvs_get_arithmetic()
+    got, errors = {}, []
+
+    def worker(slot):
+        try:
+            assert cvs.cvs_set_context(ctxs[slot]) >= -1
+            for g in frames:
+                if cvs.cvs_frame_owner(g, len(ctxs)) != slot:
+                    continue
+                assert cvs.cvs_current_context() == ctxs[slot] and cvs.cvs_get_arithmetic() == arith
+                dl = [DeviceFrame.from_host(synth.layer_frame(w, h, k, g)) for k in range(2)]
+                out = DeviceFrame((0, 0, w - 1, h - 1), np.uint16)
+                chain_color_over([(out, dl)], m, _lib.LUT_REC709_TO_LINEAR_SCENE, _lib.LUT_NONE)
+                got[g] = out.download().array
+                for d in dl + [out]:
+                    d.free()
+        except Exception as e:                                   # noqa: BLE001
+            errors.append((slot, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(len(ctxs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert sorted(got) == frames
+    for g in frames:
+        assert_same_f16(got[g], want[g], "frame %d on context %d" % (g, g % len(ctxs)))

@@ -345,3 +345,20 @@ def test_reference_own_frame_function_tests_run_unmodified(process):
     assert mod.process is process                       # it imported fluggo.media.process from this repo
     result = unittest.TextTestRunner(stream=open(os.devnull, "w")).run(unittest.defaultTestLoader.loadTestsFromModule(mod))
     assert result.testsRun >= 3 and result.wasSuccessful(), (result.failures, result.errors)
+
+
+def test_frame_owner_and_arithmetic_functions(process):
+    """Added beside the reference's surface in round 4: the frame-to-device rule and the arithmetic flavour switch."""
+    assert [process.frame_owner(g, 4) for g in range(-2, 9)] == [g % 4 for g in range(-2, 9)]
+    with pytest.raises(ValueError):
+        process.frame_owner(3, 0)
+    assert isinstance(process.device_count(), int)
+    before = process.get_arithmetic()
+    assert before in ("separate", "contracted")
+    try:
+        assert process.set_arithmetic("contracted") == before
+        assert process.get_arithmetic() == "contracted"
+        with pytest.raises(ValueError):
+            process.set_arithmetic("fast")
+    finally:
+        process.set_arithmetic(before)

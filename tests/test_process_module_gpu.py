@@ -610,3 +610,36 @@ def test_random_graphs_f16_pull_equals_truncated_f32_pull(process, bt, orc):
                 # fold zero signs and NaNs the way tests/util.py does
                 same = np.array_equal(got, want) or all((g == w) or ((g & 0x7FFF) == 0 and (w & 0x7FFF) == 0) or ((g & 0x7FFF) > 0x7C00 and (w & 0x7FFF) > 0x7C00) for g, w in zip(got, want))
                 assert same, (case, frame, x, y, got, want)
+
+
+def test_pull_queue_over_device_contexts(process, bt):
+    """VideoPullQueue(workers=N, devices=[...]): one device context per entry (two entries naming device 0 = two contexts on
+    the one GPU of this box), worker w bound to context w % G, frame g rendered by context g % G -- and the frames are the ones
+    a direct pull gives."""
+    assert process.device_count() >= 1
+    assert [process.frame_owner(g, 2) for g in range(5)] == [0, 1, 0, 1, 0]
+    with pytest.raises(ValueError):
+        process.VideoPullQueue(workers=1, devices=[0, 0])       # fewer workers than devices
+    q = process.VideoPullQueue(workers=4, devices=[0, 0])
+    assert q.devices == (0, 0) and len(set(q.contexts)) == 2 and min(q.contexts) >= 0
+    assert process.VideoPullQueue().devices == ()
+    red, green = ramp(process, 0), ramp(process, 1)
+    graph = process.VideoMixFilter(src_a=red, src_b=process.VideoGainOffsetFilter(green, gain=0.5, offset=0.25), mix_b=0.25)
+    window = bt.box2i(0, 0, 15, 8)
+    want = {g: graph.get_frame_f16(g, window) for g in range(16)}
+    done, got = threading.Event(), {}
+
+    def callback(frame_index, frame, user_data):
+        got[frame_index] = frame
+        if len(got) == 16:
+            done.set()
+
+    items = [q.enqueue(source=graph, frame_index=g, window=window, callback=callback, user_data=None) for g in range(16)]
+    assert [it.owner for it in items] == [g % 2 for g in range(16)]
+    assert done.wait(60), "callbacks did not arrive"
+    for g in range(16):
+        assert got[g].current_window == want[g].current_window
+        for y in (0, 4, 8):
+            for x in (0, 7, 15):
+                almost(got[g].pixel(x, y), want[g].pixel(x, y), 7)
+    del items
