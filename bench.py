@@ -173,17 +173,18 @@ def main():
 
     # stdout carries exactly ONE line, the JSON result: libraries that write banners there (RCCL prints its version,
     # host name and library path on communicator creation) are sent to stderr until the result is ready
-    sys.stdout.flush()
-    try:
-        real_stdout = os.dup(1)
-        os.dup2(2, 1)
-    except OSError:                     # no usable stderr: leave stdout alone
-        real_stdout = None
+    result = launch.ResultOnly().__enter__()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    if world > 1:
+        launch.tag_own_stderr(rank)         # "[rank r] " in front of every stderr line (no-op under this script's own launcher, which tags)
+    # host placement, BEFORE the first HIP call: each rank on the CPUs local to its GPU (canvas_amd/launch.py place_rank)
+    placement = launch.place_rank(local_rank, world)
+    if world > 1:
+        sys.stderr.write("rank %d of %d: GPU %d, host placement: %s\n" % (rank, world, local_rank, json.dumps(placement)))
 
     dist = None
     # CANVAS_FORCE_DIST=1 takes the multi-process path at world size 1 too (rehearsal of the RCCL code on one GPU)
@@ -322,7 +323,9 @@ def main():
             "config": {"workload": "%dx%d f16 RGBA, Rec.709->linear LUT + RGB->Y'PbPr 3x3 on %d layers + %d-layer alpha-over, f16 out" % (w, h, nl, nl),
                        "storage": "rgba_f16 (8 B per pixel) in and out, f32 arithmetic in registers",
                        "frames_per_step_per_gpu": args.batch, "ring_frames_per_gpu": len(ring),
-                       "sharding": "frame g -> gpu g %% %d, no data-path collective" % world},
+                       "sharding": "frame g -> gpu g %% %d, no data-path collective" % world,
+                       "host_placement_rank0": placement,
+                       "collectives": "none" if dist is None else "%s: one broadcast of the parameter block, one all-gather of per-rank results per record" % dist.get_backend()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_chain<%d layers, grade, pre-LUT>" % nl,
@@ -350,12 +353,7 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds, native_oracle)
             except Exception as e:
                 res["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 0, "kind": "port", "sample": "failed: %s" % e}
-        sys.stdout.flush()
-        if real_stdout is not None:
-            os.dup2(real_stdout, 1)
-        print(json.dumps(res), flush=True)
-        if real_stdout is not None:
-            os.dup2(2, 1)
+        result.emit(json.dumps(res))
 
     if dist is not None:
         dist.barrier()

@@ -129,3 +129,83 @@ def test_checksum52_fits_a_float64():
     d = "f" * 64
     v = shard.checksum52(d)
     assert v == (1 << 52) - 1 and float(v) == v
+
+
+# ---------------------------------------------------------------- eight ranks on one host
+
+WORKER8 = textwrap.dedent("""
+    import os, sys, json
+    import numpy as np
+    sys.path.insert(0, %(root)r)
+    from canvas_amd import launch, shard
+    from tests.test_shard_gloo import FakeStore
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    with launch.ResultOnly() as out:
+        os.write(1, ("NCCL version 2.x banner of rank %%d on fd 1\\n" %% rank).encode())      # what RCCL does on communicator creation
+        sys.stderr.write("rank %%d says hello\\n" %% rank)
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        table = np.random.default_rng(5).integers(0, 65536, 65536).astype(np.uint16)
+        store = FakeStore({0: table}) if rank == 0 else FakeStore()
+        m = shard.broadcast_parameters(store, dist, rank, np.arange(9, dtype=np.float32), [0])
+        ok = bool(np.array_equal(m, np.arange(9, dtype=np.float32))) and (rank == 0 or bool(np.array_equal(store.installed[0], table)))
+        mine = shard.frames_of_rank(rank, world, 4)
+        stats = shard.gather_stats(dist, len(mine), sum(mine), 0.1, extra=(float(ok),))
+        print("stray print of rank %%d" %% rank)                     # a library printing through Python's stdout: also not the result
+        if rank == 0:
+            out.emit(json.dumps({"world": world, "frames_per_rank": [s[0] for s in stats], "sums": [s[1] for s in stats], "ok": [s[3] for s in stats]}))
+        dist.barrier()
+        dist.destroy_process_group()
+""")
+
+
+def test_eight_ranks_one_result_line_and_tagged_stderr(tmp_path):
+    """`bench.py --gpus 8` as the driver will see it, rehearsed on CPU: eight ranks through the launcher's own spawn_ranks,
+    gloo in RCCL's place, every rank writing a banner to file descriptor 1 -- the launcher's stdout must carry exactly ONE
+    line (rank 0's result), and every stderr line must say which rank wrote it."""
+    import json
+    script = tmp_path / "worker8.py"
+    script.write_text(WORKER8 % {"root": ROOT})
+    driver = tmp_path / "driver.py"
+    driver.write_text("import sys\nsys.path.insert(0, %r)\nfrom canvas_amd import launch\nrc, _ = launch.spawn_ranks(8, [sys.executable, %r], timeout=400)\nsys.exit(rc)\n" % (ROOT, str(script)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, str(driver)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    res = json.loads(lines[0])
+    assert res["world"] == 8 and res["frames_per_rank"] == [4] * 8 and res["ok"] == [1.0] * 8
+    assert res["sums"] == [sum(shard.frames_of_rank(r, 8, 4)) for r in range(8)]
+    for r in range(8):
+        assert "[rank %d] rank %d says hello" % (r, r) in p.stderr
+        assert "[rank %d] NCCL version 2.x banner of rank %d on fd 1" % (r, r) in p.stderr
+        assert "[rank %d] stray print of rank %d" % (r, r) in p.stderr
+    assert all(l.startswith("[rank ") for l in p.stderr.splitlines() if l.strip())
+
+
+def test_rank_placement_from_a_sysfs_tree(tmp_path):
+    """place_rank reads the KFD topology and the PCI device of the rank's GPU from sysfs (no HIP call): two GPUs on node 0,
+    two on node 1 of a made-up tree -> each rank gets the CPUs local to its GPU, shared with its node mate."""
+    from canvas_amd import launch
+    root = tmp_path / "sys"
+    gpus = [(0x0300, 0, "0-3"), (0x0400, 0, "0-3"), (0x8300, 1, "4-7"), (0x8400, 1, "4-7")]
+    nodes = root / "class" / "kfd" / "kfd" / "topology" / "nodes"
+    (nodes / "0").mkdir(parents=True)
+    (nodes / "0" / "properties").write_text("cpu_cores_count 8\nsimd_count 0\n")           # the CPU node: not a GPU
+    for i, (loc, numa, cpus) in enumerate(gpus):
+        (nodes / str(i + 1)).mkdir()
+        (nodes / str(i + 1) / "properties").write_text("cpu_cores_count 0\nsimd_count 1024\nlocation_id %d\ndomain 0\n" % loc)
+        dev = root / "bus" / "pci" / "devices" / ("0000:%02x:%02x.%d" % ((loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7))
+        dev.mkdir(parents=True)
+        (dev / "numa_node").write_text("%d\n" % numa)
+        (dev / "local_cpulist").write_text(cpus + "\n")
+    assert launch.gpu_numa_cpus(2, str(root)) == {"numa_node": 1, "pci": "0000:83:00.0", "cpus": {4, 5, 6, 7}}
+    assert launch.gpu_numa_cpus(7, str(root)) is None
+    if len(os.sched_getaffinity(0)) >= 8 and set(range(8)) <= os.sched_getaffinity(0):
+        before = os.sched_getaffinity(0)
+        try:
+            got = launch.place_rank(3, 4, str(root))
+            assert got["numa_node"] == 1 and os.sched_getaffinity(0) == {6, 7}, got     # node 1's second rank: the second half of 4-7
+        finally:
+            os.sched_setaffinity(0, before)
+    assert launch.place_rank(0, 1, str(root))["method"].startswith("none")
