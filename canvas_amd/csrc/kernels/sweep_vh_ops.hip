@@ -33,6 +33,17 @@
 #include "sweep_common.hpp"
 #include "gather_common.hpp"
 
+#if defined(CVS_DIAG) && !defined(CVS_CONTRACT)
+#define CVS_VH_PROBES 1
+// timing probes (diagnostic build only): per workgroup, the shader clock at set-up start, after the tap lists and the first
+// record, after the first row has landed in the window, at the first store, and at the end -> tools/vh_clocks.py
+__device__ unsigned long long *g_vh_clocks;
+extern "C" __attribute__((visibility("default"))) int cvk_fir_vh_clock_buffer(void *dev) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_vh_clocks), &dev, sizeof dev); }
+#define CVS_VH_CLOCK(slot) do { if (g_vh_clocks && threadIdx.x == 0) g_vh_clocks[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CVS_VH_CLOCK(slot) do { } while (0)
+#endif
+
 namespace {
 
 using cvs::f32x2;
@@ -50,6 +61,7 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
     constexpr int kStrip = kLanes * PXL;                                 // target columns per workgroup
     __shared__ float4 mid[kZero + 1];
     const int lane = threadIdx.x;
+    CVS_VH_CLOCK(0);
     // the lane's columns: halfs out -> the adjacent pair 2 lane, 2 lane + 1 (one 16-byte store); floats out -> lane and
     // lane + 64 (two 16-byte stores, each contiguous across the wave)
     constexpr bool out_half = INH;                                       // (both frames of a scaler call have the caller's format)
@@ -93,6 +105,10 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
         }
     }
     if (lane == 0) mid[kZero] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#ifdef CVS_VH_PROBES
+    { float acc = 0.0f; _Pragma("unroll") for (int p = 0; p < PXL; p++) { _Pragma("unroll") for (int k = 0; k < MAXTH; k++) acc += wt[p][k] + (float)aoff[p][k]; } asm volatile("" :: "v"(acc)); }
+#endif
+    CVS_VH_CLOCK(1);                                                     // the tap lists have landed
     const bool all_live = fp.tx0 + ((int)blockIdx.x + 1) * kStrip - 1 <= fp.tx1;      // (uniform) every lane's columns exist
 
     constexpr uint32_t tpx = out_half ? 8 : 16;
@@ -125,6 +141,7 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
             if ((int)r[0] > 0) { s_hi = (int)r[1] + min((int)r[0], W) - 1; break; }
     }
     const bool any_taps = s_lo <= s_hi;                                  // (uniform) else every line of the segment is zeros
+    CVS_VH_CLOCK(2);                                                     // the segment's row range is known
 
     // rows are requested through a uniform row pointer + one 32-bit lane offset per unit (clamped: every load unconditional)
     constexpr int PXB = INH ? 8 : 16;
@@ -170,6 +187,9 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
     };
 
     Line cur = load_line();
+#ifdef CVS_VH_PROBES
+    int probe_lines = 0;
+#endif
     int left = ib - ia + 1;                                              // lines still to produce
     // lines until one needs the window moved (true) or the segment is done (false)
     auto run_lines = [&]() __attribute__((always_inline)) -> bool {
@@ -230,11 +250,17 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
                     if (all_live || col_live[p]) *reinterpret_cast<float4 *>(optr + 16 * kLanes * p) = make_float4(hlo[p].x, hlo[p].y, hhi[p].x, hhi[p].y);
             }
             optr += trow;
+#ifdef CVS_VH_PROBES
+            if (probe_lines == 0) CVS_VH_CLOCK(4);                       // the first line's store is issued
+            if (probe_lines == 7) CVS_VH_CLOCK(5);                       // ... the eighth's
+            probe_lines++;
+#endif
             cur = nxt;
             if (--left == 0) return false;
         }
     };
     static_assert(kPF == 3, "three positions written out");
+    CVS_VH_CLOCK(3);                                                     // set-up done: the line loop starts
     if (left > 0) {
         for (;;) {
             if (!run_lines()) break;
@@ -245,6 +271,7 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
             advance_from(pf[2]);
         }
     }
+    CVS_VH_CLOCK(6);                                                     // the last line's store is issued
 }
 
 template <int W, int MAXTH, int NQ, bool INH, int PXL>
