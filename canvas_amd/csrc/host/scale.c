@@ -42,7 +42,7 @@ static void fir_launch_fell_through(const char *kernel, int rc) {
     t_fell_through++;
     cvs_log_warning("%s did not launch (%s): falling back to the next FIR kernel", kernel, hipGetErrorString((hipError_t)rc));
 }
-CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_HV | CVS_FIR_PATH_ONE_COLUMN | CVS_FIR_PATH_TWO_COLUMNS)); }
+CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_HV | CVS_FIR_PATH_ONE_COLUMN | CVS_FIR_PATH_TWO_COLUMNS | CVS_FIR_PATH_STRIPS)); }
 
 typedef struct {
     int t0, t1;            /* target lines covered by the table */
@@ -220,13 +220,15 @@ static int triangle_fused_vh(any_frame *target, v2f tp, const any_frame *source,
             fp.ty0 = mid_full->min.y; fp.ty1 = hi2;                   /* the vertical table's lines; lo2 .. hi2 of them are produced */
             fp.h = th; fp.v = tv;
             fp.max_sw = hfoot > 0 ? hfoot : 1;
-            if (hhi >= hlo && CVK(cvk_fir_vh_supported)(&fp)) {
+            /* short lists over few source pixels (enlarging): a workgroup per tile; else a wave per strip */
+            const bool tiles = hhi >= hlo && !(atomic_load(&g_fir_path) & CVS_FIR_PATH_STRIPS) && CVK(cvk_fir_tvh_supported)(&fp);
+            if (hhi >= hlo && (tiles || CVK(cvk_fir_vh_supported)(&fp))) {
                 /* video_scale.c:25-32,44: rows the pass leaves alone are zeros */
                 const bool covers = lo2 == tf->min.y && hi2 == tf->max.y;
                 hipError_t e = covers || !any_bytes(target) ? hipSuccess : hipMemsetAsync(target->data, 0, any_bytes(target), s);
-                int krc = e == hipSuccess ? CVK(cvk_fir_vh)(&fp, lo2 - fp.ty0, cvs_cus(), s) : (int)e;
-                if (krc == 0) { box2i_set(&target->cur, hlo, lo2, hhi, hi2); t_fir_kernel = CVS_FIR_KERNEL_VH; rc = 0; }
-                else { fir_launch_fell_through("k_fir_vh", krc); rc = 1; }   /* did not launch: the two passes decide */
+                int krc = e != hipSuccess ? (int)e : tiles ? CVK(cvk_fir_tvh)(&fp, lo2 - fp.ty0, s) : CVK(cvk_fir_vh)(&fp, lo2 - fp.ty0, cvs_cus(), s);
+                if (krc == 0) { box2i_set(&target->cur, hlo, lo2, hhi, hi2); t_fir_kernel = tiles ? CVS_FIR_KERNEL_TILE_VH : CVS_FIR_KERNEL_VH; rc = 0; }
+                else { fir_launch_fell_through(tiles ? "k_fir_tile_vh" : "k_fir_vh", krc); rc = 1; }   /* did not launch: the two passes decide */
             }
         }
     }
@@ -475,7 +477,8 @@ static uint64_t fnv1a(const void *p, size_t n) {
 static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     const int lines = tb->t1 >= tb->t0 ? tb->t1 - tb->t0 + 1 : 0;
     const int tiles = (lines + tile - 1) / tile;
-    int *foot = malloc(sizeof(int) * 2 * (size_t)(tiles ? tiles : 1));
+    const int tiles_pad = ((tiles ? tiles : 1) + 3) & ~3;          /* kernels read four entries at once: spare ones touch nothing */
+    int *foot = malloc(sizeof(int) * 2 * (size_t)tiles_pad);
     int *ntaps = malloc(sizeof(int) * (size_t)(lines ? lines : 1));
     if (!foot || !ntaps) { free(foot); free(ntaps); return -1; }
     int max_foot = 0;
@@ -492,6 +495,7 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
         foot[2 * t] = first; foot[2 * t + 1] = last;
         if (last - first + 1 > max_foot) max_foot = last - first + 1;
     }
+    for (int t = tiles; t < tiles_pad; t++) { foot[2 * t] = 0; foot[2 * t + 1] = -1; }
     /* what the streaming kernel needs to know about the table */
     int max_taps = 0, wide_foot = 0, max_active = 0, streamable = 1;
     {
@@ -531,6 +535,23 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
             }
         }
     }
+    /* source lines under any CVK_FIR_TVH_LINES consecutive target lines (tile_vh_ops.hip sizes its LDS rows by it) */
+    int span_lines[3] = { 0, 0, 0 };
+    if (streamable) {
+        for (int g = 0; g < 3; g++) {
+            const int run = CVK_FIR_TVH_LINES << g;
+            for (int i = 0; i < lines; i++) {
+                int first = INT_MAX, last = INT_MIN;
+                for (int j = i; j < lines && j < i + run; j++) {
+                    if (!ntaps[j]) continue;
+                    const int *src = tb->tap_src + (size_t)j * tb->stride;
+                    if (first == INT_MAX) first = src[0];
+                    last = src[ntaps[j] - 1];
+                }
+                if (last >= first && last - first + 1 > span_lines[g]) span_lines[g] = last - first + 1;
+            }
+        }
+    }
     /* the table by TARGET line in one record each (kernels.h cvk_fir_axis.lrec): one scalar load per line */
     uint32_t *lrec = NULL;
     if (streamable && max_taps >= 1 && max_taps <= CVK_FIR_LREC - 2) {
@@ -545,10 +566,8 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
         }
     }
     const size_t n_l = (size_t)(lines ? lines : 1), n_t = n_l * (size_t)tb->stride;
-    const size_t off_src = (n_l * sizeof(int) + 255) & ~(size_t)255;
-    const size_t off_tap = off_src + ((n_t * sizeof(int) + 255) & ~(size_t)255);
-    const size_t off_foot = off_tap + ((n_t * sizeof(float) + 255) & ~(size_t)255);
-    const size_t off_lrec = off_foot + ((sizeof(int) * 2 * (size_t)(tiles ? tiles : 1) + 255) & ~(size_t)255);
+    const size_t off_src = CVK_AXIS_OFF_SRC(lines), off_tap = CVK_AXIS_OFF_TAPS(lines, tb->stride), off_foot = CVK_AXIS_OFF_FOOT(lines, tb->stride);
+    const size_t off_lrec = off_foot + ((sizeof(int) * 2 * (size_t)tiles_pad + 255) & ~(size_t)255);
     const size_t lrec_bytes = lrec ? ((size_t)lines + 1) * CVK_FIR_LREC * sizeof *lrec : 0;
     const size_t total = off_lrec + (lrec_bytes ? lrec_bytes : 4);
     char *dev = NULL;
@@ -556,7 +575,7 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     if (err == hipSuccess) err = hipMemcpy(dev, ntaps, n_l * sizeof(int), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(dev + off_src, tb->tap_src, n_t * sizeof(int), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(dev + off_tap, tb->taps, n_t * sizeof(float), hipMemcpyHostToDevice);
-    if (err == hipSuccess) err = hipMemcpy(dev + off_foot, foot, sizeof(int) * 2 * (size_t)(tiles ? tiles : 1), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(dev + off_foot, foot, sizeof(int) * 2 * (size_t)tiles_pad, hipMemcpyHostToDevice);
     if (err == hipSuccess && lrec_bytes) err = hipMemcpy(dev + off_lrec, lrec, lrec_bytes, hipMemcpyHostToDevice);
     free(foot); free(ntaps); free(lrec);
     if (err != hipSuccess) { if (dev) hipFree(dev); cvs_set_error("FIR table upload: %s", hipGetErrorString(err)); return -1; }
@@ -565,9 +584,10 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     e->axis.src = (const int *)(dev + off_src);
     e->axis.taps = (const float *)(dev + off_tap);
     e->axis.foot = (const int *)(dev + off_foot);
-    e->axis.stride = tb->stride;
+    e->axis.stride = tb->stride; e->axis.lines = lines;
     e->axis.max_taps = max_taps; e->axis.wide_foot = wide_foot; e->axis.max_active = max_active; e->axis.streamable = streamable;
     e->axis.lrec = lrec_bytes ? (const uint32_t *)(dev + off_lrec) : NULL;
+    memcpy(e->axis.span_lines, span_lines, sizeof span_lines);
     e->max_foot = max_foot;
     return 0;
 }

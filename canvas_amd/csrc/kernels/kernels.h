@@ -37,6 +37,8 @@
 #define cvk_fir2d                    cvk_fir2d_fma
 #define cvk_fir_vh_supported         cvk_fir_vh_supported_fma
 #define cvk_fir_vh                   cvk_fir_vh_fma
+#define cvk_fir_tvh_supported        cvk_fir_tvh_supported_fma
+#define cvk_fir_tvh                  cvk_fir_tvh_fma
 #define cvk_blur_supported           cvk_blur_supported_fma
 #define cvk_blur_takes_pairs         cvk_blur_takes_pairs_fma
 #define cvk_blur                     cvk_blur_fma
@@ -139,12 +141,14 @@ int cvk_zero_f32(cvk_view v, void *stream);
 /* separable FIR, both passes in one launch with the source tile and the horizontal result staged in LDS.
  * One device table per axis (cvk_fir_axis): for target line i (0-based within the rect) ntaps[i] taps,
  * source indices src[i*stride + k] (ascending) and weights taps[i*stride + k]; foot[2*t], foot[2*t+1] =
- * first and last source index any line of tile t touches (first > last: the tile touches nothing). */
+ * first and last source index any line of tile t touches (first > last: the tile touches nothing); the list is padded with
+ * such entries to a multiple of four. */
 typedef struct {
     const int *ntaps, *src;
     const float *taps;
     const int *foot;
     int stride;
+    int lines;                 /* target lines the table covers (ntaps is also the start of the table's device block: CVK_AXIS_OFF_*) */
     /* facts about the table the host worked out when it built it (for the streaming kernel, resample_ops.hip) */
     int max_taps;              /* longest tap list */
     int wide_foot;             /* widest source footprint of any run of 128 lines starting at a multiple of 128 */
@@ -154,8 +158,18 @@ typedef struct {
      * than CVK_FIR_LREC - 2): [0] tap count, [1] first source line (INT_MIN for a line without taps), [2 + k] weight of
      * tap k; unused entries 0.  One spare all-zero record (count 0) follows the last.  sweep_vh_ops.hip reads one per line. */
     const uint32_t *lrec;
+    int span_lines[3];         /* (streamable tables) most source lines any 16, 32, 64 consecutive target lines reach, first tap of the first to last tap of the last */
 } cvk_fir_axis;
 #define CVK_FIR_LREC 32
+/* One device block per table: ntaps | src | taps | foot | lrec, each part on a 256-byte boundary, ntaps first.  A kernel that
+ * is handed the block's start can form the other pointers itself (tile_vh_ops.hip does, to have them before its arguments
+ * arrive); the host lays the block out with the same macros (scale.c axis_upload). */
+#define CVK_AXIS_ALIGN(bytes)              (((size_t)(bytes) + 255) & ~(size_t)255)
+#define CVK_AXIS_NLINES(lines)             ((size_t)((lines) > 0 ? (lines) : 1))
+#define CVK_AXIS_OFF_SRC(lines)            CVK_AXIS_ALIGN(CVK_AXIS_NLINES(lines) * 4)
+#define CVK_AXIS_OFF_TAPS(lines, stride)   (CVK_AXIS_OFF_SRC(lines) + CVK_AXIS_ALIGN(CVK_AXIS_NLINES(lines) * (size_t)(stride) * 4))
+#define CVK_AXIS_OFF_FOOT(lines, stride)   (CVK_AXIS_OFF_TAPS(lines, stride) + CVK_AXIS_ALIGN(CVK_AXIS_NLINES(lines) * (size_t)(stride) * 4))
+#define CVK_FIR_TVH_LINES 16     /* the shortest segment of tile_vh_ops.hip (span_lines[0]); [1], [2]: twice, four times as many */
 typedef struct {
     cvk_view target, source;
     int in_half, out_half;     /* 0: rgba_f32 pixels, 1: rgba_f16 pixels */
@@ -176,6 +190,10 @@ int cvk_fir_hv(const cvk_fir2d_params *fp, int cus, void *stream);
  * equal or the vertical one is smaller.  fp->ty0 = first line of the vertical table; lines ty0 + line0 .. ty1 are produced */
 int cvk_fir_vh_supported(const cvk_fir2d_params *fp);
 int cvk_fir_vh(const cvk_fir2d_params *fp, int line0, int cus, void *stream);
+/* the same, a workgroup per tile of 128 columns x CVK_FIR_TVH_LINES lines with both passes through LDS (tile_vh_ops.hip):
+ * for tables with short lists and narrow footprints (enlarging); needs v.span_lines and h.wide_foot (columns counted from fp->tx0) */
+int cvk_fir_tvh_supported(const cvk_fir2d_params *fp);
+int cvk_fir_tvh(const cvk_fir2d_params *fp, int line0, void *stream);
 size_t cvk_fir2d_lds_bytes(const cvk_fir2d_params *fp);     /* dynamic LDS the launch would need */
 int cvk_fir2d(const cvk_fir2d_params *fp, void *stream);
 
@@ -265,6 +283,8 @@ size_t cvk_fir2d_lds_bytes_fma(const cvk_fir2d_params *fp);
 int cvk_fir2d_fma(const cvk_fir2d_params *fp, void *stream);
 int cvk_fir_vh_supported_fma(const cvk_fir2d_params *fp);
 int cvk_fir_vh_fma(const cvk_fir2d_params *fp, int line0, int cus, void *stream);
+int cvk_fir_tvh_supported_fma(const cvk_fir2d_params *fp);
+int cvk_fir_tvh_fma(const cvk_fir2d_params *fp, int line0, void *stream);
 int cvk_blur_supported_fma(int ntaps, int step);
 int cvk_blur_takes_pairs_fma(const cvk_blur_params *bp);
 int cvk_blur_fma(const cvk_blur_params *bp, int cus, void *stream);

@@ -62,6 +62,9 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
     __shared__ float4 mid[kZero + 1];
     const int lane = threadIdx.x;
     CVS_VH_CLOCK(0);
+#ifdef CVS_VH_PROBES
+    if (g_vh_clocks && threadIdx.x == 0) g_vh_clocks[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = __builtin_amdgcn_s_memrealtime();     // the start again, on the clock all XCDs share
+#endif
     // the lane's columns: halfs out -> the adjacent pair 2 lane, 2 lane + 1 (one 16-byte store); floats out -> lane and
     // lane + 64 (two 16-byte stores, each contiguous across the wave)
     constexpr bool out_half = INH;                                       // (both frames of a scaler call have the caller's format)

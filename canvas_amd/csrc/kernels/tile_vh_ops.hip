@@ -1,0 +1,383 @@
+// tile_vh_ops.hip -- separable FIR with per-line tap tables, VERTICAL pass first, one workgroup per tile of the target.
+//
+// The enlarging case of video_scale_bilinear_f32 (video_scale.c:231-286; pass order :252, vertical sums :63-122, horizontal
+// sums :161-226).  sweep_vh_ops.hip walks a strip of the target line by line with one wave: every line is a chain
+// record -> window -> vertical sum -> LDS row -> horizontal sum -> store, about 1 900 cycles a line whatever the arithmetic
+// costs (profiles/r04/vh_clocks_*.txt), and when the target is the large frame the chip spends its time waiting on those
+// chains.  Here a workgroup of four waves takes a tile of 128 columns x 16 lines and runs the two passes as two sweeps over
+// LDS with a barrier between them, so that nothing inside a pass depends on anything else inside it:
+//   1. the source rows the tile's lines reach (first tap of its first line .. last tap of its last) x the source columns
+//      under its 128 target columns (four tiles of the horizontal table's footprint list) are loaded -- every load of a lane
+//      requested before the first is used -- widened and written to S[row][column];
+//   2. V: M[line][column] = S[first][column] w0 + S[first + 1][column] w1 ... in ascending source order, exactly the line's
+//      n taps (count, first row and weights: one scalar load per line from cvk_fir_axis.lrec); a line without taps is zeros;
+//      wave w takes lines w, w + 4, ...; lanes take the columns;
+//   3. H: each lane gathers the taps of its two target columns from M[line] -- sum from the first product in ascending tap
+//      order, padded taps read the row's zero pixel with weight 0 -- narrows and stores: 1 KB per wave and line.
+// Same sums in the same order as k_fir_vh and as the two k_fir launches: the three are bit-equal (tests/test_gpu_parity.py).
+// Algorithmic bytes: source pixel once + target pixel once (a tile re-reads the one or two source rows and columns its
+// neighbours also reach: + 10..25 % of the SOURCE, which is the small frame here).
+#include <atomic>
+#include <climits>
+#include <cstdlib>
+#include "kernels.h"
+#include "chain_math.hpp"
+#include "sweep_common.hpp"
+#include "gather_common.hpp"
+
+#if defined(CVS_DIAG) && !defined(CVS_CONTRACT)
+// timing probes (diagnostic build only): per workgroup, the constant-rate clock at six points -> tools/vh_clocks.py tiles
+__device__ unsigned long long *g_tvh_clocks;
+extern "C" __attribute__((visibility("default"))) int cvk_fir_tvh_clock_buffer(void *dev) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tvh_clocks), &dev, sizeof dev); }
+// (the buffer pointer is read once, at the kernel's start: a probe that fetched it again would time its own fetch)
+// timing-only variants (wrong pixels on purpose): 1 = stores only, in the kernel's own pattern, nothing read or computed;
+// 2 = everything but the stores' data dependence (the set-up and the line loop run, zeros are stored)
+__device__ int g_tvh_mode;
+extern "C" __attribute__((visibility("default"))) int cvk_fir_tvh_diag_mode(int mode) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tvh_mode), &mode, sizeof mode); }
+#define CVS_TVH_DIAG 1
+#define CVS_TVH_CLOCK_START() unsigned long long *const tvh_clk = g_tvh_clocks ? g_tvh_clocks + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 : NULL
+#define CVS_TVH_CLOCK(slot) do { if (tvh_clk && threadIdx.x == 0) { tvh_clk[slot] = __builtin_amdgcn_s_memtime(); tvh_clk[8 + (slot)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define CVS_TVH_CLOCK_START() do { } while (0)
+#define CVS_TVH_CLOCK(slot) do { } while (0)
+#endif
+
+namespace {
+
+using cvs::f32x2;
+
+constexpr int kTW = 128, kThreads = 256, kWaves = kThreads / 64;
+constexpr int kNJ = 8;           // source pixels a lane stages at most (all requested at once)
+static_assert(kTW == 4 * CVK_FIR2D_TILE_X, "a tile spans four entries of the footprint table");
+
+__device__ __forceinline__ Px zero_px() { return Px{ f32x2{ 0.0f, 0.0f }, f32x2{ 0.0f, 0.0f } }; }
+// "this value is needed here": keeps hipcc from sinking an LDS read into the branch that first uses it, where it would be
+// requested and waited for on its own (a line's reads then cost one LDS trip each instead of one for all)
+__device__ __forceinline__ void pin(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void pin(uint4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
+// seg: target lines per workgroup (a multiple of kSub); swp: pixels per LDS row (>= source columns under any 128 target
+// columns + 1: the last is the row's zero pixel); shp: rows of S (>= source rows under any `seg` consecutive lines)
+// The first arguments are what the set-up needs before anything else, as plain scalars: hipcc is told to have them preloaded
+// into SGPRs (-amdgpu-kernarg-preload-count, csrc/Makefile), so the first table reads do not wait for a kernarg fetch.
+template <int MAXTV, int MAXTH, bool INH>
+__global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const char *hblock, const uint32_t *vlrec, int line0, int seg, int tx0, int tx1, int ty0, int ty1,
+                                                         int hstride, int hlines, int swp, int shp, cvk_fir2d_params fp) {
+    static_assert(MAXTV >= 1 && MAXTV <= 4 && MAXTH >= 1 && MAXTH <= 8, "instances (a record in LDS holds four weights)");
+    extern __shared__ __align__(16) unsigned char tile_lds[];
+    typedef float4 raw_t;                                                // a source pixel in LDS: widened once, when it is staged (every
+                                                                         // use would otherwise pay four conversions: the line loop is VALU-bound)
+    uint4 *R = reinterpret_cast<uint4 *>(tile_lds);                      // [seg][2]  the segment's line records: count, first row, four weights
+    raw_t *S = reinterpret_cast<raw_t *>(R + 2 * seg);                   // [shp][swp]  the segment's source rows, widened
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef CVS_TVH_DIAG
+    if (g_tvh_mode == 1) {                                               // stores only
+        const int nl = ty1 - ty0 + 1, a = line0 + (int)blockIdx.y * seg, b = min(a + seg - 1, nl - 1);
+        const int col = tx0 + (int)blockIdx.x * kTW + (INH ? 2 * lane : lane);
+        char *o = reinterpret_cast<char *>(fp.target.data) + ((size_t)(col - fp.target.fx0)) * (INH ? 8 : 16);
+        for (int line = a + wave; line <= b; line += kWaves) {
+            char *q = o + (size_t)(ty0 + line - fp.target.fy0) * (size_t)fp.target.pitch * (INH ? 8 : 16);
+            if (INH) { if (col + 1 <= tx1) *reinterpret_cast<uint4 *>(q) = make_uint4(line, lane, 0, 0); }
+            else { if (col <= tx1) *reinterpret_cast<uint4 *>(q) = make_uint4(line, lane, 0, 0); if (col + 64 <= tx1) *reinterpret_cast<uint4 *>(q + 1024) = make_uint4(line, lane, 0, 0); }
+        }
+        return;
+    }
+#endif
+    CVS_TVH_CLOCK_START();
+    CVS_TVH_CLOCK(0);
+    CVS_TVH_CLOCK(6);                                                    // (a probe right after a probe: what a probe costs)
+    constexpr bool out_half = INH;                                       // (both frames of a scaler call have the caller's format)
+    constexpr int cstep = out_half ? 1 : 64;                             // halfs: the pair 2 lane, 2 lane + 1; floats: lane, lane + 64
+    const int tcol = tx0 + (int)blockIdx.x * kTW + (out_half ? 2 * lane : lane);
+    const int nlines = ty1 - ty0 + 1;
+    // table lines of this segment (counted from fp.ty0); the launch covers lines line0 .. nlines - 1
+    const int ia = line0 + (int)blockIdx.y * seg, ib = min(ia + seg - 1, nlines - 1);
+    const int tl = ib - ia + 1;
+    // the horizontal table's parts, from the start of its device block (kernels.h CVK_AXIS_OFF_*)
+    const int *const h_ntaps = reinterpret_cast<const int *>(hblock);
+    const int *const h_src = reinterpret_cast<const int *>(hblock + CVK_AXIS_OFF_SRC(hlines));
+    const float *const h_taps = reinterpret_cast<const float *>(hblock + CVK_AXIS_OFF_TAPS(hlines, hstride));
+    const konst foot = as_konst(hblock + CVK_AXIS_OFF_FOOT(hlines, hstride));
+    const int zcol = swp - 1;                                            // the zero pixel of every S row
+
+    // --- set-up in two trips to memory.  First: what depends on the preloaded arguments only -- the tap lists, the segment's
+    // records, the footprint entries and the segment's first and last record (scalar) -- next to the fetch of the remaining
+    // arguments.  Second: the source rows.  No load waits for another inside a trip.
+    constexpr int LR = CVK_FIR_LREC;
+    // the horizontal taps of this lane's two columns (all MAXTH of each, clamped into the line's list: which of them are
+    // taps is decided afterwards, so the loads do not wait for the count)
+    bool col_live[2];
+    int hn[2], hsrc[2][MAXTH];
+    float hw[2][MAXTH];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        col_live[p] = tcol + p * cstep <= tx1;
+        const int hline = min(tcol + p * cstep, tx1) - tx0;
+        hn[p] = h_ntaps[hline];
+#pragma unroll
+        for (int k = 0; k < MAXTH; k++) {
+            const size_t at = (size_t)hline * hstride + min(k, hstride - 1);
+            hsrc[p][k] = h_src[at];
+            hw[p][k] = h_taps[at];
+        }
+    }
+    // the segment's line records go to LDS with the rows (lane = line), so that the line loop never goes to memory for one
+    // (a record fetched per tile was a trip to L2 per tile: profiles/r04)
+    uint4 my_rec[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
+    {                                                                    // (lanes past the segment's last line: its last, not kept)
+        const uint4 *g = reinterpret_cast<const uint4 *>(vlrec + (size_t)(ia + min(tid, tl - 1)) * LR);
+        my_rec[0] = g[0];
+        if (MAXTV > 2) my_rec[1] = g[1];
+    }
+    // source columns under the 128 target columns: four entries of the footprint list in one scalar load (the list is padded
+    // to a multiple of four; first > last: that entry touches nothing)
+    constexpr int kTiles = kTW / CVK_FIR2D_TILE_X;
+    const int ntiles = (tx1 - tx0) / CVK_FIR2D_TILE_X + 1, t0 = kTiles * (int)blockIdx.x;
+    int flo[kTiles], fhi[kTiles];
+#pragma unroll
+    for (int t = 0; t < kTiles; t++) { flo[t] = (int)foot[2 * (t0 + t)]; fhi[t] = (int)foot[2 * (t0 + t) + 1]; }
+    // source rows the segment's lines reach: the first record's first tap .. the last record's last (first and last taps never
+    // decrease down the table); both records requested at once
+    const konst lrec = as_konst(vlrec) + (size_t)ia * LR;
+    const konst lend = lrec + (size_t)(tl - 1) * LR;
+    const int n_a = (int)lrec[0], f_a = (int)lrec[1], n_b = (int)lend[0], f_b = (int)lend[1];
+    __builtin_amdgcn_sched_barrier(0);                                   // (the table reads are requested before the arguments are fetched)
+    // ... and every other argument the kernel uses.  The empty asm makes all of it one request-and-wait: left alone, hipcc
+    // sinks each of these loads to its first use, and every one then costs its own trip.
+    const char *const sdata = reinterpret_cast<const char *>(fp.source.data);
+    char *const tdata = reinterpret_cast<char *>(fp.target.data);
+    const int spitch = fp.source.pitch, sfx0 = fp.source.fx0, sfy0 = fp.source.fy0, tpitch = fp.target.pitch, tfx0 = fp.target.fx0, tfy0 = fp.target.fy0;
+    const int sfx1 = fp.source.fx1, tfx1 = fp.target.fx1;               // (fetched with their neighbours: named here so that their registers are not handed out while the fetch is in flight, which costs a wait)
+    asm volatile("" :: "s"(n_a), "s"(f_a), "s"(n_b), "s"(f_b), "s"(flo[0]), "s"(fhi[0]), "s"(flo[1]), "s"(fhi[1]), "s"(flo[2]), "s"(fhi[2]), "s"(flo[3]), "s"(fhi[3]),
+                 "s"(sdata), "s"(tdata), "s"(spitch), "s"(sfx0), "s"(sfy0), "s"(tpitch), "s"(tfx0), "s"(tfy0), "s"(sfx1), "s"(tfx1));
+
+    int sx_lo = INT_MAX, sx_hi = INT_MIN;
+#pragma unroll
+    for (int t = 0; t < kTiles; t++)
+        if (t0 + t < ntiles && fhi[t] >= flo[t]) { sx_lo = min(sx_lo, flo[t]); sx_hi = max(sx_hi, fhi[t]); }
+    const int sw = sx_hi >= sx_lo ? min(sx_hi - sx_lo + 1, swp - 1) : 0;  // (the host sized swp to cover them)
+    int s_lo = f_a, s_hi = f_b + min(n_b, MAXTV) - 1;
+    if (n_a <= 0 || n_b <= 0) {                                          // rare: lines without taps at an end of the segment -> look further in
+        s_lo = INT_MAX; s_hi = INT_MIN;
+        konst r = lrec;
+        for (int i = 0; i < tl; i++, r += LR)
+            if ((int)r[0] > 0) { s_lo = (int)r[1]; break; }
+        r = lend;
+        for (int i = tl - 1; i >= 0; i--, r -= LR)
+            if ((int)r[0] > 0) { s_hi = (int)r[1] + min((int)r[0], MAXTV) - 1; break; }
+    }
+    const int sh = s_hi >= s_lo ? min(s_hi - s_lo + 1, shp) : 0;
+    CVS_TVH_CLOCK(1);                                                    // column and row range known
+
+    // 1. stage the segment's rows (requested before the tap lists and records are looked at: same trip): pixel
+    //    u = row * sw + column of the block, lane tid takes u = tid, tid + 256, ... (at most kNJ of them: the host checked);
+    //    all of a lane's loads are requested before the first is used
+    if (sw > 0 && sh > 0) {
+        constexpr int PXB = INH ? 8 : 16;
+        const int units = min(sh * sw, kNJ * kThreads);
+        const float inv_sw = 1.0f / (float)sw;
+        const char *base = sdata + ((size_t)(s_lo - sfy0) * (size_t)spitch + (size_t)(sx_lo - sfx0)) * PXB;
+        const uint32_t rowpx = (uint32_t)spitch;
+        Raw<INH> v[kNJ];
+        int sidx[kNJ];
+#pragma unroll
+        for (int j = 0; j < kNJ; j++) {
+            const int u = min(tid + j * kThreads, units - 1);            // clamped: every load unconditional
+            int r = (int)(((float)u + 0.5f) * inv_sw);                   // u / sw, up to one either way (u < 2^22)
+            int c = u - r * sw;
+            const int fix = (c >= sw ? 1 : 0) - (c < 0 ? 1 : 0);
+            r += fix; c -= fix * sw;
+            sidx[j] = r * swp + c;
+            v[j].v = *reinterpret_cast<const decltype(v[j].v) *>(base + ((uint32_t)r * rowpx + (uint32_t)c) * (uint32_t)PXB);
+        }
+#pragma unroll
+        for (int j = 0; j < kNJ; j++)
+            if (tid + j * kThreads < units) { const Px w = widen(v[j]); S[sidx[j]] = make_float4(w.lo.x, w.lo.y, w.hi.x, w.hi.y); }
+    }
+    // columns of the M row and weights; padded taps -> the row's zero pixel, weight 0
+    int acol[2][MAXTH];
+    float wt[2][MAXTH];
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int n = col_live[p] ? min(hn[p], MAXTH) : 0;
+#pragma unroll
+        for (int k = 0; k < MAXTH; k++) {
+            const bool live = k < n;
+            acol[p][k] = live ? min(max(hsrc[p][k] - sx_lo, 0), zcol) : zcol;
+            wt[p][k] = live ? hw[p][k] : 0.0f;
+        }
+    }
+    if (tid < shp) S[tid * swp + zcol] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (tid < tl) { R[2 * tid] = my_rec[0]; R[2 * tid + 1] = my_rec[1]; }
+    CVS_TVH_CLOCK(2);                                                    // tap lists and records landed
+
+    CVS_TVH_CLOCK(3);                                                    // this wave's share of the rows is in LDS
+    __syncthreads();
+    CVS_TVH_CLOCK(4);
+
+    const bool all_live = tx0 + ((int)blockIdx.x + 1) * kTW - 1 <= tx1;       // (uniform) every lane's columns exist
+    constexpr uint32_t tpx = out_half ? 8 : 16;
+    const size_t trow = (size_t)tpitch * tpx;
+    char *obase = tdata + ((size_t)(tcol - tfx0)) * tpx + (size_t)(ty0 + ia - tfy0) * trow;
+
+    // one record per line (cvk_fir_axis.lrec: count, first source row, weights), from LDS: every lane reads the same address
+    struct Rec { int n, row; float w[MAXTV]; };
+    struct RawRec { uint4 a, b; };
+    auto read_rec = [&](int line) __attribute__((always_inline)) {      // lines past the segment's last: its last (never used)
+        const int at = 2 * min(line, tl - 1);
+        RawRec r;
+        r.a = R[at];
+        r.b = MAXTV > 2 ? R[at + 1] : make_uint4(0, 0, 0, 0);
+        return r;
+    };
+    auto decode = [&](const RawRec &r) __attribute__((always_inline)) {
+        Rec rec;
+        rec.n = min((int)__builtin_amdgcn_readfirstlane(r.a.x), MAXTV);
+        rec.row = rec.n > 0 ? ((int)__builtin_amdgcn_readfirstlane(r.a.y) - s_lo) * swp : 0;   // (a line without taps reads row 0 and keeps nothing)
+        rec.w[0] = __uint_as_float(__builtin_amdgcn_readfirstlane(r.a.z));
+        if constexpr (MAXTV > 1) rec.w[1] = __uint_as_float(__builtin_amdgcn_readfirstlane(r.a.w));
+        if constexpr (MAXTV > 2) rec.w[2] = __uint_as_float(__builtin_amdgcn_readfirstlane(r.b.x));
+        if constexpr (MAXTV > 3) rec.w[3] = __uint_as_float(__builtin_amdgcn_readfirstlane(r.b.y));
+        return rec;
+    };
+
+    // 2. the lines: wave w takes lines w, w + 4, ... of the segment, each lane its two target columns.  For each of a column's
+    //    horizontal taps the lane forms the vertical sum at that source column itself -- S[first .. first + n - 1][column] times
+    //    the line's weights, ascending, exactly the line's n taps (video_scale.c:82-85) -- and adds the products in ascending
+    //    tap order (:176-179; padded taps: the row's zero pixel, weight 0).  The same vertical sum is formed by every lane
+    //    whose taps name that source column, to the same bits; what that costs is arithmetic, of which there is plenty,
+    //    and what it saves is the intermediate row in LDS with its barrier per line group.  All reads of a line (and the
+    //    next line's record) are requested before the first is used: every address is valid whatever the counts are, the
+    //    counts only decide what is added.
+    constexpr bool kBothAtOnce = MAXTH * MAXTV <= 4;              // registers: both pixels' reads in flight, or one pixel's
+    RawRec first_rec = read_rec(wave);
+    Rec rc = decode(first_rec);
+    for (int line = wave; line < tl; line += kWaves) {
+        const Rec cur = rc;
+        const int n = cur.n;                                             // uniform
+        RawRec nxt = read_rec(line + kWaves);
+        raw_t sp[2][MAXTH][MAXTV];
+        auto request = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < MAXTH; j++) {
+#pragma unroll
+                for (int k = 0; k < MAXTV; k++) sp[p][j][k] = S[cur.row + min(k, max(n - 1, 0)) * swp + acol[p][j]];
+            }
+        };
+        auto landed = [&](int p) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < MAXTH; j++) {
+#pragma unroll
+                for (int k = 0; k < MAXTV; k++) pin(sp[p][j][k]);
+            }
+        };
+        request(0);
+        if constexpr (kBothAtOnce) request(1);
+        pin(nxt.a);
+        if constexpr (MAXTV > 2) pin(nxt.b);
+        rc = decode(nxt);
+        f32x2 hlo[2], hhi[2];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            if (p == 1 && !kBothAtOnce) request(1);
+            if (p == 0 || !kBothAtOnce) landed(p);
+            if (p == 0 && kBothAtOnce) landed(1);
+#pragma unroll
+            for (int j = 0; j < MAXTH; j++) {
+                Px mid = zero_px();
+                if (n > 0) {
+                    const Px p0 = { f32x2{ sp[p][j][0].x, sp[p][j][0].y }, f32x2{ sp[p][j][0].z, sp[p][j][0].w } };
+                    const f32x2 w0 = { cur.w[0], cur.w[0] };
+                    mid.lo = p0.lo * w0; mid.hi = p0.hi * w0;            // (0 + p0 is p0: gather_common.hpp vsum)
+#pragma unroll
+                    for (int k = 1; k < MAXTV; k++) {
+                        if (k < n) {
+                            const Px pk = { f32x2{ sp[p][j][k].x, sp[p][j][k].y }, f32x2{ sp[p][j][k].z, sp[p][j][k].w } };
+                            const f32x2 wk = { cur.w[k], cur.w[k] };
+                            mid.lo = cvs::madd(pk.lo, wk, mid.lo);       // t += s * coeff
+                            mid.hi = cvs::madd(pk.hi, wk, mid.hi);
+                        }
+                    }
+                }
+                const f32x2 wj = { wt[p][j], wt[p][j] };
+                if (j == 0) { hlo[p] = mid.lo * wj; hhi[p] = mid.hi * wj; }
+                else { hlo[p] = cvs::madd(mid.lo, wj, hlo[p]); hhi[p] = cvs::madd(mid.hi, wj, hhi[p]); }
+            }
+        }
+        char *optr = obase + (size_t)line * trow;
+        if constexpr (out_half) {
+            const uint2 a = narrow4(hlo[0], hhi[0]), b = narrow4(hlo[1], hhi[1]);
+            if (all_live || col_live[1]) *reinterpret_cast<uint4 *>(optr) = make_uint4(a.x, a.y, b.x, b.y);
+            else if (col_live[0]) *reinterpret_cast<uint2 *>(optr) = a;
+        } else {
+#pragma unroll
+            for (int p = 0; p < 2; p++)
+                if (all_live || col_live[p]) *reinterpret_cast<float4 *>(optr + 16 * 64 * p) = make_float4(hlo[p].x, hlo[p].y, hhi[p].x, hhi[p].y);
+        }
+        if (line == wave) CVS_TVH_CLOCK(5);                              // the wave's first line: stores issued
+    }
+    CVS_TVH_CLOCK(7);                                                    // last line's stores issued
+}
+
+constexpr size_t kLdsCap = 64 * 1024;
+
+int row_pixels(const cvk_fir2d_params *fp) { return fp->h.wide_foot + 1; }            // (the h table's line 0 is column fp->tx0)
+int seg_index(int seg) { return seg == 64 ? 2 : seg == 32 ? 1 : 0; }
+int seg_rows(const cvk_fir2d_params *fp, int seg) { return fp->v.span_lines[seg_index(seg)]; }
+size_t lds_bytes(const cvk_fir2d_params *fp, int seg) { return (size_t)seg_rows(fp, seg) * (size_t)row_pixels(fp) * sizeof(float4) + (size_t)seg * 2 * sizeof(uint4); }
+
+// lines per workgroup: as many as keep four workgroups on a CU (the set-up -- tap lists, row range, the rows themselves -- is
+// three trips to memory, the same for 16 lines as for 64) and all of a lane's row requests in flight at once
+int pick_seg(const cvk_fir2d_params *fp) {
+    static int forced = -1;
+    if (forced < 0) { const char *e = getenv("CVS_TVH_SEG"); forced = e ? atoi(e) : 0; }
+    if ((forced == 16 || forced == 32 || forced == 64) && lds_bytes(fp, forced) <= kLdsCap && (size_t)seg_rows(fp, forced) * (size_t)fp->h.wide_foot <= (size_t)kNJ * kThreads) return forced;
+    for (int seg = 64; seg > CVK_FIR_TVH_LINES; seg /= 2)
+        if (lds_bytes(fp, seg) <= 40 * 1024 && (size_t)seg_rows(fp, seg) * (size_t)fp->h.wide_foot <= (size_t)kNJ * kThreads) return seg;
+    return CVK_FIR_TVH_LINES;
+}
+
+template <int MAXTV, int MAXTH, bool INH>
+int launch(const cvk_fir2d_params &fp, int line0, hipStream_t s) {
+    const int cols = fp.tx1 - fp.tx0 + 1, rows = fp.ty1 - fp.ty0 + 1 - line0;
+    const int seg = pick_seg(&fp);
+    dim3 grid((unsigned)((cols + kTW - 1) / kTW), (unsigned)((rows + seg - 1) / seg));
+    hipLaunchKernelGGL((k_fir_tile_vh<MAXTV, MAXTH, INH>), grid, dim3(kThreads), lds_bytes(&fp, seg), s,
+                       reinterpret_cast<const char *>(fp.h.ntaps), fp.v.lrec, line0, seg, fp.tx0, fp.tx1, fp.ty0, fp.ty1,
+                       fp.h.stride, fp.h.lines, row_pixels(&fp), seg_rows(&fp, seg), fp);
+    return (int)hipGetLastError();
+}
+
+typedef int (*launch_fn)(const cvk_fir2d_params &, int, hipStream_t);
+struct Instance { int maxtv, maxth; launch_fn f16, f32; };
+#define CVK_TVH_INSTANCE(V, H) { V, H, launch<V, H, true>, launch<V, H, false> }
+const Instance kInstances[] = { CVK_TVH_INSTANCE(2, 2), CVK_TVH_INSTANCE(4, 4) };
+
+const Instance *pick(const cvk_fir2d_params *fp) {
+    for (const Instance &in : kInstances)
+        if (fp->v.max_taps <= in.maxtv && fp->h.max_taps <= in.maxth) return &in;
+    return NULL;
+}
+
+}  // namespace
+
+// Tables of an enlarging (or gently reducing) call: short lists, few source rows and columns under a tile.  The rest -- long
+// lists, wide footprints -- is k_fir_vh's.
+extern "C" int cvk_fir_tvh_supported(const cvk_fir2d_params *fp) {
+    if (!(fp->in_half == fp->out_half && fp->v.streamable && fp->v.lrec != NULL && fp->v.max_taps >= 1 && fp->h.max_taps >= 1
+          && fp->h.wide_foot >= 1 && fp->h.wide_foot <= 128 && fp->v.span_lines[0] >= 1 && pick(fp) != NULL)) return 0;
+    if (fp->tx1 - fp->tx0 + 1 < 2 * kTW) return 0;                    // narrow targets: the strips of k_fir_vh
+    // two halfs-pixels per lane are ONE 16-byte store: the pair must sit on a 16-byte boundary in every row
+    if (fp->out_half && ((((uintptr_t)fp->target.data) & 15u) || (fp->target.pitch & 1) || ((fp->tx0 - fp->target.fx0) & 1))) return 0;
+    if ((size_t)fp->v.span_lines[0] * (size_t)fp->h.wide_foot > (size_t)kNJ * kThreads) return 0;     // a lane stages at most kNJ source pixels
+    return lds_bytes(fp, CVK_FIR_TVH_LINES) <= kLdsCap;
+}
+
+// fp->ty0 is the vertical table's first line; lines fp->ty0 + line0 .. fp->ty1 are produced
+extern "C" int cvk_fir_tvh(const cvk_fir2d_params *fp, int line0, void *stream) {
+    if (fp->tx1 < fp->tx0 || fp->ty1 < fp->ty0 + line0 || line0 < 0) return 0;
+    if (!cvk_fir_tvh_supported(fp)) return (int)hipErrorInvalidValue;
+    const Instance *in = pick(fp);
+    return fp->in_half ? in->f16(*fp, line0, (hipStream_t)stream) : in->f32(*fp, line0, (hipStream_t)stream);
+}

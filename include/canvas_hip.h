@@ -415,7 +415,8 @@ CVS_EXPORT int cvs_blur_lanczos_f16_batch_dev(rgba_frame_f16 *const *targets, co
 enum { CVS_FIR_PATH_AUTO = 0, CVS_FIR_PATH_SWEEP = 1 /* lane per pixel */, CVS_FIR_PATH_TILED = 2, CVS_FIR_PATH_TABLES = 4 /* skip the register-window kernel */,
        CVS_FIR_PATH_HV = 16 /* per-line gather, horizontal pass first (the automatic first choice) */,
        CVS_FIR_PATH_ONE_COLUMN = 32 /* the register-window kernels (blur, blur + halving) with one column per lane, never two */,
-       CVS_FIR_PATH_TWO_COLUMNS = 64 /* ... with two columns per lane wherever that form takes the launch, narrow frames included */ };
+       CVS_FIR_PATH_TWO_COLUMNS = 64 /* ... with two columns per lane wherever that form takes the launch, narrow frames included */,
+       CVS_FIR_PATH_STRIPS = 128 /* the vertical-first triangle scaler on k_fir_vh's strips even where its tile form (k_fir_tile_vh) would take the call */ };
 CVS_EXPORT void cvs_fir_path_override(int mode);
 /* Which kernel the calling thread's last FIR launch (scaler, blur, Lanczos resample, blur + resample) went to -- what a
  * test pinned to one kernel asserts, and what tells a silent fallback from the intended kernel.  A fused kernel that was
@@ -431,7 +432,8 @@ enum { CVS_FIR_KERNEL_NONE = 0,
        CVS_FIR_KERNEL_PASS = 8,        /* k_fir: one pass of the triangle scaler (both passes: two of these) */
        CVS_FIR_KERNEL_HV = 9,          /* k_fir_hv: per-line tables, horizontal pass first, gather per target line */
        CVS_FIR_KERNEL_WINDOW_PAIR = 10,    /* k_blur_pair: the register-window blur with two columns per lane (f16, up to 13 taps) */
-       CVS_FIR_KERNEL_HALVE_PAIR = 11 };   /* k_blur_halve_pair: blur + Lanczos halving with two source columns per lane (f16) */
+       CVS_FIR_KERNEL_HALVE_PAIR = 11,     /* k_blur_halve_pair: blur + Lanczos halving with two source columns per lane (f16) */
+       CVS_FIR_KERNEL_TILE_VH = 12 };      /* k_fir_tile_vh: the triangle scaler, vertical pass first, a workgroup per 128 x 16 tile (enlarging) */
 CVS_EXPORT int cvs_fir_last_kernel(void);
 /* How many FIR launches of the calling thread were chosen for a fused kernel that then did not launch and went to the next
  * kernel in line (same pixels, slower): each is also reported to the log handler as a warning.  A successful call leaves

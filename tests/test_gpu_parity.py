@@ -841,7 +841,8 @@ def force_fir(request):
             mode |= _lib.FIR_PATH_TILED
         elif which == "hv":
             mode |= _lib.FIR_PATH_HV
-
+        if which == "strips":                               # the fused vertical-first scaler on k_fir_vh, never its tile form
+            mode = _lib.FIR_PATH_STRIPS
         lib.cvs_fir_path_override(mode)
     yield pin
     pin(None)
@@ -855,7 +856,7 @@ def force_fir(request):
 _KERNEL_NAMES = {_lib.FIR_KERNEL_NONE: "none", _lib.FIR_KERNEL_WINDOW: "window", _lib.FIR_KERNEL_HALVE: "halve",
                  _lib.FIR_KERNEL_VH: "vh", _lib.FIR_KERNEL_TILED: "tiled", _lib.FIR_KERNEL_STREAM: "stream",
                  _lib.FIR_KERNEL_TWO_PASS: "two-pass", _lib.FIR_KERNEL_PASS: "pass", _lib.FIR_KERNEL_HV: "hv",
-                 _lib.FIR_KERNEL_WINDOW_PAIR: "window-pair", _lib.FIR_KERNEL_HALVE_PAIR: "halve-pair"}
+                 _lib.FIR_KERNEL_WINDOW_PAIR: "window-pair", _lib.FIR_KERNEL_HALVE_PAIR: "halve-pair", _lib.FIR_KERNEL_TILE_VH: "tile-vh"}
 _FIR_SEEN = {}
 
 
@@ -2095,13 +2096,17 @@ def test_scale_bilinear_f16_twin(cvs, orc, tfull, sfull, scur, tp, sp, fac):
         assert_same_f16(got.window_view(), want.window_view(), "f16 scale %r" % (fac,))
 
 
+@pytest.mark.parametrize("form", ["tiles", "strips"])
 @pytest.mark.parametrize("tw,fmt", [(1025, "f16"), (1026, "f16"), (1100, "f32"), (1027, "f32")])
 @pytest.mark.parametrize("fac", [(2.0, 2.0), (1.5, 1.5), (1.25, 1.25)])
-def test_scale_wide_targets_two_columns_per_lane(cvs, orc, tw, fmt, fac):
-    """Targets of 1024 columns and more take the scaler kernel's two-columns-per-lane instances (strips of 128: the adjacent
-    pair as one 16-byte store for halfs, columns l and l + 64 for floats); an odd row pitch (1025, 1027) puts half of the
-    rows' pairs off a 16-byte boundary, so those targets stay with one column per lane.  Ragged last strip either way."""
+def test_scale_wide_targets_two_columns_per_lane(cvs, orc, force_fir, tw, fmt, fac, form):
+    """Enlarging into a wide target, in the kernel's two forms.  Tiles (k_fir_tile_vh, the automatic choice): 128 columns x 16
+    lines per workgroup, two columns per lane.  Strips (k_fir_vh): targets of 1024 columns and more take its
+    two-columns-per-lane instances.  Either way the adjacent pair is one 16-byte store for halfs (columns l and l + 64 for
+    floats), and an odd row pitch (1025, 1027) puts half of the rows' pairs off a 16-byte boundary: those f16 targets go to
+    the strips with one column per lane.  Ragged last strip and ragged last tile row (37 lines) either way."""
     th = 37
+    force_fir("strips" if form == "strips" else None)
     sw, sh = int(tw / fac[0]) + 2, int(th / fac[1]) + 2
     sfull, tfull = (0, 0, sw - 1, sh - 1), (0, 0, tw - 1, th - 1)
     rng = np.random.default_rng(4100 + tw)
@@ -2121,7 +2126,56 @@ def test_scale_wide_targets_two_columns_per_lane(cvs, orc, tw, fmt, fac):
         got = d_out.download()
         assert same_window(got.current_window, want32.current_window)
         assert_same_f32(got.window_view(), want32.window_view(), "wide f32 scale %r" % (fac,))
-    assert cvs.cvs_scale_last_was_fused() == 1 and cvs.cvs_fir_last_kernel() == _lib.FIR_KERNEL_VH
+    tiled = form == "tiles" and not (fmt == "f16" and tw % 2)
+    assert cvs.cvs_scale_last_was_fused() == 1 and cvs.cvs_fir_last_kernel() == (_lib.FIR_KERNEL_TILE_VH if tiled else _lib.FIR_KERNEL_VH)
+
+
+def test_tile_scaler_random_geometry(cvs, orc):
+    """The tile form of the vertical-first scaler (k_fir_tile_vh) takes targets of 256 columns and more whose tables are short
+    and narrow.  80 random set-ups wide enough for it -- enlarging factors with the vertical one never the larger, fractional
+    points, source windows inside their buffers, buffers with negative origins, an Inf and a NaN in the source -- against
+    the oracle, f32 and f16; most of them must indeed have run on the tiles."""
+    rng = np.random.default_rng(4242)
+    seen = {}
+    for case in range(80):
+        fy = float(rng.choice([1.125, 1.25, 1.5, 2.0, 2.5, 3.0]))
+        fx = float(rng.choice([f for f in (1.25, 1.5, 2.0, 2.5, 3.0, 4.0) if f >= fy]))
+        tw, th = int(rng.integers(256, 520)), int(rng.integers(5, 70))
+        tx0, ty0 = int(rng.integers(-6, 4)) * 2, int(rng.integers(-5, 4))
+        tfull = (tx0, ty0, tx0 + tw - 1, ty0 + th - 1)
+        sw, sh = int(tw / fx) + int(rng.integers(-20, 6)), int(th / fy) + int(rng.integers(-3, 4))
+        sx0, sy0 = int(rng.integers(-4, 4)), int(rng.integers(-4, 4))
+        sfull = (sx0, sy0, sx0 + max(sw, 8) - 1, sy0 + max(sh, 3) - 1)
+        scur = sfull if case % 3 else _random_window(rng, sfull, allow_empty=False)
+        tp = (float(rng.choice([0.0, 0.5, 2.25])) + tx0, float(rng.choice([0.0, 1.0, 3.5])) + ty0)
+        sp = (float(rng.choice([0.0, 0.75, 2.0])) + sx0, float(rng.choice([0.0, 0.5, 1.0])) + sy0)
+        src16 = rand_f16_frame(rng, sfull, scur)
+        v = src16.window_view()
+        if v.shape[0] > 2 and v.shape[1] > 9:
+            v[1, 7, 0] = 0x7C00
+            v[v.shape[0] - 1, 3, 2] = 0x7E00
+        src32 = HostFrame(sfull, np.float32, orc.half_to_float(src16.array), scur)
+        want32 = HostFrame(tfull, np.float32)
+        orc.lib().orc_scale_bilinear_f32(want32.ref(), v2f(*tp), src32.ref(), v2f(*sp), v2f(fx, fy))
+        if case % 2:
+            d_src, d_out = DeviceFrame.from_host(src16), DeviceFrame(tfull, np.uint16)
+            _lib.check(cvs.cvs_scale_bilinear_f16_dev(d_out.ref(), v2f(*tp), d_src.ref(), v2f(*sp), v2f(fx, fy), None))
+            got = d_out.download()
+            assert same_window(got.current_window, want32.current_window), (case, got.current_window.tuple(), want32.current_window.tuple())
+            if not want32.current_window.is_empty():
+                assert_same_f16(got.window_view(), orc.float_to_half(want32.window_view()), "tile scale f16, case %d %r" % (case, (fx, fy)))
+        else:
+            d_src, d_out = DeviceFrame.from_host(src32), DeviceFrame(tfull, np.float32)
+            _lib.check(cvs.cvs_scale_bilinear_f32_dev(d_out.ref(), v2f(*tp), d_src.ref(), v2f(*sp), v2f(fx, fy), None))
+            got = d_out.download()
+            assert same_window(got.current_window, want32.current_window), (case, got.current_window.tuple(), want32.current_window.tuple())
+            if not want32.current_window.is_empty():
+                assert_same_f32(got.window_view(), want32.window_view(), "tile scale f32, case %d %r" % (case, (fx, fy)))
+        name = _KERNEL_NAMES[cvs.cvs_fir_last_kernel()]
+        seen[name] = seen.get(name, 0) + 1
+        d_src.free(); d_out.free()
+    assert seen.get("tile-vh", 0) >= 50, seen
+    assert cvs.cvs_fir_fell_through_count() == 0
 
 
 # ------------------------------------------------------------------ randomized window sweeps (region walks of video_mix.c / copy / scale)
@@ -2234,7 +2288,9 @@ def test_scaler_in_one_launch_agrees_with_the_two_passes(cvs, force_fir, fac, fm
     src16.array[5, 7, 1] = 0x7C00                                    # an Inf and a NaN: they must spread the same way
     src16.array[400, 900, 2] = 0x7E00
     outs, fused = [], []
-    for kernel in (None, "stream"):
+    # the tile form takes the enlarging calls whose rows of LDS fit (tile_vh_ops.hip cvk_fir_tvh_supported)
+    tile_cases = {((1.5, 1.5), "f32"), ((2.0, 2.0), "f16"), ((1.25, 1.125), "f32")}
+    for kernel in (None, "strips", "stream"):
         force_fir(kernel)
         if fmt == "f16":
             d_src, d_out = DeviceFrame.from_host(src16), DeviceFrame((0, 0, tw - 1, th - 1), np.uint16)
@@ -2249,18 +2305,16 @@ def test_scaler_in_one_launch_agrees_with_the_two_passes(cvs, force_fir, fac, fm
         # ... and when the horizontal pass goes first: the per-line gather unless the horizontal axis reduces (hv_goes_first)
         # (the horizontal-first gather exists in the default arithmetic flavour only: the contracted one runs the two passes)
         contracted = cvs.cvs_get_arithmetic() == _lib.ARITH_CONTRACTED
-        assert _KERNEL_NAMES[cvs.cvs_fir_last_kernel()] == ("pass" if kernel or (contracted and fac[0] < fac[1]) else "hv" if fac[0] < fac[1] else "vh")
+        vh = "tile-vh" if kernel is None and (fac, fmt) in tile_cases else "vh"
+        assert _KERNEL_NAMES[cvs.cvs_fir_last_kernel()] == ("pass" if kernel == "stream" or (contracted and fac[0] < fac[1]) else "hv" if fac[0] < fac[1] else vh)
         got = d_out.download()
         outs.append((got.current_window.tuple(), got.array.copy()))
         d_src.free(); d_out.free()
     contracted = cvs.cvs_get_arithmetic() == _lib.ARITH_CONTRACTED
-    assert fused == [0 if contracted and fac[0] < fac[1] else 1, 0]
-    assert outs[0][0] == outs[1][0]
-    a, b = outs[0][1], outs[1][1]
-    if fmt == "f16":
-        assert_same_f16(a, b, "scaler, one launch against two")
-    else:
-        assert_same_f32(a, b, "scaler, one launch against two")
+    assert fused == [0 if contracted and fac[0] < fac[1] else 1] * 2 + [0]
+    assert outs[0][0] == outs[1][0] == outs[2][0]
+    for k, form in ((0, "automatic choice"), (1, "strips")):
+        (assert_same_f16 if fmt == "f16" else assert_same_f32)(outs[k][1], outs[2][1], "scaler, one launch (%s) against two" % form)
 
 
 def test_fir_blur_random_geometry(cvs, orc):

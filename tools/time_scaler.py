@@ -1,6 +1,6 @@
 """The reference's own scaler (video_scale_bilinear_f32 and its f16 twin) at the factors the editor uses, per call:
 ms, TB/s of source + target bytes, and which kernel took it (cvs_fir_last_kernel).  Sources rotate over enough frames to
-stay out of the Infinity Cache.   usage: python3 tools/time_scaler.py [--reps 40]"""
+stay out of the Infinity Cache.   usage: python3 tools/time_scaler.py [--reps 40] [--only NAME] [--strips]"""
 import argparse
 import ctypes as C
 import os
@@ -14,19 +14,36 @@ from canvas_amd import _lib, synth                      # noqa: E402
 from canvas_amd.abi import v2f                          # noqa: E402
 from canvas_amd.device import DeviceFrame               # noqa: E402
 
-NAMES = ["none", "window", "halve", "lanes", "vh", "tiled", "stream", "two-pass", "pass", "hv", "window-pair", "halve-pair"]
+NAMES = ["none", "window", "halve", "lanes", "vh", "tiled", "stream", "two-pass", "pass", "hv", "window-pair", "halve-pair", "tile-vh"]
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=40)
     ap.add_argument("--only", default="")
+    ap.add_argument("--streams", type=int, default=1, help="frames alternate over this many HIP streams (the bench's scaler record uses 2)")
+    ap.add_argument("--diag-mode", type=int, default=0, help="diagnostic build only: k_fir_tile_vh's timing-only variants (1: stores only)")
+    ap.add_argument("--strips", action="store_true", help="pin the vertical-first scaler to k_fir_vh's strips (CVS_FIR_PATH_STRIPS)")
     args = ap.parse_args()
+    if args.diag_mode:
+        from tools._diag import use_diag_library
+        use_diag_library()
     if os.environ.get("CANVAS_LIB"):                      # A/B runs: another build of the library (never set by the package)
         _lib.LIB_PATH = os.environ["CANVAS_LIB"]
     lib = _lib.load()
     assert lib.cvs_init(0) == 0
     lib.init_half()
+    if args.strips:
+        lib.cvs_fir_path_override(_lib.FIR_PATH_STRIPS)
+    if args.diag_mode:
+        lib.cvk_fir_tvh_diag_mode.restype, lib.cvk_fir_tvh_diag_mode.argtypes = C.c_int, [C.c_int]
+        assert lib.cvk_fir_tvh_diag_mode(args.diag_mode) == 0
+    streams = [None] if args.streams <= 1 else [lib.cvs_stream_create() for _ in range(args.streams)]
+    nout = max(2, 2 * len(streams))
+
+    def sync():
+        for st in streams:
+            lib.cvs_stream_sync(st)
     cases = [("1080p->4K", (1920, 1080), (2.0, 2.0)), ("4K->1080p", (3840, 2160), (0.5, 0.5)), ("4K->0.75", (3840, 2160), (0.75, 0.75)),
              ("4K->1.5", (3840, 2160), (1.5, 1.5)), ("4K->2x", (3840, 2160), (2.0, 2.0)), ("4K->0.4", (3840, 2160), (0.4, 0.4)),
              ("4K->0.3", (3840, 2160), (0.3, 0.3)), ("4K->0.75x1.5", (3840, 2160), (0.75, 1.5)), ("4K->1.25x1.125", (3840, 2160), (1.25, 1.125))]
@@ -58,21 +75,21 @@ def main():
                     else:
                         _lib.check(lib.cvs_memcpy_d2d(d.ptr, srcs[0].ptr, d.nbytes, None))
                     srcs.append(d)
-            outs = [DeviceFrame((0, 0, tw - 1, th - 1), np.uint16 if fmt == "f16" else np.float32) for _ in range(2)]
+            outs = [DeviceFrame((0, 0, tw - 1, th - 1), np.uint16 if fmt == "f16" else np.float32) for _ in range(nout)]
             lib.cvs_stream_sync(None)
             call = lib.cvs_scale_bilinear_f16_dev if fmt == "f16" else lib.cvs_scale_bilinear_f32_dev
 
             def run(i):
-                _lib.check(call(outs[i & 1].ref(), v2f(0, 0), srcs[i % nsrc].ref(), v2f(0, 0), v2f(*fac), None))
+                _lib.check(call(outs[i % nout].ref(), v2f(0, 0), srcs[i % nsrc].ref(), v2f(0, 0), v2f(*fac), streams[i % len(streams)]))
             for i in range(3):
                 run(i)
-            lib.cvs_stream_sync(None)
+            sync()
             best = 1e9
             for rep in range(3):
                 t0 = time.perf_counter()
                 for i in range(args.reps):
                     run(i)
-                lib.cvs_stream_sync(None)
+                sync()
                 best = min(best, (time.perf_counter() - t0) / args.reps)
             nbytes = (w * h + tw * th) * bpp
             print("%-16s %s  %.4f ms  %.2f TB/s (%.3f of 8)  kernel=%s fused=%d" % (
