@@ -198,7 +198,7 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
                   n * len(srcs), w * h, dt, digest, verify.stream_fixture("scaler_1920x1080_x2.00", g0), 10,
                   "Mpixels/s and bytes are per OUTPUT pixel: source read once (2 B per output px) + target written once; both passes in one launch; "
                   "frames alternate over two HIP streams", rank,
-                  kernels=["k_fir_vh<2, 2, 2, f16, 2 px per lane> (one launch)"])
+                  kernels=["k_fir_tile_vh<2, 2, f16> (one launch: a workgroup per 128 columns x 64 lines, source rows in LDS)"])
     if rec:
         out.append(rec)
     for d in srcs + bigs:

@@ -565,11 +565,29 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
             for (int k = 0; k < n; k++) memcpy(&r[2 + k], &tb->taps[(size_t)i * tb->stride + k], 4);
         }
     }
+    /* ... and, for short lists, by target line in one aligned read each (kernels.h cvk_fir_axis.pack) */
+    const int pack_width = max_taps >= 1 && max_taps <= 2 ? 2 : max_taps <= 4 && max_taps >= 1 ? 4 : 0;
+    uint32_t *pack = NULL;
+    if (pack_width) {
+        pack = malloc((size_t)(lines ? lines : 1) * 2 * (size_t)pack_width * sizeof *pack);
+        if (!pack) { free(foot); free(ntaps); free(lrec); return -1; }
+        for (int i = 0; i < lines; i++) {
+            uint32_t *r = pack + (size_t)i * 2 * pack_width;
+            for (int k = 0; k < pack_width; k++) {
+                const bool has = k < ntaps[i];
+                const float zero = 0.0f;
+                r[k] = has ? (uint32_t)tb->tap_src[(size_t)i * tb->stride + k] : (uint32_t)INT_MIN;
+                memcpy(&r[pack_width + k], has ? &tb->taps[(size_t)i * tb->stride + k] : &zero, 4);
+            }
+        }
+    }
     const size_t n_l = (size_t)(lines ? lines : 1), n_t = n_l * (size_t)tb->stride;
     const size_t off_src = CVK_AXIS_OFF_SRC(lines), off_tap = CVK_AXIS_OFF_TAPS(lines, tb->stride), off_foot = CVK_AXIS_OFF_FOOT(lines, tb->stride);
     const size_t off_lrec = off_foot + ((sizeof(int) * 2 * (size_t)tiles_pad + 255) & ~(size_t)255);
     const size_t lrec_bytes = lrec ? ((size_t)lines + 1) * CVK_FIR_LREC * sizeof *lrec : 0;
-    const size_t total = off_lrec + (lrec_bytes ? lrec_bytes : 4);
+    const size_t off_pack = off_lrec + (((lrec_bytes ? lrec_bytes : 4) + 255) & ~(size_t)255);
+    const size_t pack_bytes = pack ? n_l * 2 * (size_t)pack_width * sizeof *pack : 0;
+    const size_t total = off_pack + (pack_bytes ? pack_bytes : 4);
     char *dev = NULL;
     hipError_t err = hipMalloc((void **)&dev, total);
     if (err == hipSuccess) err = hipMemcpy(dev, ntaps, n_l * sizeof(int), hipMemcpyHostToDevice);
@@ -577,7 +595,8 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     if (err == hipSuccess) err = hipMemcpy(dev + off_tap, tb->taps, n_t * sizeof(float), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(dev + off_foot, foot, sizeof(int) * 2 * (size_t)tiles_pad, hipMemcpyHostToDevice);
     if (err == hipSuccess && lrec_bytes) err = hipMemcpy(dev + off_lrec, lrec, lrec_bytes, hipMemcpyHostToDevice);
-    free(foot); free(ntaps); free(lrec);
+    if (err == hipSuccess && pack_bytes) err = hipMemcpy(dev + off_pack, pack, pack_bytes, hipMemcpyHostToDevice);
+    free(foot); free(ntaps); free(lrec); free(pack);
     if (err != hipSuccess) { if (dev) hipFree(dev); cvs_set_error("FIR table upload: %s", hipGetErrorString(err)); return -1; }
     e->dev = dev;
     e->axis.ntaps = (const int *)dev;
@@ -587,6 +606,7 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
     e->axis.stride = tb->stride; e->axis.lines = lines;
     e->axis.max_taps = max_taps; e->axis.wide_foot = wide_foot; e->axis.max_active = max_active; e->axis.streamable = streamable;
     e->axis.lrec = lrec_bytes ? (const uint32_t *)(dev + off_lrec) : NULL;
+    e->axis.pack = pack_bytes ? (const uint32_t *)(dev + off_pack) : NULL; e->axis.pack_width = pack_bytes ? pack_width : 0;
     memcpy(e->axis.span_lines, span_lines, sizeof span_lines);
     e->max_foot = max_foot;
     return 0;

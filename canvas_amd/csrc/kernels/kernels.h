@@ -158,6 +158,11 @@ typedef struct {
      * than CVK_FIR_LREC - 2): [0] tap count, [1] first source line (INT_MIN for a line without taps), [2 + k] weight of
      * tap k; unused entries 0.  One spare all-zero record (count 0) follows the last.  sweep_vh_ops.hip reads one per line. */
     const uint32_t *lrec;
+    /* the table by target line for short lists (longest <= 4; width pack_width = 2 or 4): pack_width source lines, then
+     * pack_width weights per line, 32-bit each; entries past the line's count: source line INT_MIN, weight 0.  One aligned
+     * 16- or 32-byte read per line instead of 1 + 2 x count scattered ones (tile_vh_ops.hip: lane = line).  NULL otherwise. */
+    const uint32_t *pack;
+    int pack_width;
     int span_lines[3];         /* (streamable tables) most source lines any 16, 32, 64 consecutive target lines reach, first tap of the first to last tap of the last */
 } cvk_fir_axis;
 #define CVK_FIR_LREC 32

@@ -1,25 +1,28 @@
-// tile_vh_ops.hip -- separable FIR with per-line tap tables, VERTICAL pass first, one workgroup per tile of the target.
+// tile_vh_ops.hip -- separable FIR with per-line tap tables, VERTICAL pass first, a workgroup per block of the target.
 //
 // The enlarging case of video_scale_bilinear_f32 (video_scale.c:231-286; pass order :252, vertical sums :63-122, horizontal
-// sums :161-226).  sweep_vh_ops.hip walks a strip of the target line by line with one wave: every line is a chain
-// record -> window -> vertical sum -> LDS row -> horizontal sum -> store, about 1 900 cycles a line whatever the arithmetic
-// costs (profiles/r04/vh_clocks_*.txt), and when the target is the large frame the chip spends its time waiting on those
-// chains.  Here a workgroup of four waves takes a tile of 128 columns x 16 lines and runs the two passes as two sweeps over
-// LDS with a barrier between them, so that nothing inside a pass depends on anything else inside it:
-//   1. the source rows the tile's lines reach (first tap of its first line .. last tap of its last) x the source columns
-//      under its 128 target columns (four tiles of the horizontal table's footprint list) are loaded -- every load of a lane
-//      requested before the first is used -- widened and written to S[row][column];
-//   2. V: M[line][column] = S[first][column] w0 + S[first + 1][column] w1 ... in ascending source order, exactly the line's
-//      n taps (count, first row and weights: one scalar load per line from cvk_fir_axis.lrec); a line without taps is zeros;
-//      wave w takes lines w, w + 4, ...; lanes take the columns;
-//   3. H: each lane gathers the taps of its two target columns from M[line] -- sum from the first product in ascending tap
-//      order, padded taps read the row's zero pixel with weight 0 -- narrows and stores: 1 KB per wave and line.
+// sums :161-226).  sweep_vh_ops.hip walks a strip of the target line by line with one wave, every line a chain
+// record -> window -> vertical sum -> LDS row -> horizontal sum -> store; when the target is the large frame the chip spends
+// its time in those chains and in the set-up in front of them (profiles/r04/vh_clocks_*.txt).  Here a workgroup of four
+// waves takes 128 columns x 16, 32 or 64 lines (a segment), and:
+//   1. set-up, two trips to memory.  First trip, on the preloaded arguments alone: the packed tap lists of the lane's two
+//      target columns (cvk_fir_axis.pack: one aligned read per column, lanes consecutive), the segment's line records,
+//      the footprint entries of the 128 columns and the first and last line's record (row range), next to the fetch of the
+//      remaining arguments.  Second trip: the source rows the segment's lines reach x the source columns under the 128
+//      target columns, every load of a lane requested before the first is used; widened and written to S[row][column];
+//   2. one barrier; then wave w takes lines w, w + 4, ... and each lane its two target columns: for each of a column's
+//      horizontal taps the lane forms the vertical sum at that source column itself -- S[first .. first + n - 1][column] times
+//      the line's weights in ascending order, exactly the line's n taps -- and adds the products in ascending tap order
+//      (padded taps: the row's zero pixel, weight 0), narrows, stores: 1 KB per wave and line.  The vertical sum of a
+//      source column is formed by every lane whose taps name it, to the same bits: arithmetic instead of an intermediate
+//      row in LDS with a barrier per line group (the first form of this kernel; both are in profiles/r04).
 // Same sums in the same order as k_fir_vh and as the two k_fir launches: the three are bit-equal (tests/test_gpu_parity.py).
-// Algorithmic bytes: source pixel once + target pixel once (a tile re-reads the one or two source rows and columns its
+// Algorithmic bytes: source pixel once + target pixel once (a segment re-reads the one or two source rows and columns its
 // neighbours also reach: + 10..25 % of the SOURCE, which is the small frame here).
 #include <atomic>
 #include <climits>
 #include <cstdlib>
+#include <type_traits>
 #include "kernels.h"
 #include "chain_math.hpp"
 #include "sweep_common.hpp"
@@ -30,8 +33,8 @@
 __device__ unsigned long long *g_tvh_clocks;
 extern "C" __attribute__((visibility("default"))) int cvk_fir_tvh_clock_buffer(void *dev) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tvh_clocks), &dev, sizeof dev); }
 // (the buffer pointer is read once, at the kernel's start: a probe that fetched it again would time its own fetch)
-// timing-only variants (wrong pixels on purpose): 1 = stores only, in the kernel's own pattern, nothing read or computed;
-// 2 = everything but the stores' data dependence (the set-up and the line loop run, zeros are stored)
+// timing-only variants (wrong pixels on purpose; tools/time_scaler.py --diag-mode): 1 = stores only, in the kernel's own
+// pattern, nothing read or computed; 2 = the whole set-up, then stores only; 3 = everything but the source rows' loads
 __device__ int g_tvh_mode;
 extern "C" __attribute__((visibility("default"))) int cvk_fir_tvh_diag_mode(int mode) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tvh_mode), &mode, sizeof mode); }
 #define CVS_TVH_DIAG 1
@@ -47,26 +50,24 @@ namespace {
 using cvs::f32x2;
 
 constexpr int kTW = 128, kThreads = 256, kWaves = kThreads / 64;
-constexpr int kNJ = 8;           // source pixels a lane stages at most (all requested at once)
+constexpr int kNJ = 9;           // source pixels a lane stages at most (all requested at once)
 static_assert(kTW == 4 * CVK_FIR2D_TILE_X, "a tile spans four entries of the footprint table");
 
-__device__ __forceinline__ Px zero_px() { return Px{ f32x2{ 0.0f, 0.0f }, f32x2{ 0.0f, 0.0f } }; }
 // "this value is needed here": keeps hipcc from sinking an LDS read into the branch that first uses it, where it would be
 // requested and waited for on its own (a line's reads then cost one LDS trip each instead of one for all)
-__device__ __forceinline__ void pin(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void pin(Px &v) { asm volatile("" : "+v"(v.lo), "+v"(v.hi)); }           // (as the two register pairs the packed arithmetic takes)
 __device__ __forceinline__ void pin(uint4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
-// seg: target lines per workgroup (a multiple of kSub); swp: pixels per LDS row (>= source columns under any 128 target
-// columns + 1: the last is the row's zero pixel); shp: rows of S (>= source rows under any `seg` consecutive lines)
+// seg: target lines per workgroup; swp: pixels per LDS row (>= source columns under any 128 target columns + 1: the last
+// is the row's zero pixel); shp: rows of S (>= source rows under any `seg` consecutive lines)
 // The first arguments are what the set-up needs before anything else, as plain scalars: hipcc is told to have them preloaded
 // into SGPRs (-amdgpu-kernarg-preload-count, csrc/Makefile), so the first table reads do not wait for a kernarg fetch.
 template <int MAXTV, int MAXTH, bool INH>
-__global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const char *hblock, const uint32_t *vlrec, int line0, int seg, int tx0, int tx1, int ty0, int ty1,
-                                                         int hstride, int hlines, int swp, int shp, cvk_fir2d_params fp) {
+__global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const uint32_t *hpack, const int *hfoot, const uint32_t *vlrec, int line0, int seg, int tx0, int tx1, int ty0, int ty1,
+                                                         int swp, int shp, cvk_fir2d_params fp) {
     static_assert(MAXTV >= 1 && MAXTV <= 4 && MAXTH >= 1 && MAXTH <= 8, "instances (a record in LDS holds four weights)");
     extern __shared__ __align__(16) unsigned char tile_lds[];
-    typedef float4 raw_t;                                                // a source pixel in LDS: widened once, when it is staged (every
-                                                                         // use would otherwise pay four conversions: the line loop is VALU-bound)
+    typedef float4 raw_t;                                                // a source pixel in LDS: widened once, when it is staged
     uint4 *R = reinterpret_cast<uint4 *>(tile_lds);                      // [seg][2]  the segment's line records: count, first row, four weights
     raw_t *S = reinterpret_cast<raw_t *>(R + 2 * seg);                   // [shp][swp]  the segment's source rows, widened
     const int tid = threadIdx.x, lane = tid & 63;
@@ -94,32 +95,30 @@ __global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const char *hblock, co
     // table lines of this segment (counted from fp.ty0); the launch covers lines line0 .. nlines - 1
     const int ia = line0 + (int)blockIdx.y * seg, ib = min(ia + seg - 1, nlines - 1);
     const int tl = ib - ia + 1;
-    // the horizontal table's parts, from the start of its device block (kernels.h CVK_AXIS_OFF_*)
-    const int *const h_ntaps = reinterpret_cast<const int *>(hblock);
-    const int *const h_src = reinterpret_cast<const int *>(hblock + CVK_AXIS_OFF_SRC(hlines));
-    const float *const h_taps = reinterpret_cast<const float *>(hblock + CVK_AXIS_OFF_TAPS(hlines, hstride));
-    const konst foot = as_konst(hblock + CVK_AXIS_OFF_FOOT(hlines, hstride));
+    const konst foot = as_konst(hfoot);
     const int zcol = swp - 1;                                            // the zero pixel of every S row
 
     // --- set-up in two trips to memory.  First: what depends on the preloaded arguments only -- the tap lists, the segment's
     // records, the footprint entries and the segment's first and last record (scalar) -- next to the fetch of the remaining
     // arguments.  Second: the source rows.  No load waits for another inside a trip.
     constexpr int LR = CVK_FIR_LREC;
-    // the horizontal taps of this lane's two columns (all MAXTH of each, clamped into the line's list: which of them are
-    // taps is decided afterwards, so the loads do not wait for the count)
+    // the horizontal taps of this lane's two columns: one aligned read each of the packed list (kernels.h cvk_fir_axis.pack:
+    // MAXTH source columns, MAXTH weights; past the column's count: INT_MIN, 0) -- lanes read consecutive records
     bool col_live[2];
-    int hn[2], hsrc[2][MAXTH];
+    int hsrc[2][MAXTH];
     float hw[2][MAXTH];
 #pragma unroll
     for (int p = 0; p < 2; p++) {
         col_live[p] = tcol + p * cstep <= tx1;
         const int hline = min(tcol + p * cstep, tx1) - tx0;
-        hn[p] = h_ntaps[hline];
-#pragma unroll
-        for (int k = 0; k < MAXTH; k++) {
-            const size_t at = (size_t)hline * hstride + min(k, hstride - 1);
-            hsrc[p][k] = h_src[at];
-            hw[p][k] = h_taps[at];
+        if constexpr (MAXTH == 2) {
+            const uint4 r = *reinterpret_cast<const uint4 *>(hpack + (size_t)hline * 4);
+            hsrc[p][0] = (int)r.x; hsrc[p][1] = (int)r.y; hw[p][0] = __uint_as_float(r.z); hw[p][1] = __uint_as_float(r.w);
+        } else {
+            static_assert(MAXTH == 4, "packed lists are two or four wide");
+            const uint4 a = *reinterpret_cast<const uint4 *>(hpack + (size_t)hline * 8), b = *reinterpret_cast<const uint4 *>(hpack + (size_t)hline * 8 + 4);
+            hsrc[p][0] = (int)a.x; hsrc[p][1] = (int)a.y; hsrc[p][2] = (int)a.z; hsrc[p][3] = (int)a.w;
+            hw[p][0] = __uint_as_float(b.x); hw[p][1] = __uint_as_float(b.y); hw[p][2] = __uint_as_float(b.z); hw[p][3] = __uint_as_float(b.w);
         }
     }
     // the segment's line records go to LDS with the rows (lane = line), so that the line loop never goes to memory for one
@@ -173,7 +172,12 @@ __global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const char *hblock, co
     // 1. stage the segment's rows (requested before the tap lists and records are looked at: same trip): pixel
     //    u = row * sw + column of the block, lane tid takes u = tid, tid + 256, ... (at most kNJ of them: the host checked);
     //    all of a lane's loads are requested before the first is used
-    if (sw > 0 && sh > 0) {
+#ifdef CVS_TVH_DIAG
+    const bool skip_rows = g_tvh_mode == 3;
+#else
+    constexpr bool skip_rows = false;
+#endif
+    if (sw > 0 && sh > 0 && !skip_rows) {
         constexpr int PXB = INH ? 8 : 16;
         const int units = min(sh * sw, kNJ * kThreads);
         const float inv_sw = 1.0f / (float)sw;
@@ -183,7 +187,8 @@ __global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const char *hblock, co
         int sidx[kNJ];
 #pragma unroll
         for (int j = 0; j < kNJ; j++) {
-            const int u = min(tid + j * kThreads, units - 1);            // clamped: every load unconditional
+            if (j * kThreads >= units) break;                            // (uniform) no lane has a j-th pixel
+            const int u = min(tid + j * kThreads, units - 1);            // clamped: the load itself is unconditional
             int r = (int)(((float)u + 0.5f) * inv_sw);                   // u / sw, up to one either way (u < 2^22)
             int c = u - r * sw;
             const int fix = (c >= sw ? 1 : 0) - (c < 0 ? 1 : 0);
@@ -195,15 +200,14 @@ __global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const char *hblock, co
         for (int j = 0; j < kNJ; j++)
             if (tid + j * kThreads < units) { const Px w = widen(v[j]); S[sidx[j]] = make_float4(w.lo.x, w.lo.y, w.hi.x, w.hi.y); }
     }
-    // columns of the M row and weights; padded taps -> the row's zero pixel, weight 0
+    // columns of the S row and weights; padded taps (and columns past the target's last) -> the row's zero pixel, weight 0
     int acol[2][MAXTH];
     float wt[2][MAXTH];
 #pragma unroll
     for (int p = 0; p < 2; p++) {
-        const int n = col_live[p] ? min(hn[p], MAXTH) : 0;
 #pragma unroll
         for (int k = 0; k < MAXTH; k++) {
-            const bool live = k < n;
+            const bool live = col_live[p] && hsrc[p][k] != INT_MIN;
             acol[p][k] = live ? min(max(hsrc[p][k] - sx_lo, 0), zcol) : zcol;
             wt[p][k] = live ? hw[p][k] : 0.0f;
         }
@@ -250,26 +254,39 @@ __global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const char *hblock, co
     //    and what it saves is the intermediate row in LDS with its barrier per line group.  All reads of a line (and the
     //    next line's record) are requested before the first is used: every address is valid whatever the counts are, the
     //    counts only decide what is added.
-    constexpr bool kBothAtOnce = MAXTH * MAXTV <= 4;              // registers: both pixels' reads in flight, or one pixel's
+    constexpr bool kBothAtOnce = MAXTH * MAXTV <= 4;                     // registers: both pixels' reads in flight, or one pixel's
     RawRec first_rec = read_rec(wave);
     Rec rc = decode(first_rec);
+#ifdef CVS_TVH_DIAG
+    if (g_tvh_mode == 2) {                                               // the whole set-up, then stores only
+        for (int line = wave; line < tl; line += kWaves) {
+            char *q = obase + (size_t)line * trow;
+            if (out_half) { if (all_live || col_live[1]) *reinterpret_cast<uint4 *>(q) = make_uint4(line, lane, 0, 0); }
+            else { if (all_live || col_live[0]) *reinterpret_cast<uint4 *>(q) = make_uint4(line, lane, 0, 0); if (all_live || col_live[1]) *reinterpret_cast<uint4 *>(q + 1024) = make_uint4(line, lane, 0, 0); }
+        }
+        return;
+    }
+#endif
     for (int line = wave; line < tl; line += kWaves) {
         const Rec cur = rc;
         const int n = cur.n;                                             // uniform
         RawRec nxt = read_rec(line + kWaves);
-        raw_t sp[2][MAXTH][MAXTV];
+        Px sp[kBothAtOnce ? 2 : 1][MAXTH][MAXTV];                       // (one pixel's at a time when they are many)
         auto request = [&](int p) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < MAXTH; j++) {
 #pragma unroll
-                for (int k = 0; k < MAXTV; k++) sp[p][j][k] = S[cur.row + min(k, max(n - 1, 0)) * swp + acol[p][j]];
+                for (int k = 0; k < MAXTV; k++) {
+                    const float4 v = S[cur.row + min(k, max(n - 1, 0)) * swp + acol[p][j]];
+                    sp[kBothAtOnce ? p : 0][j][k] = Px{ f32x2{ v.x, v.y }, f32x2{ v.z, v.w } };
+                }
             }
         };
         auto landed = [&](int p) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < MAXTH; j++) {
 #pragma unroll
-                for (int k = 0; k < MAXTV; k++) pin(sp[p][j][k]);
+                for (int k = 0; k < MAXTV; k++) pin(sp[kBothAtOnce ? p : 0][j][k]);
             }
         };
         request(0);
@@ -278,31 +295,39 @@ __global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const char *hblock, co
         if constexpr (MAXTV > 2) pin(nxt.b);
         rc = decode(nxt);
         f32x2 hlo[2], hhi[2];
+        // the vertical sum at each tap's source column -- exactly the line's taps, ascending -- times the tap's weight, added
+        // in ascending tap order.  The usual line has all MAXTV taps: its chain has no test in it (wave-uniform choice).
+        auto sums = [&](auto full) __attribute__((always_inline)) {
 #pragma unroll
-        for (int p = 0; p < 2; p++) {
-            if (p == 1 && !kBothAtOnce) request(1);
-            if (p == 0 || !kBothAtOnce) landed(p);
-            if (p == 0 && kBothAtOnce) landed(1);
+            for (int p = 0; p < 2; p++) {
+                if (p == 1 && !kBothAtOnce) request(1);
+                if (p == 0 || !kBothAtOnce) landed(p);
+                if (p == 0 && kBothAtOnce) landed(1);
 #pragma unroll
-            for (int j = 0; j < MAXTH; j++) {
-                Px mid = zero_px();
-                if (n > 0) {
-                    const Px p0 = { f32x2{ sp[p][j][0].x, sp[p][j][0].y }, f32x2{ sp[p][j][0].z, sp[p][j][0].w } };
+                for (int j = 0; j < MAXTH; j++) {
                     const f32x2 w0 = { cur.w[0], cur.w[0] };
-                    mid.lo = p0.lo * w0; mid.hi = p0.hi * w0;            // (0 + p0 is p0: gather_common.hpp vsum)
+                    const int q = kBothAtOnce ? p : 0;
+                    Px mid = { sp[q][j][0].lo * w0, sp[q][j][0].hi * w0 };       // (0 + p0 is p0: gather_common.hpp vsum)
 #pragma unroll
                     for (int k = 1; k < MAXTV; k++) {
-                        if (k < n) {
-                            const Px pk = { f32x2{ sp[p][j][k].x, sp[p][j][k].y }, f32x2{ sp[p][j][k].z, sp[p][j][k].w } };
+                        if (decltype(full)::value || k < n) {
                             const f32x2 wk = { cur.w[k], cur.w[k] };
-                            mid.lo = cvs::madd(pk.lo, wk, mid.lo);       // t += s * coeff
-                            mid.hi = cvs::madd(pk.hi, wk, mid.hi);
+                            mid.lo = cvs::madd(sp[q][j][k].lo, wk, mid.lo);      // t += s * coeff
+                            mid.hi = cvs::madd(sp[q][j][k].hi, wk, mid.hi);
                         }
                     }
+                    const f32x2 wj = { wt[p][j], wt[p][j] };
+                    if (j == 0) { hlo[p] = mid.lo * wj; hhi[p] = mid.hi * wj; }
+                    else { hlo[p] = cvs::madd(mid.lo, wj, hlo[p]); hhi[p] = cvs::madd(mid.hi, wj, hhi[p]); }
                 }
-                const f32x2 wj = { wt[p][j], wt[p][j] };
-                if (j == 0) { hlo[p] = mid.lo * wj; hhi[p] = mid.hi * wj; }
-                else { hlo[p] = cvs::madd(mid.lo, wj, hlo[p]); hhi[p] = cvs::madd(mid.hi, wj, hhi[p]); }
+            }
+        };
+        if (__builtin_expect(n == MAXTV, 1)) sums(std::true_type{});
+        else {
+            sums(std::false_type{});
+            if (n <= 0) {                                                // a line without taps is zeros
+#pragma unroll
+                for (int p = 0; p < 2; p++) { hlo[p] = f32x2{ 0.0f, 0.0f }; hhi[p] = f32x2{ 0.0f, 0.0f }; }
             }
         }
         char *optr = obase + (size_t)line * trow;
@@ -344,19 +369,19 @@ int launch(const cvk_fir2d_params &fp, int line0, hipStream_t s) {
     const int seg = pick_seg(&fp);
     dim3 grid((unsigned)((cols + kTW - 1) / kTW), (unsigned)((rows + seg - 1) / seg));
     hipLaunchKernelGGL((k_fir_tile_vh<MAXTV, MAXTH, INH>), grid, dim3(kThreads), lds_bytes(&fp, seg), s,
-                       reinterpret_cast<const char *>(fp.h.ntaps), fp.v.lrec, line0, seg, fp.tx0, fp.tx1, fp.ty0, fp.ty1,
-                       fp.h.stride, fp.h.lines, row_pixels(&fp), seg_rows(&fp, seg), fp);
+                       fp.h.pack, fp.h.foot, fp.v.lrec, line0, seg, fp.tx0, fp.tx1, fp.ty0, fp.ty1, row_pixels(&fp), seg_rows(&fp, seg), fp);
     return (int)hipGetLastError();
 }
 
 typedef int (*launch_fn)(const cvk_fir2d_params &, int, hipStream_t);
 struct Instance { int maxtv, maxth; launch_fn f16, f32; };
 #define CVK_TVH_INSTANCE(V, H) { V, H, launch<V, H, true>, launch<V, H, false> }
-const Instance kInstances[] = { CVK_TVH_INSTANCE(2, 2), CVK_TVH_INSTANCE(4, 4) };
+const Instance kInstances[] = { CVK_TVH_INSTANCE(2, 2), CVK_TVH_INSTANCE(4, 2), CVK_TVH_INSTANCE(2, 4), CVK_TVH_INSTANCE(4, 4) };
 
+// (the horizontal instance width is the packed list's width: the kernel reads whole records)
 const Instance *pick(const cvk_fir2d_params *fp) {
     for (const Instance &in : kInstances)
-        if (fp->v.max_taps <= in.maxtv && fp->h.max_taps <= in.maxth) return &in;
+        if (fp->v.max_taps <= in.maxtv && fp->h.pack != NULL && fp->h.pack_width == in.maxth) return &in;
     return NULL;
 }
 

@@ -159,7 +159,7 @@ PLAN = [
     ("k_blur_halve_pair<9, 11, 128>", ["config3", "config3_contracted"], 4, PX4K * 8 + PX1080 * 8, "config 3: 4K f16 in, 1080p f16 out; 128-lane workgroups, four frames per launch, two streams"),
     ("k_blur_pair<9, 64, 3>", ["config5", "config5_contracted"], 4, PX4K * 40, "config 5, blur + 3 overlays: 8 r + 24 r + 8 w per px; 64-lane workgroups, four frames per launch, two streams"),
     ("k_color_flat<true, false>", ["config5", "config5_contracted"], 1, PX4K * 16, "config 5, colour launch: 8 r + 8 w per px, one frame per launch"),
-    ("k_fir_vh<2, 2, 2, true, 2>", ["scaler_x2.00"], 1, PX1080 * 8 + PX4K * 8, "scaler 1080p -> 4K f16, one frame per launch, two streams"),
+    ("k_fir_tile_vh<2, 2, true>", ["scaler_x2.00"], 1, PX1080 * 8 + PX4K * 8, "scaler 1080p -> 4K f16, one frame per launch, two streams"),
     ("k_chain<3, 1, false, false, 0>", ["config4"], 1, PX8K * 32, "config 4: three 8K layers in, one out, one frame per launch"),
 ]
 xs = {}
@@ -183,7 +183,7 @@ for pat, recs, fpl, algo_b, note in PLAN:
         rec["algorithmic_bytes_per_frame"] = algo_b
         rec["frac_of_8TBps_on_these_bytes_at_trace_rate"] = round(algo_b / (per_frame_us * 1e-6) / 8e12, 4)
         if "FETCH_SIZE" in cm and "WRITE_SIZE" in cm:
-            lanes16 = not pat.startswith("k_fir_vh")
+            lanes16 = not pat.startswith("k_fir_")
             fb = cm["FETCH_SIZE"] * 1024 * (rf16 if lanes16 else rf8)
             wb = cm["WRITE_SIZE"] * 1024
             rec["traffic"] = {"per": "LAUNCH of %d frame(s)" % fpl, "FETCH_SIZE_KiB_per_launch": round(cm["FETCH_SIZE"], 1), "read_factor_applied": 2.0,
