@@ -42,7 +42,7 @@ static void fir_launch_fell_through(const char *kernel, int rc) {
     t_fell_through++;
     cvs_log_warning("%s did not launch (%s): falling back to the next FIR kernel", kernel, hipGetErrorString((hipError_t)rc));
 }
-CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_HV | CVS_FIR_PATH_ONE_COLUMN | CVS_FIR_PATH_TWO_COLUMNS | CVS_FIR_PATH_STRIPS)); }
+CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_HV | CVS_FIR_PATH_ONE_COLUMN | CVS_FIR_PATH_TWO_COLUMNS | CVS_FIR_PATH_STRIPS | CVS_FIR_PATH_TILES)); }
 
 typedef struct {
     int t0, t1;            /* target lines covered by the table */
@@ -220,8 +220,11 @@ static int triangle_fused_vh(any_frame *target, v2f tp, const any_frame *source,
             fp.ty0 = mid_full->min.y; fp.ty1 = hi2;                   /* the vertical table's lines; lo2 .. hi2 of them are produced */
             fp.h = th; fp.v = tv;
             fp.max_sw = hfoot > 0 ? hfoot : 1;
-            /* short lists over few source pixels (enlarging): a workgroup per tile; else a wave per strip */
-            const bool tiles = hhi >= hlo && !(atomic_load(&g_fir_path) & CVS_FIR_PATH_STRIPS) && CVK(cvk_fir_tvh_supported)(&fp);
+            /* short lists over few source pixels (enlarging): a workgroup per tile where that is the faster form (pinned:
+             * wherever it takes the call); else a wave per strip */
+            const int pinned = atomic_load(&g_fir_path);
+            const bool tiles = hhi >= hlo && !(pinned & CVS_FIR_PATH_STRIPS) &&
+                               ((pinned & CVS_FIR_PATH_TILES) ? CVK(cvk_fir_tvh_supported)(&fp) : CVK(cvk_fir_tvh_preferred)(&fp));
             if (hhi >= hlo && (tiles || CVK(cvk_fir_vh_supported)(&fp))) {
                 /* video_scale.c:25-32,44: rows the pass leaves alone are zeros */
                 const bool covers = lo2 == tf->min.y && hi2 == tf->max.y;

@@ -38,6 +38,7 @@
 #define cvk_fir_vh_supported         cvk_fir_vh_supported_fma
 #define cvk_fir_vh                   cvk_fir_vh_fma
 #define cvk_fir_tvh_supported        cvk_fir_tvh_supported_fma
+#define cvk_fir_tvh_preferred        cvk_fir_tvh_preferred_fma
 #define cvk_fir_tvh                  cvk_fir_tvh_fma
 #define cvk_blur_supported           cvk_blur_supported_fma
 #define cvk_blur_takes_pairs         cvk_blur_takes_pairs_fma
@@ -198,6 +199,7 @@ int cvk_fir_vh(const cvk_fir2d_params *fp, int line0, int cus, void *stream);
 /* the same, a workgroup per tile of 128 columns x CVK_FIR_TVH_LINES lines with both passes through LDS (tile_vh_ops.hip):
  * for tables with short lists and narrow footprints (enlarging); needs v.span_lines and h.wide_foot (columns counted from fp->tx0) */
 int cvk_fir_tvh_supported(const cvk_fir2d_params *fp);
+int cvk_fir_tvh_preferred(const cvk_fir2d_params *fp);    /* supported, and measured faster than cvk_fir_vh for this format and size */
 int cvk_fir_tvh(const cvk_fir2d_params *fp, int line0, void *stream);
 size_t cvk_fir2d_lds_bytes(const cvk_fir2d_params *fp);     /* dynamic LDS the launch would need */
 int cvk_fir2d(const cvk_fir2d_params *fp, void *stream);
@@ -289,6 +291,7 @@ int cvk_fir2d_fma(const cvk_fir2d_params *fp, void *stream);
 int cvk_fir_vh_supported_fma(const cvk_fir2d_params *fp);
 int cvk_fir_vh_fma(const cvk_fir2d_params *fp, int line0, int cus, void *stream);
 int cvk_fir_tvh_supported_fma(const cvk_fir2d_params *fp);
+int cvk_fir_tvh_preferred_fma(const cvk_fir2d_params *fp);
 int cvk_fir_tvh_fma(const cvk_fir2d_params *fp, int line0, void *stream);
 int cvk_blur_supported_fma(int ntaps, int step);
 int cvk_blur_takes_pairs_fma(const cvk_blur_params *bp);

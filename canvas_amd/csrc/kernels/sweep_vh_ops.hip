@@ -94,17 +94,37 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
     bool col_live[PXL];
     int aoff[PXL][MAXTH];
     float wt[PXL][MAXTH];
+    if ((MAXTH == 2 || MAXTH == 4) && fp.h.pack != nullptr && fp.h.pack_width == MAXTH) {
+        // short lists come packed (kernels.h cvk_fir_axis.pack): one aligned read per column, lanes reading consecutive
+        // records, instead of 1 + 2 MAXTH scattered ones -- the set-up's first trip to memory is mostly this
 #pragma unroll
-    for (int p = 0; p < PXL; p++) {
-        col_live[p] = tcol + p * cstep <= fp.tx1;
-        const int hline = tcol + p * cstep - fp.tx0;
-        const int hn = col_live[p] ? min(fp.h.ntaps[hline], MAXTH) : 0;
+        for (int p = 0; p < PXL; p++) {
+            col_live[p] = tcol + p * cstep <= fp.tx1;
+            const int hline = min(tcol + p * cstep, fp.tx1) - fp.tx0;
+            uint32_t rec[2 * MAXTH];
+            const uint4 *g = reinterpret_cast<const uint4 *>(fp.h.pack + (size_t)hline * 2 * MAXTH);
 #pragma unroll
-        for (int k = 0; k < MAXTH; k++) {
-            const bool live = k < hn;
-            const int a = live ? fp.h.src[(size_t)hline * hstride + k] - sx_lo : kZero;
-            aoff[p][k] = min(max(a, 0), kZero);
-            wt[p][k] = live ? fp.h.taps[(size_t)hline * hstride + k] : 0.0f;
+            for (int q = 0; q < MAXTH / 2; q++) { const uint4 x = g[q]; rec[4 * q] = x.x; rec[4 * q + 1] = x.y; rec[4 * q + 2] = x.z; rec[4 * q + 3] = x.w; }
+#pragma unroll
+            for (int k = 0; k < MAXTH; k++) {
+                const bool live = col_live[p] && (int)rec[k] != INT_MIN;
+                aoff[p][k] = live ? min(max((int)rec[k] - sx_lo, 0), kZero) : kZero;
+                wt[p][k] = live ? __uint_as_float(rec[MAXTH + k]) : 0.0f;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < PXL; p++) {
+            col_live[p] = tcol + p * cstep <= fp.tx1;
+            const int hline = tcol + p * cstep - fp.tx0;
+            const int hn = col_live[p] ? min(fp.h.ntaps[hline], MAXTH) : 0;
+#pragma unroll
+            for (int k = 0; k < MAXTH; k++) {
+                const bool live = k < hn;
+                const int a = live ? fp.h.src[(size_t)hline * hstride + k] - sx_lo : kZero;
+                aoff[p][k] = min(max(a, 0), kZero);
+                wt[p][k] = live ? fp.h.taps[(size_t)hline * hstride + k] : 0.0f;
+            }
         }
     }
     if (lane == 0) mid[kZero] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);

@@ -399,6 +399,15 @@ extern "C" int cvk_fir_tvh_supported(const cvk_fir2d_params *fp) {
     return lds_bytes(fp, CVK_FIR_TVH_LINES) <= kLdsCap;
 }
 
+// Where both forms take a call, which one is faster (profiles/r04/scaler_forms.txt, one and two streams): floats -- the
+// tiles, everywhere (6..16 %); halfs -- the tiles up to about one 4K frame of target (1080p -> 4K with two frames in flight:
+// 17.2 against 19.1 us), the strips for larger targets (4K -> 6K, 4K -> 8K: 4..8 % for the strips).
+extern "C" int cvk_fir_tvh_preferred(const cvk_fir2d_params *fp) {
+    if (!cvk_fir_tvh_supported(fp)) return 0;
+    if (!fp->out_half) return 1;
+    return (size_t)(fp->tx1 - fp->tx0 + 1) * (size_t)(fp->ty1 - fp->ty0 + 1) <= (size_t)10 << 20;
+}
+
 // fp->ty0 is the vertical table's first line; lines fp->ty0 + line0 .. fp->ty1 are produced
 extern "C" int cvk_fir_tvh(const cvk_fir2d_params *fp, int line0, void *stream) {
     if (fp->tx1 < fp->tx0 || fp->ty1 < fp->ty0 + line0 || line0 < 0) return 0;

@@ -416,7 +416,8 @@ enum { CVS_FIR_PATH_AUTO = 0, CVS_FIR_PATH_SWEEP = 1 /* lane per pixel */, CVS_F
        CVS_FIR_PATH_HV = 16 /* per-line gather, horizontal pass first (the automatic first choice) */,
        CVS_FIR_PATH_ONE_COLUMN = 32 /* the register-window kernels (blur, blur + halving) with one column per lane, never two */,
        CVS_FIR_PATH_TWO_COLUMNS = 64 /* ... with two columns per lane wherever that form takes the launch, narrow frames included */,
-       CVS_FIR_PATH_STRIPS = 128 /* the vertical-first triangle scaler on k_fir_vh's strips even where its tile form (k_fir_tile_vh) would take the call */ };
+       CVS_FIR_PATH_STRIPS = 128 /* the vertical-first triangle scaler on k_fir_vh's strips even where its tile form (k_fir_tile_vh) would take the call */,
+       CVS_FIR_PATH_TILES = 256 /* ... on the tile form wherever it takes the call (left alone, the library uses it where it measured faster: floats, and halfs up to about a 4K target) */ };
 CVS_EXPORT void cvs_fir_path_override(int mode);
 /* Which kernel the calling thread's last FIR launch (scaler, blur, Lanczos resample, blur + resample) went to -- what a
  * test pinned to one kernel asserts, and what tells a silent fallback from the intended kernel.  A fused kernel that was

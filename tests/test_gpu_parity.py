@@ -843,6 +843,8 @@ def force_fir(request):
             mode |= _lib.FIR_PATH_HV
         if which == "strips":                               # the fused vertical-first scaler on k_fir_vh, never its tile form
             mode = _lib.FIR_PATH_STRIPS
+        elif which == "tiles":                              # ... on the tile form wherever it takes the call, whatever the size
+            mode = _lib.FIR_PATH_TILES
         lib.cvs_fir_path_override(mode)
     yield pin
     pin(None)
@@ -2106,7 +2108,7 @@ def test_scale_wide_targets_two_columns_per_lane(cvs, orc, force_fir, tw, fmt, f
     floats), and an odd row pitch (1025, 1027) puts half of the rows' pairs off a 16-byte boundary: those f16 targets go to
     the strips with one column per lane.  Ragged last strip and ragged last tile row (37 lines) either way."""
     th = 37
-    force_fir("strips" if form == "strips" else None)
+    force_fir(form)
     sw, sh = int(tw / fac[0]) + 2, int(th / fac[1]) + 2
     sfull, tfull = (0, 0, sw - 1, sh - 1), (0, 0, tw - 1, th - 1)
     rng = np.random.default_rng(4100 + tw)
@@ -2128,6 +2130,34 @@ def test_scale_wide_targets_two_columns_per_lane(cvs, orc, force_fir, tw, fmt, f
         assert_same_f32(got.window_view(), want32.window_view(), "wide f32 scale %r" % (fac,))
     tiled = form == "tiles" and not (fmt == "f16" and tw % 2)
     assert cvs.cvs_scale_last_was_fused() == 1 and cvs.cvs_fir_last_kernel() == (_lib.FIR_KERNEL_TILE_VH if tiled else _lib.FIR_KERNEL_VH)
+
+
+@pytest.mark.parametrize("fmt", ["f16", "f32"])
+def test_scaler_form_by_format_and_size(cvs, force_fir, fmt):
+    """Which form the library picks where both take the call (tile_vh_ops.hip cvk_fir_tvh_preferred, measured: profiles/r04/
+    scaler_forms.txt): floats -- the tiles; halfs -- the tiles up to about a 4K target, the strips beyond.  A 4224 x 2600
+    target (11 Mpx) from 2112 x 1300: halfs go to the strips, floats to the tiles, and pinned to the other form the pixels
+    are the same."""
+    w, h = 2112, 1300
+    src16 = synth.layer_frame(w, h, 2, 0)
+    outs = {}
+    for pin in (None, "tiles", "strips"):
+        force_fir(pin)
+        if fmt == "f16":
+            d_src, d_out = DeviceFrame.from_host(src16), DeviceFrame((0, 0, 2 * w - 1, 2 * h - 1), np.uint16)
+            _lib.check(cvs.cvs_scale_bilinear_f16_dev(d_out.ref(), v2f(0, 0), d_src.ref(), v2f(0, 0), v2f(2.0, 2.0), None))
+        else:
+            from tests.models import h2f_ieee
+            d_src = DeviceFrame.from_host(HostFrame(src16.full_window, np.float32, h2f_ieee(src16.array).astype(np.float32)))
+            d_out = DeviceFrame((0, 0, 2 * w - 1, 2 * h - 1), np.float32)
+            _lib.check(cvs.cvs_scale_bilinear_f32_dev(d_out.ref(), v2f(0, 0), d_src.ref(), v2f(0, 0), v2f(2.0, 2.0), None))
+        outs[pin] = (_KERNEL_NAMES[cvs.cvs_fir_last_kernel()], d_out.download().array.copy())
+        d_src.free(); d_out.free()
+    assert outs["tiles"][0] == "tile-vh" and outs["strips"][0] == "vh"
+    assert outs[None][0] == ("vh" if fmt == "f16" else "tile-vh")
+    same = assert_same_f16 if fmt == "f16" else assert_same_f32
+    same(outs["tiles"][1], outs["strips"][1], "tiles against strips, %s" % fmt)
+    same(outs[None][1], outs["strips"][1], "automatic choice against strips, %s" % fmt)
 
 
 def test_tile_scaler_random_geometry(cvs, orc):

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--streams", type=int, default=1, help="frames alternate over this many HIP streams (the bench's scaler record uses 2)")
     ap.add_argument("--diag-mode", type=int, default=0, help="diagnostic build only: k_fir_tile_vh's timing-only variants (1: stores only)")
+    ap.add_argument("--tiles", action="store_true", help="pin it to the tile form wherever that takes the call (CVS_FIR_PATH_TILES)")
     ap.add_argument("--strips", action="store_true", help="pin the vertical-first scaler to k_fir_vh's strips (CVS_FIR_PATH_STRIPS)")
     args = ap.parse_args()
     if args.diag_mode:
@@ -35,6 +36,8 @@ def main():
     lib.init_half()
     if args.strips:
         lib.cvs_fir_path_override(_lib.FIR_PATH_STRIPS)
+    if args.tiles:
+        lib.cvs_fir_path_override(_lib.FIR_PATH_TILES)
     if args.diag_mode:
         lib.cvk_fir_tvh_diag_mode.restype, lib.cvk_fir_tvh_diag_mode.argtypes = C.c_int, [C.c_int]
         assert lib.cvk_fir_tvh_diag_mode(args.diag_mode) == 0
