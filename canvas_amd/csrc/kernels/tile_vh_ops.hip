@@ -180,25 +180,32 @@ __global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const uint32_t *hpack,
     if (sw > 0 && sh > 0 && !skip_rows) {
         constexpr int PXB = INH ? 8 : 16;
         const int units = min(sh * sw, kNJ * kThreads);
-        const float inv_sw = 1.0f / (float)sw;
         const char *base = sdata + ((size_t)(s_lo - sfy0) * (size_t)spitch + (size_t)(sx_lo - sfx0)) * PXB;
         const uint32_t rowpx = (uint32_t)spitch;
+        // (row, column) of pixel u = tid, then + 256 at a time: the quotient and remainder of 256 by sw are uniform, a step is
+        // two additions and a carry (a division per pixel was a quarter of the set-up's vector instructions)
+        const float inv_sw = 1.0f / (float)sw;
+        int dq = (int)(((float)kThreads + 0.5f) * inv_sw), dm = kThreads - dq * sw;      // (uniform) 256 = dq * sw + dm
+        if (dm < 0) { dq--; dm += sw; } else if (dm >= sw) { dq++; dm -= sw; }
+        int r = (int)(((float)tid + 0.5f) * inv_sw), c = tid - r * sw;                   // tid / sw, up to one either way
+        if (c < 0) { r--; c += sw; } else if (c >= sw) { r++; c -= sw; }
         Raw<INH> v[kNJ];
         int sidx[kNJ];
 #pragma unroll
+        for (int j = 0; j < kNJ; j++) sidx[j] = -1;
+#pragma unroll
         for (int j = 0; j < kNJ; j++) {
             if (j * kThreads >= units) break;                            // (uniform) no lane has a j-th pixel
-            const int u = min(tid + j * kThreads, units - 1);            // clamped: the load itself is unconditional
-            int r = (int)(((float)u + 0.5f) * inv_sw);                   // u / sw, up to one either way (u < 2^22)
-            int c = u - r * sw;
-            const int fix = (c >= sw ? 1 : 0) - (c < 0 ? 1 : 0);
-            r += fix; c -= fix * sw;
-            sidx[j] = r * swp + c;
-            v[j].v = *reinterpret_cast<const decltype(v[j].v) *>(base + ((uint32_t)r * rowpx + (uint32_t)c) * (uint32_t)PXB);
+            const bool mine = tid + j * kThreads < units;
+            const int rr = mine ? r : sh - 1, cc = mine ? c : sw - 1;    // clamped: the load itself is unconditional
+            sidx[j] = mine ? rr * swp + cc : -1;
+            v[j].v = *reinterpret_cast<const decltype(v[j].v) *>(base + ((uint32_t)rr * rowpx + (uint32_t)cc) * (uint32_t)PXB);
+            c += dm; r += dq;
+            if (c >= sw) { c -= sw; r++; }
         }
 #pragma unroll
         for (int j = 0; j < kNJ; j++)
-            if (tid + j * kThreads < units) { const Px w = widen(v[j]); S[sidx[j]] = make_float4(w.lo.x, w.lo.y, w.hi.x, w.hi.y); }
+            if (sidx[j] >= 0) { const Px w = widen(v[j]); S[sidx[j]] = make_float4(w.lo.x, w.lo.y, w.hi.x, w.hi.y); }
     }
     // columns of the S row and weights; padded taps (and columns past the target's last) -> the row's zero pixel, weight 0
     int acol[2][MAXTH];
