@@ -40,6 +40,7 @@ class coded_image(C.Structure):
 
 P = C.POINTER
 rgba_frame_f16_t = rgba_frame_f16
+rgba_frame_f32_t = rgba_frame_f32
 _u16p, _f32p, _vp = P(C.c_uint16), P(C.c_float), C.c_void_p
 _F16, _F32 = P(rgba_frame_f16), P(rgba_frame_f32)
 
@@ -171,6 +172,8 @@ SIGNATURES = {
     "cvs_resample_lanczos_f16_dev": (C.c_int, [_F16, _F16, C.c_float, C.c_float, C.c_int, _vp]),
     "cvs_blur_lanczos_f16_dev": (C.c_int, [_F16, _F16, _f32p, C.c_int, C.c_float, C.c_float, C.c_int, _vp]),
     "cvs_blur_over_f16_batch_dev": (C.c_int, [P(_F16), P(_F16), _f32p, C.c_int, P(_F16), C.c_int, C.c_int, _vp]),
+    "cvs_scale_bilinear_f16_batch_dev": (C.c_int, [P(_F16), v2f, P(_F16), v2f, v2f, C.c_int, _vp]),
+    "cvs_scale_bilinear_f32_batch_dev": (C.c_int, [P(_F32), v2f, P(_F32), v2f, v2f, C.c_int, _vp]),
     "cvs_blur_lanczos_f16_batch_dev": (C.c_int, [P(_F16), P(_F16), C.c_int, _f32p, C.c_int, C.c_float, C.c_float, C.c_int, _vp]),
     "cvs_fir_path_override": (None, [C.c_int]),
     # (3) fused chain

@@ -198,6 +198,11 @@ static int triangle_pass(any_frame *target, float tmin, const any_frame *source,
  * one smaller: video_scale.c:252) -- sweep_vh_ops.hip.  Same tables, same windows as the two triangle_pass calls below
  * would use: the frame between the passes (`mid_full`, video_scale.c:254-272) never exists, only its geometry does.
  * 0 = done, 1 = not for this kernel (the caller runs the two passes), < 0 = error. */
+/* A batch call (cvs_scale_bilinear_*_batch_dev) in progress on this thread: the frames that go into the launch with the one
+ * scale_core is called for.  Only the tile kernel takes a batch; anything else answers 2 = "frame by frame". */
+typedef struct { int n; const void *source[8]; void *target[8]; size_t target_bytes; } scale_batch;
+static _Thread_local const scale_batch *t_scale_batch;
+
 static int triangle_fused_vh(any_frame *target, v2f tp, const any_frame *source, v2f sp, v2f fac, const box2i *mid_full, hipStream_t s) {
     const box2i *tf = &target->full, *sc = &source->cur;
     /* pass 1 (vertical) into the frame between the passes */
@@ -223,12 +228,23 @@ static int triangle_fused_vh(any_frame *target, v2f tp, const any_frame *source,
             /* short lists over few source pixels (enlarging): a workgroup per tile where that is the faster form (pinned:
              * wherever it takes the call); else a wave per strip */
             const int pinned = atomic_load(&g_fir_path);
+            const scale_batch *const batch = t_scale_batch;
+            /* (a batch is one large target to the kernels: halfs go to the strips, as 4K -> 8K does -- profiles/r04/scaler_batch.txt) */
             const bool tiles = hhi >= hlo && !(pinned & CVS_FIR_PATH_STRIPS) &&
-                               ((pinned & CVS_FIR_PATH_TILES) ? CVK(cvk_fir_tvh_supported)(&fp) : CVK(cvk_fir_tvh_preferred)(&fp));
-            if (hhi >= hlo && (tiles || CVK(cvk_fir_vh_supported)(&fp))) {
+                               ((pinned & CVS_FIR_PATH_TILES) ? CVK(cvk_fir_tvh_supported)(&fp)
+                                : batch && target->half ? false : CVK(cvk_fir_tvh_preferred)(&fp));
+            if (batch && !(hhi >= hlo && (tiles || CVK(cvk_fir_vh_supported)(&fp)))) rc = 2;
+            else if (hhi >= hlo && (tiles || CVK(cvk_fir_vh_supported)(&fp))) {
                 /* video_scale.c:25-32,44: rows the pass leaves alone are zeros */
                 const bool covers = lo2 == tf->min.y && hi2 == tf->max.y;
-                hipError_t e = covers || !any_bytes(target) ? hipSuccess : hipMemsetAsync(target->data, 0, any_bytes(target), s);
+                hipError_t e = hipSuccess;
+                if (batch) {
+                    fp.nframes = batch->n;
+                    for (int i = 0; i < batch->n; i++) {
+                        fp.frame_source[i] = batch->source[i]; fp.frame_target[i] = batch->target[i];
+                        if (!covers && batch->target_bytes && e == hipSuccess) e = hipMemsetAsync(batch->target[i], 0, batch->target_bytes, s);
+                    }
+                } else if (!covers && any_bytes(target)) e = hipMemsetAsync(target->data, 0, any_bytes(target), s);
                 int krc = e != hipSuccess ? (int)e : tiles ? CVK(cvk_fir_tvh)(&fp, lo2 - fp.ty0, s) : CVK(cvk_fir_vh)(&fp, lo2 - fp.ty0, cvs_cus(), s);
                 if (krc == 0) { box2i_set(&target->cur, hlo, lo2, hhi, hi2); t_fir_kernel = tiles ? CVS_FIR_KERNEL_TILE_VH : CVS_FIR_KERNEL_VH; rc = 0; }
                 else { fir_launch_fell_through(tiles ? "k_fir_tile_vh" : "k_fir_vh", krc); rc = 1; }   /* did not launch: the two passes decide */
@@ -283,6 +299,9 @@ static int triangle_fused_hv(any_frame *target, v2f tp, const any_frame *source,
 static int scale_core(any_frame *target, v2f tp, const any_frame *source, v2f sp, v2f fac, hipStream_t s) {
     t_scale_fused = 0;
     t_fir_kernel = CVS_FIR_KERNEL_NONE;
+    /* a batch goes through the vertical-first fused launch or not at all (2: the caller does its frames one by one) */
+    if (t_scale_batch && ((fac.x == 1.0f && tp.x == sp.x) || (fac.y == 1.0f && tp.y == sp.y) || fac.x < fac.y ||
+                          (atomic_load(&g_fir_path) & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED)))) return 2;
     if (fac.x == 1.0f && tp.x == sp.x) return triangle_pass(target, tp.y, source, sp.y, fac.y, 0, s);
     if (fac.y == 1.0f && tp.y == sp.y) return triangle_pass(target, tp.x, source, sp.x, fac.x, 1, s);
 
@@ -303,6 +322,7 @@ static int scale_core(any_frame *target, v2f tp, const any_frame *source, v2f sp
         int rc = x_first ? triangle_fused_hv(target, tp, source, sp, fac, &mid.full, s) : triangle_fused_vh(target, tp, source, sp, fac, &mid.full, s);
         if (rc == 0) t_scale_fused = 1;
         if (rc <= 0) return rc;                              /* done, or failed; 1: not for the fused kernel */
+        if (t_scale_batch) return 2;
     }
     size_t n = cvs_box_pixels(&mid.full);
     mid.data = cvs_pool_malloc(sizeof(rgba_f32) * (n ? n : 1), s);
@@ -339,6 +359,112 @@ CVS_EXPORT int cvs_scale_bilinear_f16_dev(rgba_frame_f16 *target, v2f tp, const 
     int rc = scale_core(&t, tp, &src, sp, fac, s);
     target->current_window = t.cur;
     if (rc != 0) box2i_set_empty(&target->current_window);
+    return rc;
+}
+
+/* cvs_scale_bilinear_f16_dev / _f32_dev for `count` INDEPENDENT frames (a pull queue's frames in flight): frames of one geometry
+ * that do not overlap go up to eight at a time into ONE launch of the tile kernel (grid.z = frame), where that kernel takes
+ * the call (vertical pass first, short tap lists: enlarging); every other combination is carried out frame by frame, exactly
+ * as `count` single calls.  Results are those of the single calls, bit for bit. */
+static bool same_box(const box2i *a, const box2i *b);
+static bool batch_has_hazard(void *const *outs, size_t out_bytes, const void *const *ins, size_t in_bytes, int nouts, int nins);
+
+static int scale_batch_any(void *const *tdata, const box2i *const *tfull, box2i *const *tcur, const void *const *sdata, const box2i *const *sfull,
+                           const box2i *const *scur, int count, int half, v2f tp, v2f sp, v2f fac, hipStream_t s, int *done_out) {
+    int done = 0;
+    bool uniform = count > 1 && !box2i_is_empty(scur[0]) && !box2i_is_empty(tfull[0]) &&
+                   !(fac.x == 1.0f && tp.x == sp.x && fac.y == 1.0f && tp.y == sp.y);
+    for (int i = 1; uniform && i < count; i++)
+        uniform = same_box(tfull[i], tfull[0]) && same_box(sfull[i], sfull[0]) && same_box(scur[i], scur[0]);
+    const size_t px = half ? sizeof(rgba_f16) : sizeof(rgba_f32);
+    const size_t tbytes = cvs_box_pixels(tfull[0]) * px, sbytes = cvs_box_pixels(sfull[0]) * px;
+    while (uniform && done < count) {
+        const int n = count - done < 8 ? count - done : 8;
+        scale_batch b;
+        memset(&b, 0, sizeof b);
+        for (int i = 0; i < n; i++) { b.source[i] = sdata[done + i]; b.target[i] = tdata[done + i]; }
+        if (n < 2 || batch_has_hazard(b.target, tbytes, b.source, sbytes, n, n)) break;      /* the rest frame by frame */
+        b.n = n; b.target_bytes = tbytes;
+        any_frame t = { tdata[done], *tfull[done], *tfull[done], half };
+        const any_frame src = { (void *)sdata[done], *sfull[done], *scur[done], half };
+        t_scale_batch = &b;
+        const int rc = scale_core(&t, tp, &src, sp, fac, s);
+        t_scale_batch = NULL;
+        if (rc == 2) break;
+        if (rc != 0) { *done_out = done; return -1; }
+        for (int i = 0; i < n; i++) *tcur[done + i] = t.cur;
+        done += n;
+    }
+    *done_out = done;
+    return 0;
+}
+
+CVS_EXPORT int cvs_scale_bilinear_f16_batch_dev(rgba_frame_f16 *const *targets, v2f tp, const rgba_frame_f16 *const *sources, v2f sp, v2f fac, int count, cvs_stream_t stream) {
+    if (count <= 0) return 0;
+    if (!targets || !sources) { cvs_set_error("cvs_scale_bilinear_f16_batch_dev: bad arguments"); return -1; }
+    for (int i = 0; i < count; i++)
+        if (!targets[i] || !sources[i]) { cvs_set_error("cvs_scale_bilinear_f16_batch_dev: frame %d of %d is a null pointer", i, count); return -1; }
+    /* what count single calls would refuse, the batch refuses -- before any launch */
+    for (int i = 0; i < count; i++)
+        if (!cvs_box_contains(&sources[i]->full_window, &sources[i]->current_window)) {
+            cvs_set_error("cvs_scale_bilinear_f16_batch_dev: the input's current_window lies outside its buffer (frame %d)", i);
+            for (int k = 0; k < count; k++) box2i_set_empty(&targets[k]->current_window);
+            return -1;
+        }
+    if (cvs_enter() != 0) { for (int i = 0; i < count; i++) box2i_set_empty(&targets[i]->current_window); return -1; }
+    hipStream_t s = cvs_pick_stream(stream);
+    int rc = 0, done = 0;
+    if (count > 1) {
+        void *td[64]; const void *sd[64]; const box2i *tf[64], *sf[64], *sc[64]; box2i *tc[64];
+        for (int base = 0; rc == 0 && base < count; ) {
+            const int n = count - base < 64 ? count - base : 64;
+            for (int i = 0; i < n; i++) {
+                td[i] = targets[base + i]->data; sd[i] = sources[base + i]->data; tf[i] = &targets[base + i]->full_window;
+                sf[i] = &sources[base + i]->full_window; sc[i] = &sources[base + i]->current_window; tc[i] = &targets[base + i]->current_window;
+            }
+            int d = 0;
+            rc = scale_batch_any(td, tf, tc, sd, sf, sc, n, 1, tp, sp, fac, s, &d);
+            done = base + d;
+            if (d < n) break;                                /* from here on frame by frame */
+            base += n;
+        }
+    }
+    for (; rc == 0 && done < count; done++) rc = cvs_scale_bilinear_f16_dev(targets[done], tp, sources[done], sp, fac, stream);
+    if (rc != 0) for (int i = done; i < count; i++) box2i_set_empty(&targets[i]->current_window);
+    return rc;
+}
+
+CVS_EXPORT int cvs_scale_bilinear_f32_batch_dev(rgba_frame_f32 *const *targets, v2f tp, const rgba_frame_f32 *const *sources, v2f sp, v2f fac, int count, cvs_stream_t stream) {
+    if (count <= 0) return 0;
+    if (!targets || !sources) { cvs_set_error("cvs_scale_bilinear_f32_batch_dev: bad arguments"); return -1; }
+    for (int i = 0; i < count; i++)
+        if (!targets[i] || !sources[i]) { cvs_set_error("cvs_scale_bilinear_f32_batch_dev: frame %d of %d is a null pointer", i, count); return -1; }
+    for (int i = 0; i < count; i++)
+        if (!cvs_box_contains(&sources[i]->full_window, &sources[i]->current_window)) {
+            cvs_set_error("cvs_scale_bilinear_f32_batch_dev: the input's current_window lies outside its buffer (frame %d)", i);
+            for (int k = 0; k < count; k++) box2i_set_empty(&targets[k]->current_window);
+            return -1;
+        }
+    if (cvs_enter() != 0) { for (int i = 0; i < count; i++) box2i_set_empty(&targets[i]->current_window); return -1; }
+    hipStream_t s = cvs_pick_stream(stream);
+    int rc = 0, done = 0;
+    if (count > 1) {
+        void *td[64]; const void *sd[64]; const box2i *tf[64], *sf[64], *sc[64]; box2i *tc[64];
+        for (int base = 0; rc == 0 && base < count; ) {
+            const int n = count - base < 64 ? count - base : 64;
+            for (int i = 0; i < n; i++) {
+                td[i] = targets[base + i]->data; sd[i] = sources[base + i]->data; tf[i] = &targets[base + i]->full_window;
+                sf[i] = &sources[base + i]->full_window; sc[i] = &sources[base + i]->current_window; tc[i] = &targets[base + i]->current_window;
+            }
+            int d = 0;
+            rc = scale_batch_any(td, tf, tc, sd, sf, sc, n, 0, tp, sp, fac, s, &d);
+            done = base + d;
+            if (d < n) break;
+            base += n;
+        }
+    }
+    for (; rc == 0 && done < count; done++) rc = cvs_scale_bilinear_f32_dev(targets[done], tp, sources[done], sp, fac, stream);
+    if (rc != 0) for (int i = done; i < count; i++) box2i_set_empty(&targets[i]->current_window);
     return rc;
 }
 

@@ -182,6 +182,11 @@ typedef struct {
     int tx0, ty0, tx1, ty1;    /* target rectangle */
     cvk_fir_axis h, v;         /* h: per target column, v: per target row */
     int max_sw, max_sh;        /* largest tile footprint in source pixels (sizes the LDS tile) */
+    /* cvk_fir_tvh and cvk_fir_vh only: nframes > 1 = that many frames of this geometry in one launch (grid.z = frame); their
+     * data pointers replace target.data / source.data */
+    int nframes, pad_;
+    const void *frame_source[8];
+    void *frame_target[8];
 } cvk_fir2d_params;
 #define CVK_FIR2D_TILE_X 32
 #define CVK_FIR2D_TILE_Y 16

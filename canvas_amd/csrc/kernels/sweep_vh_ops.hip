@@ -69,6 +69,12 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
     // lane + 64 (two 16-byte stores, each contiguous across the wave)
     constexpr bool out_half = INH;                                       // (both frames of a scaler call have the caller's format)
     constexpr int cstep = PXL == 2 && !out_half ? kLanes : 1;            // from the lane's first column to its second
+    // a batch of frames of this geometry: grid.z picks the frame (its pointers read through the kernel-argument segment: a
+    // scalar load at a computed offset; the struct is the kernel's first argument)
+    typedef const cvk_fir2d_params __attribute__((address_space(4))) *kargs_t;
+    const kargs_t ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
+    const void *const src_data = fp.nframes > 1 ? ka->frame_source[blockIdx.z] : fp.source.data;
+    void *const dst_data = fp.nframes > 1 ? ka->frame_target[blockIdx.z] : fp.target.data;
     const int tcol = fp.tx0 + (int)blockIdx.x * kStrip + (PXL == 2 && out_half ? 2 * lane : lane);
     const int nlines = fp.ty1 - fp.ty0 + 1;
     // target lines, counted from the vertical table's first (fp.ty0); the launch covers lines line0 .. nlines - 1
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
     const bool all_live = fp.tx0 + ((int)blockIdx.x + 1) * kStrip - 1 <= fp.tx1;      // (uniform) every lane's columns exist
 
     constexpr uint32_t tpx = out_half ? 8 : 16;
-    char *optr = reinterpret_cast<char *>(fp.target.data) + ((size_t)(tcol - fp.target.fx0)) * tpx
+    char *optr = reinterpret_cast<char *>(dst_data) + ((size_t)(tcol - fp.target.fx0)) * tpx
                + (size_t)(fp.ty0 + ia - fp.target.fy0) * (size_t)fp.target.pitch * tpx;
     const size_t trow = (size_t)fp.target.pitch * tpx;
 
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
 #pragma unroll
     for (int q = 0; q < NQ; q++) uoff[q] = (uint32_t)(min(lane + q * kLanes, npx - 1) * PXB);
     const uint32_t rowb = (uint32_t)fp.source.pitch * PXB;
-    const char *rp = reinterpret_cast<const char *>(fp.source.data) + (size_t)(sx_lo - fp.source.fx0) * PXB
+    const char *rp = reinterpret_cast<const char *>(src_data) + (size_t)(sx_lo - fp.source.fx0) * PXB
                    + (size_t)((any_taps ? s_lo : fp.source.fy0) - fp.source.fy0) * (size_t)rowb;
     int s_left = any_taps ? s_hi - s_lo : 0;                             // rows after the one `rp` points at
 
@@ -311,14 +317,15 @@ int launch(const cvk_fir2d_params &fp, int line0, int cus, hipStream_t s) {
         cached.store(n, std::memory_order_relaxed);
     }
     // one round of resident workgroups over the frame; a segment re-reads the W - 1 source rows its first line reaches back to
-    int segs = (per_cu * (cus > 0 ? cus : 256)) / strips;
+    const int frames = fp.nframes > 1 ? fp.nframes : 1;
+    int segs = (per_cu * (cus > 0 ? cus : 256)) / (strips * frames);
     if (segs < 1) segs = 1;
     int r = (rows + segs - 1) / segs;
     // measured (1080p -> 4K and 4K -> 1080p, profiles/r03): the wide strips want 16 lines, the narrow ones as many waves as the chip holds
     if (r < (PXL == 2 ? 16 : 8)) r = PXL == 2 ? 16 : 8;
     if (r > 256) r = 256;
     if (r > rows) r = rows;
-    dim3 grid((unsigned)strips, (unsigned)((rows + r - 1) / r));
+    dim3 grid((unsigned)strips, (unsigned)((rows + r - 1) / r), (unsigned)frames);
     hipLaunchKernelGGL((k_fir_vh<W, MAXTH, NQ, INH, PXL>), grid, dim3(kLanes), 0, s, fp, r, line0);
     return (int)hipGetLastError();
 }

@@ -50,6 +50,7 @@ namespace {
 using cvs::f32x2;
 
 constexpr int kTW = 128, kThreads = 256, kWaves = kThreads / 64;
+constexpr int kFpOffset = 56;    // where cvk_fir2d_params starts in k_fir_tile_vh's kernel-argument segment: three pointers, eight ints (checked in the kernel)
 constexpr int kNJ = 9;           // source pixels a lane stages at most (all requested at once)
 static_assert(kTW == 4 * CVK_FIR2D_TILE_X, "a tile spans four entries of the footprint table");
 
@@ -144,12 +145,26 @@ __global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const uint32_t *hpack,
     __builtin_amdgcn_sched_barrier(0);                                   // (the table reads are requested before the arguments are fetched)
     // ... and every other argument the kernel uses.  The empty asm makes all of it one request-and-wait: left alone, hipcc
     // sinks each of these loads to its first use, and every one then costs its own trip.
-    const char *const sdata = reinterpret_cast<const char *>(fp.source.data);
-    char *const tdata = reinterpret_cast<char *>(fp.target.data);
+    // (a batch of frames: grid.z picks the frame; its pointers are read through the kernel-argument segment -- a scalar load
+    // at a computed offset -- whether there is a batch or not, so that the read is part of this trip)
+    typedef const cvk_fir2d_params __attribute__((address_space(4))) *kargs_t;
+    const kargs_t ka = (kargs_t)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + kFpOffset);
+    const int z = (int)blockIdx.z;
+    const void *const zsrc = ka->frame_source[z];
+    void *const ztgt = ka->frame_target[z];
+    const int nframes = fp.nframes;
+    // the segment's layout is the compiler's: were the struct not where kFpOffset says, no pointer from it may be used
+    const int chk_n = ka->nframes, chk_x = ka->tx1, chk_y = ka->ty1, chk_p = ka->source.pitch;
+    const void *const one_src = fp.source.data;
+    void *const one_tgt = fp.target.data;
     const int spitch = fp.source.pitch, sfx0 = fp.source.fx0, sfy0 = fp.source.fy0, tpitch = fp.target.pitch, tfx0 = fp.target.fx0, tfy0 = fp.target.fy0;
     const int sfx1 = fp.source.fx1, tfx1 = fp.target.fx1;               // (fetched with their neighbours: named here so that their registers are not handed out while the fetch is in flight, which costs a wait)
     asm volatile("" :: "s"(n_a), "s"(f_a), "s"(n_b), "s"(f_b), "s"(flo[0]), "s"(fhi[0]), "s"(flo[1]), "s"(fhi[1]), "s"(flo[2]), "s"(fhi[2]), "s"(flo[3]), "s"(fhi[3]),
-                 "s"(sdata), "s"(tdata), "s"(spitch), "s"(sfx0), "s"(sfy0), "s"(tpitch), "s"(tfx0), "s"(tfy0), "s"(sfx1), "s"(tfx1));
+                 "s"(one_src), "s"(one_tgt), "s"(spitch), "s"(sfx0), "s"(sfy0), "s"(tpitch), "s"(tfx0), "s"(tfy0), "s"(sfx1), "s"(tfx1),
+                 "s"(zsrc), "s"(ztgt), "s"(nframes), "s"(chk_n), "s"(chk_x), "s"(chk_y), "s"(chk_p));
+    if (nframes > 1 && !(chk_n == nframes && chk_x == tx1 && chk_y == ty1 && chk_p == spitch)) return;
+    const char *const sdata = reinterpret_cast<const char *>(nframes > 1 ? zsrc : one_src);
+    char *const tdata = reinterpret_cast<char *>(nframes > 1 ? ztgt : one_tgt);
 
     int sx_lo = INT_MAX, sx_hi = INT_MIN;
 #pragma unroll
@@ -363,7 +378,7 @@ size_t lds_bytes(const cvk_fir2d_params *fp, int seg) { return (size_t)seg_rows(
 // three trips to memory, the same for 16 lines as for 64) and all of a lane's row requests in flight at once
 int pick_seg(const cvk_fir2d_params *fp) {
     static int forced = -1;
-    if (forced < 0) { const char *e = getenv("CVS_TVH_SEG"); forced = e ? atoi(e) : 0; }
+    if (forced < 0) { const char *e = CVS_DIAG_ENV("CVS_TVH_SEG"); forced = e ? atoi(e) : 0; }     // (diagnostic build only)
     if ((forced == 16 || forced == 32 || forced == 64) && lds_bytes(fp, forced) <= kLdsCap && (size_t)seg_rows(fp, forced) * (size_t)fp->h.wide_foot <= (size_t)kNJ * kThreads) return forced;
     for (int seg = 64; seg > CVK_FIR_TVH_LINES; seg /= 2)
         if (lds_bytes(fp, seg) <= 40 * 1024 && (size_t)seg_rows(fp, seg) * (size_t)fp->h.wide_foot <= (size_t)kNJ * kThreads) return seg;
@@ -374,7 +389,7 @@ template <int MAXTV, int MAXTH, bool INH>
 int launch(const cvk_fir2d_params &fp, int line0, hipStream_t s) {
     const int cols = fp.tx1 - fp.tx0 + 1, rows = fp.ty1 - fp.ty0 + 1 - line0;
     const int seg = pick_seg(&fp);
-    dim3 grid((unsigned)((cols + kTW - 1) / kTW), (unsigned)((rows + seg - 1) / seg));
+    dim3 grid((unsigned)((cols + kTW - 1) / kTW), (unsigned)((rows + seg - 1) / seg), (unsigned)(fp.nframes > 1 ? fp.nframes : 1));
     hipLaunchKernelGGL((k_fir_tile_vh<MAXTV, MAXTH, INH>), grid, dim3(kThreads), lds_bytes(&fp, seg), s,
                        fp.h.pack, fp.h.foot, fp.v.lrec, line0, seg, fp.tx0, fp.tx1, fp.ty0, fp.ty1, row_pixels(&fp), seg_rows(&fp, seg), fp);
     return (int)hipGetLastError();

@@ -337,6 +337,15 @@ CVS_EXPORT int cvs_fill_solid_f16_dev(rgba_frame_f16 *frame, const box2i *window
 CVS_EXPORT int cvs_fill_solid_f32_dev(rgba_frame_f32 *frame, const box2i *window, const rgba_f32 *color, cvs_stream_t s);
 /* the f16 twin: widen on load, truncate on store (the f16 pull of a scaler node over a half-native source) */
 CVS_EXPORT int cvs_scale_bilinear_f16_dev(rgba_frame_f16 *target, v2f tp, const rgba_frame_f16 *source, v2f sp, v2f fac, cvs_stream_t stream);
+/* The two device entries of the scaler for `count` INDEPENDENT frames (a pull queue's frames in flight): frames of one geometry
+ * whose buffers do not overlap go up to eight at a time into one launch where the tile kernel takes the call (vertical pass
+ * first -- video_scale.c:252 -- and short tap lists: enlarging; 1080p -> 4K: 0.0173 -> see DESIGN.md 4.4 per frame); every
+ * other combination is carried out frame by frame, exactly as `count` single calls.  Results are those of the single calls,
+ * bit for bit; a NULL entry or a source window outside its buffer refuses the whole call before any launch. */
+CVS_EXPORT int cvs_scale_bilinear_f32_batch_dev(rgba_frame_f32 *const *targets, v2f target_point, const rgba_frame_f32 *const *sources, v2f source_point,
+                                                v2f factors, int count, cvs_stream_t stream);
+CVS_EXPORT int cvs_scale_bilinear_f16_batch_dev(rgba_frame_f16 *const *targets, v2f target_point, const rgba_frame_f16 *const *sources, v2f source_point,
+                                                v2f factors, int count, cvs_stream_t stream);
 CVS_EXPORT int cvs_scale_bilinear_f32_dev(rgba_frame_f32 *target, v2f target_point, const rgba_frame_f32 *source, v2f source_point, v2f factors, cvs_stream_t s);
 /* separable FIR blur at factor 1 (absent from the reference; defined in DESIGN.md) and the Lanczos
  * gather resampler built on filter_createLanczos */

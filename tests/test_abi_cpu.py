@@ -366,6 +366,23 @@ def test_batch_entries_refuse_what_the_single_calls_refuse(lib):
     holes = (fp16 * 3)(C.pointer(good[0].c), None, C.pointer(good[1].c))
     assert lib.cvs_blur_lanczos_f16_batch_dev(dsts, holes, 3, tp, 3, C.c_float(0.5), C.c_float(0.5), 3, None) == -1
     assert "null pointer" in _lib.last_error()
+    # the scaler's batch entries: same two rules
+    from canvas_amd.abi import v2f
+    big = [HostFrame((0, 0, 127, 71), np.uint16) for _ in range(3)]
+    bdst = (fp16 * 3)(*[C.pointer(o.c) for o in big])
+    assert lib.cvs_scale_bilinear_f16_batch_dev(bdst, v2f(0, 0), srcs, v2f(0, 0), v2f(2.0, 2.0), 3, None) == -1
+    assert "outside its buffer (frame 1)" in _lib.last_error()
+    assert all(o.current_window.is_empty() for o in big)
+    assert lib.cvs_scale_bilinear_f16_batch_dev(bdst, v2f(0, 0), holes, v2f(0, 0), v2f(2.0, 2.0), 3, None) == -1
+    assert "null pointer" in _lib.last_error()
+    assert lib.cvs_scale_bilinear_f16_batch_dev(bdst, v2f(0, 0), holes, v2f(0, 0), v2f(2.0, 2.0), 0, None) == 0      # nothing to do
+    fp32 = C.POINTER(_lib.rgba_frame_f32_t)
+    f32src = [HostFrame((0, 0, 63, 35), np.float32) for _ in range(2)]
+    f32dst = [HostFrame((0, 0, 127, 71), np.float32) for _ in range(2)]
+    s32 = (fp32 * 2)(C.pointer(f32src[0].c), None)
+    d32 = (fp32 * 2)(*[C.pointer(o.c) for o in f32dst])
+    assert lib.cvs_scale_bilinear_f32_batch_dev(d32, v2f(0, 0), s32, v2f(0, 0), v2f(2.0, 2.0), 2, None) == -1
+    assert "null pointer" in _lib.last_error()
     # the blur + over batch: same two rules
     full = [HostFrame((0, 0, 63, 35), np.uint16) for _ in range(3)]
     fdst = (fp16 * 3)(*[C.pointer(o.c) for o in full])

@@ -2160,6 +2160,83 @@ def test_scaler_form_by_format_and_size(cvs, force_fir, fmt):
     same(outs[None][1], outs["strips"][1], "automatic choice against strips, %s" % fmt)
 
 
+@pytest.mark.parametrize("pin", [None, "tiles", "strips"])
+@pytest.mark.parametrize("fmt,count,fac,tw,th", [("f16", 5, (2.0, 2.0), 384, 70), ("f16", 11, (1.5, 1.5), 300, 41), ("f32", 3, (2.0, 2.0), 260, 33),
+                                                ("f32", 9, (3.0, 2.0), 512, 25), ("f16", 4, (0.5, 0.5), 300, 40), ("f16", 3, (1.5, 2.0), 300, 40)])
+def test_scale_batch_is_the_single_calls(cvs, orc, force_fir, fmt, count, fac, tw, th, pin):
+    """cvs_scale_bilinear_f16/f32_batch_dev: independent frames of one geometry, up to eight per launch (grid.z = frame) of
+    one of the two vertical-first kernels -- left alone, halfs on the strips and floats on the tiles; pinned, either.  The
+    pixels must be those of `count` single calls, and those are checked against the oracle.  11 and 9 frames: a launch of
+    eight and one of three / of one (a single frame goes the ordinary way); factor 1/2: batched on the strips; a horizontal
+    factor below the vertical one: no batched form, frame by frame -- same answer."""
+    force_fir(pin)
+    rng = np.random.default_rng(900 + count)
+    sw, sh = int(tw / fac[0]) + 3, int(th / fac[1]) + 3
+    sfull, tfull = (-2, 1, sw - 3, sh), (4, -3, tw + 3, th - 4)
+    scur = (0, 2, sw - 5, sh - 1)
+    tp, sp = (4.5, -3.0), (0.75, 2.0)
+    srcs16 = [rand_f16_frame(rng, sfull, scur) for _ in range(count)]
+    if fmt == "f16":
+        d_src = [DeviceFrame.from_host(f) for f in srcs16]
+        d_one = [DeviceFrame(tfull, np.uint16) for _ in range(count)]
+        d_bat = [DeviceFrame(tfull, np.uint16) for _ in range(count)]
+        tab = lambda fr: (C.POINTER(_lib.rgba_frame_f16_t) * len(fr))(*[C.pointer(f.c) for f in fr])
+        single, batch = cvs.cvs_scale_bilinear_f16_dev, cvs.cvs_scale_bilinear_f16_batch_dev
+    else:
+        srcs32 = [HostFrame(sfull, np.float32, orc.half_to_float(f.array), scur) for f in srcs16]
+        d_src = [DeviceFrame.from_host(f) for f in srcs32]
+        d_one = [DeviceFrame(tfull, np.float32) for _ in range(count)]
+        d_bat = [DeviceFrame(tfull, np.float32) for _ in range(count)]
+        tab = lambda fr: (C.POINTER(_lib.rgba_frame_f32_t) * len(fr))(*[C.pointer(f.c) for f in fr])
+        single, batch = cvs.cvs_scale_bilinear_f32_dev, cvs.cvs_scale_bilinear_f32_batch_dev
+    for o, i in zip(d_one, d_src):
+        _lib.check(single(o.ref(), v2f(*tp), i.ref(), v2f(*sp), v2f(*fac), None))
+    _lib.check(batch(tab(d_bat), v2f(*tp), tab(d_src), v2f(*sp), v2f(*fac), count, None))
+    if fac[0] >= fac[1] and fac[1] > 1.0 and count % 8 != 1:
+        tiles = pin == "tiles" or (pin is None and fmt == "f32")
+        assert cvs.cvs_fir_last_kernel() == (_lib.FIR_KERNEL_TILE_VH if tiles else _lib.FIR_KERNEL_VH)
+    force_fir(None)
+    src32_0 = HostFrame(sfull, np.float32, orc.half_to_float(srcs16[0].array), scur)
+    want32 = HostFrame(tfull, np.float32)
+    orc.lib().orc_scale_bilinear_f32(want32.ref(), v2f(*tp), src32_0.ref(), v2f(*sp), v2f(*fac))
+    for k, (a, b) in enumerate(zip(d_one, d_bat)):
+        ga, gb = a.download(), b.download()
+        assert same_window(ga.current_window, gb.current_window), (k, ga.current_window.tuple(), gb.current_window.tuple())
+        assert np.array_equal(ga.array.view(np.uint8), gb.array.view(np.uint8)), "frame %d of the batch differs from its single call" % k
+        if k == 0:
+            assert same_window(gb.current_window, want32.current_window)
+            if fmt == "f16":
+                assert_same_f16(gb.window_view(), orc.float_to_half(want32.window_view()), "batched scale f16")
+            else:
+                assert_same_f32(gb.window_view(), want32.window_view(), "batched scale f32")
+    for d in d_src + d_one + d_bat:
+        d.free()
+
+
+def test_scale_batch_falls_back_on_mixed_geometry_and_overlap(cvs, orc):
+    """Frames of different geometry, or a target that is another frame's source, are not batched: the call still gives every
+    frame what its single call gives."""
+    rng = np.random.default_rng(77)
+    a = [rand_f16_frame(rng, (0, 0, 199, 29), (0, 0, 199, 29)) for _ in range(3)]
+    b = rand_f16_frame(rng, (0, 0, 149, 29), (0, 0, 149, 29))                    # a narrower source
+    srcs = [DeviceFrame.from_host(f) for f in (a[0], b, a[1], a[2])]
+    outs = [DeviceFrame((0, 0, 399, 59), np.uint16) for _ in range(4)]
+    ones = [DeviceFrame((0, 0, 399, 59), np.uint16) for _ in range(4)]
+    tab = lambda fr: (C.POINTER(_lib.rgba_frame_f16_t) * len(fr))(*[C.pointer(f.c) for f in fr])
+    _lib.check(cvs.cvs_scale_bilinear_f16_batch_dev(tab(outs), v2f(0, 0), tab(srcs), v2f(0, 0), v2f(2.0, 2.0), 4, None))
+    for o, i in zip(ones, srcs):
+        _lib.check(cvs.cvs_scale_bilinear_f16_dev(o.ref(), v2f(0, 0), i.ref(), v2f(0, 0), v2f(2.0, 2.0), None))
+    for k in range(4):
+        x, y = outs[k].download(), ones[k].download()
+        assert same_window(x.current_window, y.current_window) and np.array_equal(x.array, y.array), k
+    # the same target twice: the second write must see what a sequence of single calls leaves (the last frame's pixels)
+    twice = [outs[0], outs[0]]
+    _lib.check(cvs.cvs_scale_bilinear_f16_batch_dev(tab(twice), v2f(0, 0), tab([srcs[0], srcs[2]]), v2f(0, 0), v2f(2.0, 2.0), 2, None))
+    assert np.array_equal(outs[0].download().array, ones[2].download().array)
+    for d in srcs + outs + ones:
+        d.free()
+
+
 def test_tile_scaler_random_geometry(cvs, orc):
     """The tile form of the vertical-first scaler (k_fir_tile_vh) takes targets of 256 columns and more whose tables are short
     and narrow.  80 random set-ups wide enough for it -- enlarging factors with the vertical one never the larger, fractional

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--streams", type=int, default=1, help="frames alternate over this many HIP streams (the bench's scaler record uses 2)")
     ap.add_argument("--diag-mode", type=int, default=0, help="diagnostic build only: k_fir_tile_vh's timing-only variants (1: stores only)")
+    ap.add_argument("--batch", type=int, default=1, help="frames per call through cvs_scale_bilinear_*_batch_dev (1: the single-frame entry)")
     ap.add_argument("--tiles", action="store_true", help="pin it to the tile form wherever that takes the call (CVS_FIR_PATH_TILES)")
     ap.add_argument("--strips", action="store_true", help="pin the vertical-first scaler to k_fir_vh's strips (CVS_FIR_PATH_STRIPS)")
     args = ap.parse_args()
@@ -42,7 +43,7 @@ def main():
         lib.cvk_fir_tvh_diag_mode.restype, lib.cvk_fir_tvh_diag_mode.argtypes = C.c_int, [C.c_int]
         assert lib.cvk_fir_tvh_diag_mode(args.diag_mode) == 0
     streams = [None] if args.streams <= 1 else [lib.cvs_stream_create() for _ in range(args.streams)]
-    nout = max(2, 2 * len(streams))
+    nout = max(2, 2 * len(streams)) * max(args.batch, 1)
 
     def sync():
         for st in streams:
@@ -82,8 +83,19 @@ def main():
             lib.cvs_stream_sync(None)
             call = lib.cvs_scale_bilinear_f16_dev if fmt == "f16" else lib.cvs_scale_bilinear_f32_dev
 
+            B = max(args.batch, 1)
+            if B > 1:
+                bcall = lib.cvs_scale_bilinear_f16_batch_dev if fmt == "f16" else lib.cvs_scale_bilinear_f32_batch_dev
+                ft = _lib.rgba_frame_f16_t if fmt == "f16" else _lib.rgba_frame_f32_t
+                ngroups = nout // B
+                otabs = [(C.POINTER(ft) * B)(*[C.pointer(outs[g * B + k].c) for k in range(B)]) for g in range(ngroups)]
+                stabs = [(C.POINTER(ft) * B)(*[C.pointer(srcs[(g * B + k) % nsrc].c) for k in range(B)]) for g in range(max(1, nsrc // B) if nsrc >= B else 1)]
+
             def run(i):
-                _lib.check(call(outs[i % nout].ref(), v2f(0, 0), srcs[i % nsrc].ref(), v2f(0, 0), v2f(*fac), streams[i % len(streams)]))
+                if B > 1:
+                    _lib.check(bcall(otabs[i % ngroups], v2f(0, 0), stabs[i % len(stabs)], v2f(0, 0), v2f(*fac), B, streams[i % len(streams)]))
+                else:
+                    _lib.check(call(outs[i % nout].ref(), v2f(0, 0), srcs[i % nsrc].ref(), v2f(0, 0), v2f(*fac), streams[i % len(streams)]))
             for i in range(3):
                 run(i)
             sync()
@@ -93,7 +105,7 @@ def main():
                 for i in range(args.reps):
                     run(i)
                 sync()
-                best = min(best, (time.perf_counter() - t0) / args.reps)
+                best = min(best, (time.perf_counter() - t0) / (args.reps * B))
             nbytes = (w * h + tw * th) * bpp
             print("%-16s %s  %.4f ms  %.2f TB/s (%.3f of 8)  kernel=%s fused=%d" % (
                 name, fmt, best * 1e3, nbytes / best / 1e12, nbytes / best / 8e12, NAMES[lib.cvs_fir_last_kernel()], lib.cvs_scale_last_was_fused()), flush=True)
