@@ -279,6 +279,8 @@ __global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const uint32_t *hpack,
     constexpr bool kBothAtOnce = MAXTH * MAXTV <= 4;                     // registers: both pixels' reads in flight, or one pixel's
     RawRec first_rec = read_rec(wave);
     Rec rc = decode(first_rec);
+    // (uniform) every lane's second pixel starts on the source column its first pixel ends on: that vertical sum is formed once
+    const bool share = MAXTH == 2 && !cvs::wave_any(acol[1][0] != acol[0][1]);
 #ifdef CVS_TVH_DIAG
     if (g_tvh_mode == 2) {                                               // the whole set-up, then stores only
         for (int line = wave; line < tl; line += kWaves) {
@@ -294,9 +296,12 @@ __global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const uint32_t *hpack,
         const int n = cur.n;                                             // uniform
         RawRec nxt = read_rec(line + kWaves);
         Px sp[kBothAtOnce ? 2 : 1][MAXTH][MAXTV];                       // (one pixel's at a time when they are many)
-        auto request = [&](int p) __attribute__((always_inline)) {
+        // `shared`: the second pixel's first tap is the source column of the first pixel's second (every lane of the wave:
+        // a 2 : 1 enlargement away from the edges) -- that vertical sum is formed once
+        auto request = [&](int p, auto shared) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < MAXTH; j++) {
+                if (decltype(shared)::value && p == 1 && j == 0) continue;
 #pragma unroll
                 for (int k = 0; k < MAXTV; k++) {
                     const float4 v = S[cur.row + min(k, max(n - 1, 0)) * swp + acol[p][j]];
@@ -304,39 +309,43 @@ __global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const uint32_t *hpack,
                 }
             }
         };
-        auto landed = [&](int p) __attribute__((always_inline)) {
+        auto landed = [&](int p, auto shared) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < MAXTH; j++) {
+                if (decltype(shared)::value && p == 1 && j == 0) continue;
 #pragma unroll
                 for (int k = 0; k < MAXTV; k++) pin(sp[kBothAtOnce ? p : 0][j][k]);
             }
         };
-        request(0);
-        if constexpr (kBothAtOnce) request(1);
-        pin(nxt.a);
-        if constexpr (MAXTV > 2) pin(nxt.b);
-        rc = decode(nxt);
         f32x2 hlo[2], hhi[2];
         // the vertical sum at each tap's source column -- exactly the line's taps, ascending -- times the tap's weight, added
         // in ascending tap order.  The usual line has all MAXTV taps: its chain has no test in it (wave-uniform choice).
-        auto sums = [&](auto full) __attribute__((always_inline)) {
+        auto sums = [&](auto full, auto shared) __attribute__((always_inline)) {
+            request(0, shared);
+            if constexpr (kBothAtOnce) request(1, shared);
+            Px keep = { f32x2{ 0.0f, 0.0f }, f32x2{ 0.0f, 0.0f } };
 #pragma unroll
             for (int p = 0; p < 2; p++) {
-                if (p == 1 && !kBothAtOnce) request(1);
-                if (p == 0 || !kBothAtOnce) landed(p);
-                if (p == 0 && kBothAtOnce) landed(1);
+                if (p == 1 && !kBothAtOnce) request(1, shared);
+                if (p == 0 || !kBothAtOnce) landed(p, shared);
+                if (p == 0 && kBothAtOnce) landed(1, shared);
 #pragma unroll
                 for (int j = 0; j < MAXTH; j++) {
-                    const f32x2 w0 = { cur.w[0], cur.w[0] };
-                    const int q = kBothAtOnce ? p : 0;
-                    Px mid = { sp[q][j][0].lo * w0, sp[q][j][0].hi * w0 };       // (0 + p0 is p0: gather_common.hpp vsum)
+                    Px mid;
+                    if (decltype(shared)::value && p == 1 && j == 0) mid = keep;
+                    else {
+                        const f32x2 w0 = { cur.w[0], cur.w[0] };
+                        const int q = kBothAtOnce ? p : 0;
+                        mid = Px{ sp[q][j][0].lo * w0, sp[q][j][0].hi * w0 };    // (0 + p0 is p0: gather_common.hpp vsum)
 #pragma unroll
-                    for (int k = 1; k < MAXTV; k++) {
-                        if (decltype(full)::value || k < n) {
-                            const f32x2 wk = { cur.w[k], cur.w[k] };
-                            mid.lo = cvs::madd(sp[q][j][k].lo, wk, mid.lo);      // t += s * coeff
-                            mid.hi = cvs::madd(sp[q][j][k].hi, wk, mid.hi);
+                        for (int k = 1; k < MAXTV; k++) {
+                            if (decltype(full)::value || k < n) {
+                                const f32x2 wk = { cur.w[k], cur.w[k] };
+                                mid.lo = cvs::madd(sp[q][j][k].lo, wk, mid.lo);  // t += s * coeff
+                                mid.hi = cvs::madd(sp[q][j][k].hi, wk, mid.hi);
+                            }
                         }
+                        if (decltype(shared)::value && p == 0 && j == 1) keep = mid;
                     }
                     const f32x2 wj = { wt[p][j], wt[p][j] };
                     if (j == 0) { hlo[p] = mid.lo * wj; hhi[p] = mid.hi * wj; }
@@ -344,9 +353,14 @@ __global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const uint32_t *hpack,
                 }
             }
         };
-        if (__builtin_expect(n == MAXTV, 1)) sums(std::true_type{});
-        else {
-            sums(std::false_type{});
+        pin(nxt.a);
+        if constexpr (MAXTV > 2) pin(nxt.b);
+        rc = decode(nxt);
+        if (__builtin_expect(n == MAXTV, 1)) {
+            if (MAXTH == 2 && kBothAtOnce && share) sums(std::true_type{}, std::true_type{});
+            else sums(std::true_type{}, std::false_type{});
+        } else {
+            sums(std::false_type{}, std::false_type{});
             if (n <= 0) {                                                // a line without taps is zeros
 #pragma unroll
                 for (int p = 0; p < 2; p++) { hlo[p] = f32x2{ 0.0f, 0.0f }; hhi[p] = f32x2{ 0.0f, 0.0f }; }
