@@ -59,6 +59,24 @@ static_assert(kTW == 4 * CVK_FIR2D_TILE_X, "a tile spans four entries of the foo
 __device__ __forceinline__ void pin(Px &v) { asm volatile("" : "+v"(v.lo), "+v"(v.hi)); }           // (as the two register pairs the packed arithmetic takes)
 __device__ __forceinline__ void pin(uint4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 
+// narrow4 (gather_common.hpp) for the lane's two pixels at once: ONE test for all eight channels, the largest magnitude through
+// two three-input maxima with |.| as operand modifiers (written as instructions: hipcc canonicalises each operand of fmaxf
+// with an instruction of its own, which was 4 of the 62 vector instructions of a line)
+__device__ __forceinline__ uint4 narrow8(f32x2 lo0, f32x2 hi0, f32x2 lo1, f32x2 hi1) {
+    float big;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|\n\t"
+        "v_max3_f32 %0, %0, |%4|, |%5|\n\t"
+        "v_max3_f32 %0, %0, |%6|, |%7|\n\t"
+        "v_max_f32 %0, %0, |%8|"
+        : "=&v"(big) : "v"(lo0.x), "v"(lo0.y), "v"(hi0.x), "v"(hi0.y), "v"(lo1.x), "v"(lo1.y), "v"(hi1.x), "v"(hi1.y));
+    // (a NaN operand is passed over by the maxima, as by fmaxf: a NaN channel needs no fix-up, the conversion keeps it)
+    if (cvs::wave_any(!(big < 65536.0f))) {
+        cvs::rare_path();
+        return make_uint4(cvs::f2h_rz2(lo0.x, lo0.y), cvs::f2h_rz2(hi0.x, hi0.y), cvs::f2h_rz2(lo1.x, lo1.y), cvs::f2h_rz2(hi1.x, hi1.y));
+    }
+    return make_uint4(cvs::pkrtz(lo0.x, lo0.y), cvs::pkrtz(hi0.x, hi0.y), cvs::pkrtz(lo1.x, lo1.y), cvs::pkrtz(hi1.x, hi1.y));
+}
+
 // seg: target lines per workgroup; swp: pixels per LDS row (>= source columns under any 128 target columns + 1: the last
 // is the row's zero pixel); shp: rows of S (>= source rows under any `seg` consecutive lines)
 // The first arguments are what the set-up needs before anything else, as plain scalars: hipcc is told to have them preloaded
@@ -368,9 +386,9 @@ __global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const uint32_t *hpack,
         }
         char *optr = obase + (size_t)line * trow;
         if constexpr (out_half) {
-            const uint2 a = narrow4(hlo[0], hhi[0]), b = narrow4(hlo[1], hhi[1]);
-            if (all_live || col_live[1]) *reinterpret_cast<uint4 *>(optr) = make_uint4(a.x, a.y, b.x, b.y);
-            else if (col_live[0]) *reinterpret_cast<uint2 *>(optr) = a;
+            const uint4 h = narrow8(hlo[0], hhi[0], hlo[1], hhi[1]);
+            if (all_live || col_live[1]) *reinterpret_cast<uint4 *>(optr) = h;
+            else if (col_live[0]) *reinterpret_cast<uint2 *>(optr) = make_uint2(h.x, h.y);
         } else {
 #pragma unroll
             for (int p = 0; p < 2; p++)
