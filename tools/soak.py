@@ -46,6 +46,17 @@ from canvas_amd.abi import v2f  # noqa: E402
 up2 = DeviceFrame((0, 0, 2 * w - 1, 2 * h - 1), np.uint16)
 half = DeviceFrame((0, 0, w // 2 - 1, h // 2 - 1), np.uint16)
 anam = DeviceFrame((0, 0, int(w * 0.75) - 1, int(h * 1.5) - 1), np.uint16)
+# the tile form of the vertical-first scaler (round 4): 1080p -> 4K halfs, single and three frames per launch (the batch entry,
+# halfs on the strips), and floats
+hd = [DeviceFrame.from_host(synth.layer_frame(w // 2, h // 2, 1, g)) for g in range(3)]
+hd32 = DeviceFrame((0, 0, w // 2 - 1, h // 2 - 1), np.float32)
+_lib.check(lib.cvs_frame_f16_to_f32_dev(hd32.ref(), hd[0].ref(), None))
+_lib.check(lib.cvs_stream_sync(None))
+up4k = DeviceFrame(full, np.uint16)
+up4k32 = DeviceFrame(full, np.float32)
+upb = [DeviceFrame(full, np.uint16) for _ in range(3)]
+_tab16 = lambda fr: (C.POINTER(_lib.rgba_frame_f16_t) * len(fr))(*[C.pointer(f.c) for f in fr])
+upb_t, hd_t = _tab16(upb), _tab16(hd)
 
 
 def once():
@@ -61,6 +72,9 @@ def once():
     _lib.check(lib.cvs_scale_bilinear_f16_dev(up2.ref(), v2f(0, 0), sets[1][1][0].ref(), v2f(0, 0), v2f(2.0, 2.0), stream))
     _lib.check(lib.cvs_scale_bilinear_f16_dev(half.ref(), v2f(0, 0), sets[2][1][0].ref(), v2f(0, 0), v2f(0.5, 0.5), stream))
     _lib.check(lib.cvs_scale_bilinear_f16_dev(anam.ref(), v2f(0, 0), sets[3][1][0].ref(), v2f(0, 0), v2f(0.75, 1.5), stream))
+    _lib.check(lib.cvs_scale_bilinear_f16_dev(up4k.ref(), v2f(0, 0), hd[0].ref(), v2f(0, 0), v2f(2.0, 2.0), stream))
+    _lib.check(lib.cvs_scale_bilinear_f32_dev(up4k32.ref(), v2f(0, 0), hd32.ref(), v2f(0, 0), v2f(2.0, 2.0), stream))
+    _lib.check(lib.cvs_scale_bilinear_f16_batch_dev(upb_t, v2f(0, 0), hd_t, v2f(0, 0), v2f(2.0, 2.0), 3, stream))
 
 
 def snapshot():
@@ -68,7 +82,8 @@ def snapshot():
     return [s[0].download().array.copy() for s in sets] + [graph.slots[0]["out"].download().array.copy(), graph.slots[1]["out"].download().array.copy(),
                                                         small.download().array.copy(), odd.download().array.copy(), wide.download().array.copy(),
                                                         big.download().array.copy(), mid.download().array.copy(), deep.download().array.copy(),
-                                                        up2.download().array.copy(), half.download().array.copy(), anam.download().array.copy()]
+                                                        up2.download().array.copy(), half.download().array.copy(), anam.download().array.copy(),
+                                                        up4k.download().array.copy(), up4k32.download().array.copy()] + [u.download().array.copy() for u in upb]
 
 
 once()
@@ -87,5 +102,5 @@ while time.perf_counter() - t0 < seconds:
     checks += 1
     if checks % 50 == 0:                      # (a silent GPU command is taken for hung after a few minutes)
         print("  %d iterations, %d compares, %.0f s" % (n, checks, time.perf_counter() - t0), flush=True)
-print("soak ok: %d iterations (%d launches of the chain over 8 frames, %d config-5 frames, %d config-3 frames, as many 0.4x / 0.75x / 1.5x resamples, 21-tap blurs, 6-layer stacks and scaler calls at 2x, 0.5x and 0.75 x 1.5), %d full compares, %.1f s"
+print("soak ok: %d iterations (%d launches of the chain over 8 frames, %d config-5 frames, %d config-3 frames, as many 0.4x / 0.75x / 1.5x resamples, 21-tap blurs, 6-layer stacks and scaler calls at 2x, 0.5x and 0.75 x 1.5, 1080p -> 4K on the tile kernel in halfs and floats and three frames in one launch), %d full compares, %.1f s"
       % (n, n, 2 * n, n, checks, time.perf_counter() - t0))
