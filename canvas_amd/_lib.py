@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libcanvas_hip.so")
 
 CHAIN_MAX_LAYERS = 8
 DISPLAY_RGBA8, DISPLAY_ARGB32_PREMUL = 0, 1
-FIR_PATH_AUTO, FIR_PATH_SWEEP, FIR_PATH_TILED, FIR_PATH_TABLES, FIR_PATH_HV, FIR_PATH_ONE_COLUMN, FIR_PATH_TWO_COLUMNS, FIR_PATH_STRIPS, FIR_PATH_TILES = 0, 1, 2, 4, 16, 32, 64, 128, 256
-FIR_KERNEL_NONE, FIR_KERNEL_WINDOW, FIR_KERNEL_HALVE, _FIR_KERNEL_RETIRED_3, FIR_KERNEL_VH, FIR_KERNEL_TILED, FIR_KERNEL_STREAM, FIR_KERNEL_TWO_PASS, FIR_KERNEL_PASS, FIR_KERNEL_HV, FIR_KERNEL_WINDOW_PAIR, FIR_KERNEL_HALVE_PAIR, FIR_KERNEL_TILE_VH = range(13)
+FIR_PATH_AUTO, FIR_PATH_PASSES, FIR_PATH_TILED, FIR_PATH_TABLES, FIR_PATH_HV, FIR_PATH_ONE_COLUMN, FIR_PATH_TWO_COLUMNS, FIR_PATH_STRIPS, FIR_PATH_TILES = 0, 1, 2, 4, 16, 32, 64, 128, 256
+FIR_KERNEL_NONE, FIR_KERNEL_WINDOW, FIR_KERNEL_HALVE, _FIR_KERNEL_RETIRED_3, FIR_KERNEL_VH, FIR_KERNEL_TILED, _FIR_KERNEL_RETIRED_6, FIR_KERNEL_TWO_PASS, FIR_KERNEL_PASS, FIR_KERNEL_HV, FIR_KERNEL_WINDOW_PAIR, FIR_KERNEL_HALVE_PAIR, FIR_KERNEL_TILE_VH = range(13)
 ARITH_SEPARATE, ARITH_CONTRACTED = 0, 1          # cvs_set_arithmetic: the reference's gcc build / its clang (contracting) build
 LUT_NONE, LUT_REC709_TO_LINEAR_SCENE, LUT_REC709_TO_LINEAR_DISPLAY, LUT_LINEAR_TO_REC709, LUT_LINEAR_TO_SRGB = -1, 0, 1, 2, 3
 

@@ -42,7 +42,7 @@ static void fir_launch_fell_through(const char *kernel, int rc) {
     t_fell_through++;
     cvs_log_warning("%s did not launch (%s): falling back to the next FIR kernel", kernel, hipGetErrorString((hipError_t)rc));
 }
-CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_HV | CVS_FIR_PATH_ONE_COLUMN | CVS_FIR_PATH_TWO_COLUMNS | CVS_FIR_PATH_STRIPS | CVS_FIR_PATH_TILES)); }
+CVS_EXPORT void cvs_fir_path_override(int mode) { atomic_store(&g_fir_path, mode & (CVS_FIR_PATH_PASSES | CVS_FIR_PATH_TILED | CVS_FIR_PATH_TABLES | CVS_FIR_PATH_HV | CVS_FIR_PATH_ONE_COLUMN | CVS_FIR_PATH_TWO_COLUMNS | CVS_FIR_PATH_STRIPS | CVS_FIR_PATH_TILES)); }
 
 typedef struct {
     int t0, t1;            /* target lines covered by the table */
@@ -301,7 +301,7 @@ static int scale_core(any_frame *target, v2f tp, const any_frame *source, v2f sp
     t_fir_kernel = CVS_FIR_KERNEL_NONE;
     /* a batch goes through the vertical-first fused launch or not at all (2: the caller does its frames one by one) */
     if (t_scale_batch && ((fac.x == 1.0f && tp.x == sp.x) || (fac.y == 1.0f && tp.y == sp.y) || fac.x < fac.y ||
-                          (atomic_load(&g_fir_path) & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED)))) return 2;
+                          (atomic_load(&g_fir_path) & (CVS_FIR_PATH_PASSES | CVS_FIR_PATH_TILED)))) return 2;
     if (fac.x == 1.0f && tp.x == sp.x) return triangle_pass(target, tp.y, source, sp.y, fac.y, 0, s);
     if (fac.y == 1.0f && tp.y == sp.y) return triangle_pass(target, tp.x, source, sp.x, fac.x, 1, s);
 
@@ -318,7 +318,7 @@ static int scale_core(any_frame *target, v2f tp, const any_frame *source, v2f sp
                   sc->max.x, (int)madd_as(fl, tf->max.y - tp.y, fac.y, sp.y));
     box2i_intersect(&mid.full, &mid.full, tf);
     mid.cur = mid.full;
-    if (!(atomic_load(&g_fir_path) & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED))) {
+    if (!(atomic_load(&g_fir_path) & (CVS_FIR_PATH_PASSES | CVS_FIR_PATH_TILED))) {
         int rc = x_first ? triangle_fused_hv(target, tp, source, sp, fac, &mid.full, s) : triangle_fused_vh(target, tp, source, sp, fac, &mid.full, s);
         if (rc == 0) t_scale_fused = 1;
         if (rc <= 0) return rc;                              /* done, or failed; 1: not for the fused kernel */
@@ -638,7 +638,7 @@ static int axis_upload(const tap_table *tb, int tile, axis_entry *e) {
             if (src[0] < prev_a || src[n - 1] < prev_b) streamable = 0;
             prev_a = src[0]; prev_b = src[n - 1];
         }
-        for (int g = 0; g < lines; g += 128) {              /* the streaming kernel's strips (resample_ops.hip kW) */
+        for (int g = 0; g < lines; g += 128) {              /* strips of 128 lines (tile_vh_ops.hip's target columns) */
             int first = INT_MAX, last = INT_MIN;
             for (int i = g; i < lines && i < g + 128; i++) {
                 if (!ntaps[i]) continue;
@@ -907,34 +907,19 @@ static int fir2d_launch(void *tdata, const box2i *tfull, int out_half, const voi
     fp.h = *h; fp.v = *v;
     fp.max_sw = h_foot > 0 ? h_foot : 1;
     fp.max_sh = v_foot > 0 ? v_foot : 1;
-    /* Footprints that take most of the LDS leave the tiled kernel one or two workgroups per CU (a 0.4x Lanczos: 112 KiB per
-     * 32 x 16 target pixels); such table pairs are swept down the frame instead (resample_ops.hip; 4K -> 1536x864: 0.22 ->
-     * 0.08 ms) when the vertical table allows it (consecutive, non-decreasing tap lists) and the lists fit its registers.
-     * Small footprints (enlargements, blurs) stay with the tiles, which are as fast or faster there.
-     * cvs_fir_path_override() pins one or the other (parity tests of each kernel, A/B runs). */
+    /* First choice: the gather per target line (sweep_hv_ops.hip; plain flavour), whenever first taps never decrease down the
+     * vertical table and the lists fit an instance; then the LDS tiles (both flavours) while the footprint of a 32 x 16 tile
+     * fits; else 1: the caller runs the two passes through an f32 frame.  cvs_fir_path_override() pins one of the three
+     * (parity tests of each, A/B runs).  (A lane-per-pixel sweep, k_fir_stream, stood between the first two until round 4: it
+     * took table pairs whose tiles need more than 64 KiB once the gather had refused them -- lists longer than 24 -- and was
+     * retired with that corner: those go to the tiles up to 150 KiB and to the two passes beyond.) */
     const int force = atomic_load(&g_fir_path);
-    /* First choice: the gather per target line (sweep_hv_ops.hip), whenever first taps never decrease down the vertical
-     * table and the lists fit an instance. */
-    const bool pinned = (force & (CVS_FIR_PATH_SWEEP | CVS_FIR_PATH_TILED | CVS_FIR_PATH_HV)) != 0;
-    const bool plain = cvs_arith() == CVS_ARITH_SEPARATE;      /* the two sweeps below exist in the plain flavour only; the tiles and the passes in both */
-    if (plain) {
-    if ((force & CVS_FIR_PATH_HV) || !pinned) {
-        if (cvk_fir_hv_supported(&fp)) {
-            int rc = cvk_fir_hv(&fp, cvs_cus(), s);
-            if (rc == 0) { t_fir_kernel = CVS_FIR_KERNEL_HV; return 0; }
-            fir_launch_fell_through("k_fir_hv", rc);          /* did not launch: the older kernels decide */
-        }
-    }
-    const bool can_stream = v->streamable && h->max_taps >= 1 && v->max_active >= 1 && cvk_fir_stream_supported(h->max_taps, v->max_active);
-    const bool want_stream = (force & CVS_FIR_PATH_SWEEP) ? true : CVK(cvk_fir2d_lds_bytes)(&fp) > 64 * 1024;
-    if (can_stream && want_stream && !(force & CVS_FIR_PATH_TILED)) {
-        cvk_fir2d_params sp = fp;
-        sp.max_sw = h->wide_foot > 0 ? h->wide_foot : 1;
-        sp.max_sh = 0;
-        int rc = cvk_fir_stream(&sp, h->max_taps, v->max_active, cvs_cus(), s);
-        if (rc == 0) { t_fir_kernel = CVS_FIR_KERNEL_STREAM; return 0; }
-        fir_launch_fell_through("k_fir_stream", rc);          /* did not fit: the tiled kernel decides */
-    }
+    if (force & CVS_FIR_PATH_PASSES) return 1;
+    const bool pinned = (force & (CVS_FIR_PATH_TILED | CVS_FIR_PATH_HV)) != 0;
+    if (cvs_arith() == CVS_ARITH_SEPARATE && ((force & CVS_FIR_PATH_HV) || !pinned) && cvk_fir_hv_supported(&fp)) {
+        int rc = cvk_fir_hv(&fp, cvs_cus(), s);
+        if (rc == 0) { t_fir_kernel = CVS_FIR_KERNEL_HV; return 0; }
+        fir_launch_fell_through("k_fir_hv", rc);              /* did not launch: the tiles decide */
     }
     if (CVK(cvk_fir2d_lds_bytes)(&fp) > 150 * 1024 || h->stride > 64 || v->stride > 64) return 1;
     int rc = CVK(cvk_fir2d)(&fp, s);

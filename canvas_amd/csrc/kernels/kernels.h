@@ -150,7 +150,7 @@ typedef struct {
     const int *foot;
     int stride;
     int lines;                 /* target lines the table covers (ntaps is also the start of the table's device block: CVK_AXIS_OFF_*) */
-    /* facts about the table the host worked out when it built it (for the streaming kernel, resample_ops.hip) */
+    /* facts about the table the host worked out when it built it */
     int max_taps;              /* longest tap list */
     int wide_foot;             /* widest source footprint of any run of 128 lines starting at a multiple of 128 */
     int max_active;            /* as the vertical axis: the longest run of lines i..j such that line j starts at or before line i's last tap */
@@ -190,9 +190,6 @@ typedef struct {
 } cvk_fir2d_params;
 #define CVK_FIR2D_TILE_X 32
 #define CVK_FIR2D_TILE_Y 16
-/* the same tables, swept down the frame (resample_ops.hip): fp->max_sw = h.wide_foot; needs v.streamable */
-int cvk_fir_stream_supported(int h_taps, int v_active);
-int cvk_fir_stream(const cvk_fir2d_params *fp, int h_taps, int v_active, int cus, void *stream);
 /* the same tables, horizontal pass first, as a gather per target line (sweep_hv_ops.hip): needs v.streamable and
  * v.lrec (vertical lists <= CVK_FIR_LREC - 2), horizontal lists <= 24; first choice for these tables */
 int cvk_fir_hv_supported(const cvk_fir2d_params *fp);

@@ -421,7 +421,7 @@ CVS_EXPORT int cvs_blur_lanczos_f16_batch_dev(rgba_frame_f16 *const *targets, co
  * every line), and for per-line tables the gather per target line, tiles in LDS, and the sweep with a lane per pixel.
  * All compute the same sums in the same order -- results are bit-equal, which the parity tests show by pinning each kernel
  * in turn through this call.  It changes speed only, never pixels; process-wide; 0 restores the automatic choice. */
-enum { CVS_FIR_PATH_AUTO = 0, CVS_FIR_PATH_SWEEP = 1 /* lane per pixel */, CVS_FIR_PATH_TILED = 2, CVS_FIR_PATH_TABLES = 4 /* skip the register-window kernel */,
+enum { CVS_FIR_PATH_AUTO = 0, CVS_FIR_PATH_PASSES = 1 /* no launch that does both passes: the reference's two passes through an f32 frame */, CVS_FIR_PATH_TILED = 2, CVS_FIR_PATH_TABLES = 4 /* skip the register-window kernel */,
        CVS_FIR_PATH_HV = 16 /* per-line gather, horizontal pass first (the automatic first choice) */,
        CVS_FIR_PATH_ONE_COLUMN = 32 /* the register-window kernels (blur, blur + halving) with one column per lane, never two */,
        CVS_FIR_PATH_TWO_COLUMNS = 64 /* ... with two columns per lane wherever that form takes the launch, narrow frames included */,
@@ -437,7 +437,7 @@ enum { CVS_FIR_KERNEL_NONE = 0,
        /* 3: the channel-pair sweep of rounds 2-3 (k_fir_lanes), retired in round 4 in favour of k_fir_hv */
        CVS_FIR_KERNEL_VH = 4,          /* k_fir_vh: the triangle scaler with the vertical pass first */
        CVS_FIR_KERNEL_TILED = 5,       /* k_fir2d: LDS tiles */
-       CVS_FIR_KERNEL_STREAM = 6,      /* k_fir_stream: lane-per-pixel sweep */
+       CVS_FIR_KERNEL_RETIRED_6 = 6,   /* (k_fir_stream, lane-per-pixel sweep: retired in round 4) */
        CVS_FIR_KERNEL_TWO_PASS = 7,    /* two k_fir launches through an f32 frame (cached tables) */
        CVS_FIR_KERNEL_PASS = 8,        /* k_fir: one pass of the triangle scaler (both passes: two of these) */
        CVS_FIR_KERNEL_HV = 9,          /* k_fir_hv: per-line tables, horizontal pass first, gather per target line */

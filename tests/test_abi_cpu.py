@@ -202,7 +202,7 @@ def test_hot_kernels_keep_their_state_in_registers():
     import tempfile
     checked = hand = 0
     with tempfile.TemporaryDirectory(dir=build) as tmp:
-        for obj in ("blur_ops.hip.o", "blur_pair_ops.hip.o", "blur_halve_pair_ops.hip.o", "blur_long_ops.hip.o", "blur_even_ops.hip.o", "chain_ops.hip.o", "chain_deep_ops.hip.o", "color_ops.hip.o", "display_ops.hip.o", "resample_ops.hip.o", "sweep_vh_ops.hip.o", "sweep_hv_ops.hip.o", "blur_halve_ops.hip.o",
+        for obj in ("blur_ops.hip.o", "blur_pair_ops.hip.o", "blur_halve_pair_ops.hip.o", "blur_long_ops.hip.o", "blur_even_ops.hip.o", "chain_ops.hip.o", "chain_deep_ops.hip.o", "color_ops.hip.o", "display_ops.hip.o", "tile_vh_ops.hip.o", "sweep_vh_ops.hip.o", "sweep_hv_ops.hip.o", "blur_halve_ops.hip.o",
                     "blur_ops.fma.hip.o", "blur_pair_ops.fma.hip.o", "blur_halve_pair_ops.fma.hip.o", "blur_halve_ops.fma.hip.o", "chain_ops.fma.hip.o", "color_ops.fma.hip.o", "sweep_vh_ops.fma.hip.o"):
             src = os.path.join(build, obj)
             if not os.path.exists(src):

@@ -835,8 +835,8 @@ def force_fir(request):
         mode = _lib.FIR_PATH_AUTO
         if which:
             mode |= _lib.FIR_PATH_TABLES                    # blurs too: past the register-window kernel, to the table kernels
-        if which == "stream":
-            mode |= _lib.FIR_PATH_SWEEP
+        if which == "passes":                               # no launch that does both passes: two k_fir launches through an f32 frame
+            mode |= _lib.FIR_PATH_PASSES
         elif which == "tiled":
             mode |= _lib.FIR_PATH_TILED
         elif which == "hv":
@@ -856,7 +856,7 @@ def force_fir(request):
 
 
 _KERNEL_NAMES = {_lib.FIR_KERNEL_NONE: "none", _lib.FIR_KERNEL_WINDOW: "window", _lib.FIR_KERNEL_HALVE: "halve",
-                 _lib.FIR_KERNEL_VH: "vh", _lib.FIR_KERNEL_TILED: "tiled", _lib.FIR_KERNEL_STREAM: "stream",
+                 _lib.FIR_KERNEL_VH: "vh", _lib.FIR_KERNEL_TILED: "tiled",
                  _lib.FIR_KERNEL_TWO_PASS: "two-pass", _lib.FIR_KERNEL_PASS: "pass", _lib.FIR_KERNEL_HV: "hv",
                  _lib.FIR_KERNEL_WINDOW_PAIR: "window-pair", _lib.FIR_KERNEL_HALVE_PAIR: "halve-pair", _lib.FIR_KERNEL_TILE_VH: "tile-vh"}
 _FIR_SEEN = {}
@@ -864,16 +864,16 @@ _FIR_SEEN = {}
 
 def ran_on(cvs, forced, fallback=None, note=None):
     """cvs_fir_last_kernel() after a launch pinned with force_fir(forced): the pinned kernel, or -- for a table pair that
-    kernel does not take -- the documented fallback named by the caller (host/scale.c fir2d_launch: hv -> stream when
-    the tiles would need more than 64 KiB of LDS and the vertical table streams -> tiled -> two passes).
-    The two sweeps (hv, stream) exist in the default arithmetic flavour only: in the contracted one a table pair goes to the
-    tiles, or to the two passes when its footprint does not fit them -- same sums, and that is what the test then checks."""
+    kernel does not take -- the documented fallback named by the caller (host/scale.c fir2d_launch: hv -> tiled -> the two
+    passes; "passes" pins the last).  The per-line gather (hv) exists in the default arithmetic flavour only: in the contracted
+    one a table pair goes to the tiles, or to the two passes when its footprint does not fit them -- same sums, and that is
+    what the test then checks."""
     got = _KERNEL_NAMES[cvs.cvs_fir_last_kernel()]
     contracted = cvs.cvs_get_arithmetic() == _lib.ARITH_CONTRACTED
     if note is not None:
         _FIR_SEEN[note + (" [contracted]" if contracted else "")] = got
-    want = fallback or forced
-    if contracted and want in ("hv", "stream"):
+    want = {"passes": "two-pass"}.get(fallback or forced, fallback or forced)
+    if contracted and want == "hv":
         assert got in ("tiled", "two-pass"), "contracted flavour, pinned to %r: expected the tiles or the two passes, ran on %r" % (forced, got)
     else:
         assert got == want, "pinned to %r (expected to run on %r), ran on %r" % (forced, want, got)
@@ -883,14 +883,10 @@ def ran_on(cvs, forced, fallback=None, note=None):
 
 
 # cases of the tests below that the pinned kernel does NOT take, and where they go instead
-_FALLBACK = {
-    # the lane-per-pixel sweep keeps one accumulator per active target row and has instances up to 16 of them
-    # (cvk_fir_stream_supported): a 2x enlargement has 26 active rows, 2.1x and 3x more -> tiles
-    ("stream", (2.0, 2.0)): "tiled", ("stream", (1.5625, 2.1)): "tiled", ("stream", (0.3, 3.0)): "tiled",
-}
+_FALLBACK = {}
 
 
-@pytest.mark.parametrize("kernel", ["hv", "stream", "tiled"])
+@pytest.mark.parametrize("kernel", ["hv", "passes", "tiled"])
 @pytest.mark.parametrize("ssize,scur,tsize,fx,fy", [
     ((64, 36), None, (32, 18), 0.5, 0.5),
     ((400, 300), None, (160, 120), 0.4, 0.4),                # several strips of 128 columns, several row segments
@@ -927,7 +923,7 @@ def test_lanczos_resample_both_kernels(cvs, orc, force_fir, kernel, ssize, scur,
     assert_same_f16(o16.download().array, want16.array, "lanczos f16 (%s)" % kernel)
 
 
-@pytest.mark.parametrize("kernel", ["hv", "stream", "tiled"])
+@pytest.mark.parametrize("kernel", ["hv", "passes", "tiled"])
 @pytest.mark.parametrize("ssize,tsize,fx,fy", [((400, 300), (160, 120), 0.4, 0.4), ((96, 54), (144, 81), 1.5, 1.5), ((300, 200), (225, 150), 0.75, 0.75),
                                                ((96, 54), (192, 108), 2.0, 2.0)])
 def test_lanczos_resample_with_inf_and_nan_pixels(cvs, orc, force_fir, kernel, ssize, tsize, fx, fy):
@@ -955,7 +951,7 @@ def test_lanczos_resample_with_inf_and_nan_pixels(cvs, orc, force_fir, kernel, s
     assert_same_f32(got.array, want.array, "lanczos with non-finite pixels (%s)" % kernel)
 
 
-@pytest.mark.parametrize("kernel", ["hv", "stream", "tiled"])
+@pytest.mark.parametrize("kernel", ["hv", "passes", "tiled"])
 @pytest.mark.parametrize("ntaps", [1, 2, 4, 10, 16])
 def test_even_and_short_blurs_both_kernels(cvs, orc, force_fir, kernel, ntaps):
     rng = np.random.default_rng(63)
@@ -1611,7 +1607,7 @@ def test_blur_over_node_by_node(cvs, orc, case):
     assert_same_f16(got.window_view(), want.window_view(), "blur+over %s" % case)
 
 
-@pytest.mark.parametrize("kernel", ["hv", "stream", "tiled"])
+@pytest.mark.parametrize("kernel", ["hv", "passes", "tiled"])
 @pytest.mark.parametrize("ntaps", [9, 10])
 def test_blur_over_node_by_node_through_the_table_kernels(cvs, orc, force_fir, kernel, ntaps):
     """The node-by-node form blurs an f16 source into an f32 frame; with the register-window kernels out of the way that is
@@ -2397,7 +2393,7 @@ def test_scaler_in_one_launch_agrees_with_the_two_passes(cvs, force_fir, fac, fm
     outs, fused = [], []
     # the tile form takes the enlarging calls whose rows of LDS fit (tile_vh_ops.hip cvk_fir_tvh_supported)
     tile_cases = {((1.5, 1.5), "f32"), ((2.0, 2.0), "f16"), ((1.25, 1.125), "f32")}
-    for kernel in (None, "strips", "stream"):
+    for kernel in (None, "strips", "passes"):
         force_fir(kernel)
         if fmt == "f16":
             d_src, d_out = DeviceFrame.from_host(src16), DeviceFrame((0, 0, tw - 1, th - 1), np.uint16)
@@ -2413,7 +2409,7 @@ def test_scaler_in_one_launch_agrees_with_the_two_passes(cvs, force_fir, fac, fm
         # (the horizontal-first gather exists in the default arithmetic flavour only: the contracted one runs the two passes)
         contracted = cvs.cvs_get_arithmetic() == _lib.ARITH_CONTRACTED
         vh = "tile-vh" if kernel is None and (fac, fmt) in tile_cases else "vh"
-        assert _KERNEL_NAMES[cvs.cvs_fir_last_kernel()] == ("pass" if kernel == "stream" or (contracted and fac[0] < fac[1]) else "hv" if fac[0] < fac[1] else vh)
+        assert _KERNEL_NAMES[cvs.cvs_fir_last_kernel()] == ("pass" if kernel == "passes" or (contracted and fac[0] < fac[1]) else "hv" if fac[0] < fac[1] else vh)
         got = d_out.download()
         outs.append((got.current_window.tuple(), got.array.copy()))
         d_src.free(); d_out.free()

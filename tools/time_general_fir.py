@@ -42,7 +42,7 @@ def timed(name, fn, nbytes):
     print("%-58s %.3f ms  %6.0f GB/s" % (name, ms, nbytes / ms / 1e6))
 
 
-which = {"hv": _lib.FIR_PATH_HV, "stream": _lib.FIR_PATH_SWEEP, "tiled": _lib.FIR_PATH_TILED}
+which = {"hv": _lib.FIR_PATH_HV, "passes": _lib.FIR_PATH_PASSES, "tiled": _lib.FIR_PATH_TILED}
 pin = [a for a in sys.argv[1:] if a in which]
 only_f16 = "f16" in sys.argv[1:]                 # just the f16 -> f16 resampler (one kernel under the profiler)
 factors = [float(a) for a in sys.argv[1:] if a not in which and a != "f16"] or [0.4, 0.75, 1.5]
