@@ -1,5 +1,6 @@
 """The reference's own scaler (video_scale_bilinear_f32 and its f16 twin) at the factors the editor uses, per call:
-ms, TB/s of source + target bytes, and which kernel took it (cvs_fir_last_kernel).  Sources rotate over enough frames to
+ms, TB/s of the bytes under the window the call reports (a reduction produces part of the target only, as the reference
+does), and which kernel took it (cvs_fir_last_kernel).  Sources rotate over enough frames to
 stay out of the Infinity Cache.   usage: python3 tools/time_scaler.py [--reps 40] [--only NAME] [--strips]"""
 import argparse
 import ctypes as C
@@ -106,9 +107,15 @@ def main():
                     run(i)
                 sync()
                 best = min(best, (time.perf_counter() - t0) / (args.reps * B))
-            nbytes = (w * h + tw * th) * bpp
-            print("%-16s %s  %.4f ms  %.2f TB/s (%.3f of 8)  kernel=%s fused=%d" % (
-                name, fmt, best * 1e3, nbytes / best / 1e12, nbytes / best / 8e12, NAMES[lib.cvs_fir_last_kernel()], lib.cvs_scale_last_was_fused()), flush=True)
+            # bytes: the window the call reports (video_scale.c:254-277 sizes the frame between the passes with `* factor`: a
+            # reduction produces only part of the target) and the source pixels under it
+            cw = outs[0].c.current_window
+            out_px = max(cw.max.x - cw.min.x + 1, 0) * max(cw.max.y - cw.min.y + 1, 0)
+            src_px = min(w * h, int(out_px / (fac[0] * fac[1])))
+            nbytes = (src_px + out_px) * bpp
+            print("%-16s %s  %.4f ms  %.2f TB/s (%.3f of 8)  window %dx%d of %dx%d  kernel=%s fused=%d" % (
+                name, fmt, best * 1e3, nbytes / best / 1e12, nbytes / best / 8e12, cw.max.x - cw.min.x + 1, cw.max.y - cw.min.y + 1, tw, th,
+                NAMES[lib.cvs_fir_last_kernel()], lib.cvs_scale_last_was_fused()), flush=True)
             for d in srcs + outs:
                 d.free()
 
