@@ -85,14 +85,15 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
     // source columns under the strip: its tiles of the footprint table (first > last: the tile touches nothing)
     constexpr int kTiles = kStrip / CVK_FIR2D_TILE_X;
     const int ntiles = (fp.tx1 - fp.tx0) / CVK_FIR2D_TILE_X + 1, t0 = kTiles * (int)blockIdx.x;
+    // (every entry read whether the strip has that tile or not -- the list is padded to a multiple of four, kernels.h -- so
+    // that the reads are one request, not one trip each behind a test)
+    int flo[kTiles], fhi[kTiles];
+#pragma unroll
+    for (int t = 0; t < kTiles; t++) { flo[t] = (int)foot[2 * (t0 + t)]; fhi[t] = (int)foot[2 * (t0 + t) + 1]; }
     int sx_lo = INT_MAX, sx_hi = INT_MIN;
 #pragma unroll
-    for (int t = 0; t < kTiles; t++) {
-        if (t0 + t < ntiles) {
-            const int lo1 = (int)foot[2 * (t0 + t)], hi1 = (int)foot[2 * (t0 + t) + 1];
-            if (hi1 >= lo1) { sx_lo = min(sx_lo, lo1); sx_hi = max(sx_hi, hi1); }
-        }
-    }
+    for (int t = 0; t < kTiles; t++)
+        if (t0 + t < ntiles && fhi[t] >= flo[t]) { sx_lo = min(sx_lo, flo[t]); sx_hi = max(sx_hi, fhi[t]); }
     if (sx_hi < sx_lo) sx_lo = sx_hi = fp.source.fx0;                    // no column of the strip has taps: any pixel will do
     const int npx = min(sx_hi - sx_lo + 1, NQ * kLanes);                 // (the host chose NQ to cover them)
 
@@ -160,12 +161,16 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
     };
 
     // first and last source row the segment's lines reach (first taps and last taps never decrease down the table)
-    int s_lo = INT_MAX, s_hi = INT_MIN;
-    {
+    // (the first and the last record requested at once; lines without taps at an end of the segment -- rare -- look further in)
+    const konst lend = lrec + (size_t)(ib - ia) * LR;
+    const int n_a = (int)lrec[0], f_a = (int)lrec[1], n_b = (int)lend[0], f_b = (int)lend[1];
+    int s_lo = f_a, s_hi = f_b + min(n_b, W) - 1;
+    if (n_a <= 0 || n_b <= 0) {
+        s_lo = INT_MAX; s_hi = INT_MIN;
         konst r = lrec;
         for (int i = ia; i <= ib; i++, r += LR)                          // uniform, scalar loads; segments are short
             if ((int)r[0] > 0) { s_lo = (int)r[1]; break; }
-        r = lrec + (size_t)(ib - ia) * LR;
+        r = lend;
         for (int i = ib; i >= ia; i--, r -= LR)
             if ((int)r[0] > 0) { s_hi = (int)r[1] + min((int)r[0], W) - 1; break; }
     }
