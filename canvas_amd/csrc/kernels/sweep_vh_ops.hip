@@ -54,8 +54,13 @@ static_assert(kLanes == 2 * CVK_FIR2D_TILE_X, "a strip is two or four tiles of t
 
 // PXL: target pixels per lane (1: a strip of 64 columns; 2: 128 columns, the lane owns the adjacent pair 2 lane, 2 lane + 1
 // and stores 16 bytes of halfs at once -- half the waves, half the scalar work per pixel; for large targets)
+// The leading arguments are what the set-up's first table reads need, as plain scalars: they arrive in SGPRs with the wave
+// (-amdgpu-kernarg-preload-count, csrc/Makefile), so those reads do not wait for the fetch of the struct behind them.
+// hpack: the horizontal table's packed lists when their width is MAXTH, else NULL.
+constexpr int kVhFpOffset = 48;  // where cvk_fir2d_params starts in the kernel-argument segment: three pointers, six ints (checked in the kernel)
 template <int W, int MAXTH, int NQ, bool INH, int PXL>
-__global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows_per_wg, int line0) {
+__global__ __launch_bounds__(kLanes) void k_fir_vh(const uint32_t *hpack, const int *hfoot, const uint32_t *vlrec, int rows_per_wg, int line0,
+                                                   int tx0, int tx1, int ty0, int ty1, cvk_fir2d_params fp) {
     static_assert(W >= 1 && W <= 8 && MAXTH >= 1 && MAXTH <= 8 && NQ >= 1 && NQ <= 5 && (PXL == 1 || PXL == 2), "instances");
     constexpr int kZero = NQ * kLanes;                                   // the zero pixel behind the mid row
     constexpr int kStrip = kLanes * PXL;                                 // target columns per workgroup
@@ -72,19 +77,38 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
     // a batch of frames of this geometry: grid.z picks the frame (its pointers read through the kernel-argument segment: a
     // scalar load at a computed offset; the struct is the kernel's first argument)
     typedef const cvk_fir2d_params __attribute__((address_space(4))) *kargs_t;
-    const kargs_t ka = (kargs_t)__builtin_amdgcn_kernarg_segment_ptr();
-    const void *const src_data = fp.nframes > 1 ? ka->frame_source[blockIdx.z] : fp.source.data;
-    void *const dst_data = fp.nframes > 1 ? ka->frame_target[blockIdx.z] : fp.target.data;
-    const int tcol = fp.tx0 + (int)blockIdx.x * kStrip + (PXL == 2 && out_half ? 2 * lane : lane);
-    const int nlines = fp.ty1 - fp.ty0 + 1;
+    const kargs_t ka = (kargs_t)((const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr() + kVhFpOffset);
+    // (read whether there is a batch or not, so that the reads are requested with the rest of the arguments; the check: the
+    // segment's layout is the compiler's -- were the struct not where kVhFpOffset says, no pointer from it may be used)
+    const void *const zsrc = ka->frame_source[blockIdx.z];
+    void *const ztgt = ka->frame_target[blockIdx.z];
+    const int nframes = fp.nframes, chk_n = ka->nframes, chk_x = ka->tx1, chk_y = ka->ty1, chk_p = ka->source.pitch;
+    const void *const one_src = fp.source.data;
+    void *const one_tgt = fp.target.data;
+    const int tcol = tx0 + (int)blockIdx.x * kStrip + (PXL == 2 && out_half ? 2 * lane : lane);
+    const int nlines = ty1 - ty0 + 1;
     // target lines, counted from the vertical table's first (fp.ty0); the launch covers lines line0 .. nlines - 1
     const int ia = line0 + (int)blockIdx.y * rows_per_wg, ib = min(ia + rows_per_wg - 1, nlines - 1);
-    const konst foot = as_konst(fp.h.foot);
+    const konst foot = as_konst(hfoot);
+    // the packed tap lists of this lane's columns (when the table has them at this width): requested first, on the preloaded
+    // arguments alone; decoded below, once the strip's first source column is known
+    constexpr bool kPackable = MAXTH == 2 || MAXTH == 4;
+    const bool packed = kPackable && hpack != nullptr;                   // (uniform)
+    uint32_t hrec[PXL][kPackable ? 2 * MAXTH : 1];
+    if (packed) {
+#pragma unroll
+        for (int p = 0; p < PXL; p++) {
+            const int hline = min(tcol + p * cstep, tx1) - tx0;
+            const uint4 *g = reinterpret_cast<const uint4 *>(hpack + (size_t)hline * 2 * MAXTH);
+#pragma unroll
+            for (int q = 0; q < MAXTH / 2; q++) { const uint4 x = g[q]; hrec[p][4 * q] = x.x; hrec[p][4 * q + 1] = x.y; hrec[p][4 * q + 2] = x.z; hrec[p][4 * q + 3] = x.w; }
+        }
+    }
     const int hstride = fp.h.stride;
 
     // source columns under the strip: its tiles of the footprint table (first > last: the tile touches nothing)
     constexpr int kTiles = kStrip / CVK_FIR2D_TILE_X;
-    const int ntiles = (fp.tx1 - fp.tx0) / CVK_FIR2D_TILE_X + 1, t0 = kTiles * (int)blockIdx.x;
+    const int ntiles = (tx1 - tx0) / CVK_FIR2D_TILE_X + 1, t0 = kTiles * (int)blockIdx.x;
     // (every entry read whether the strip has that tile or not -- the list is padded to a multiple of four, kernels.h -- so
     // that the reads are one request, not one trip each behind a test)
     int flo[kTiles], fhi[kTiles];
@@ -101,29 +125,24 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
     bool col_live[PXL];
     int aoff[PXL][MAXTH];
     float wt[PXL][MAXTH];
-    if ((MAXTH == 2 || MAXTH == 4) && fp.h.pack != nullptr && fp.h.pack_width == MAXTH) {
+    if (packed) {
         // short lists come packed (kernels.h cvk_fir_axis.pack): one aligned read per column, lanes reading consecutive
         // records, instead of 1 + 2 MAXTH scattered ones -- the set-up's first trip to memory is mostly this
 #pragma unroll
         for (int p = 0; p < PXL; p++) {
-            col_live[p] = tcol + p * cstep <= fp.tx1;
-            const int hline = min(tcol + p * cstep, fp.tx1) - fp.tx0;
-            uint32_t rec[2 * MAXTH];
-            const uint4 *g = reinterpret_cast<const uint4 *>(fp.h.pack + (size_t)hline * 2 * MAXTH);
-#pragma unroll
-            for (int q = 0; q < MAXTH / 2; q++) { const uint4 x = g[q]; rec[4 * q] = x.x; rec[4 * q + 1] = x.y; rec[4 * q + 2] = x.z; rec[4 * q + 3] = x.w; }
+            col_live[p] = tcol + p * cstep <= tx1;
 #pragma unroll
             for (int k = 0; k < MAXTH; k++) {
-                const bool live = col_live[p] && (int)rec[k] != INT_MIN;
-                aoff[p][k] = live ? min(max((int)rec[k] - sx_lo, 0), kZero) : kZero;
-                wt[p][k] = live ? __uint_as_float(rec[MAXTH + k]) : 0.0f;
+                const bool live = col_live[p] && (int)hrec[p][k] != INT_MIN;
+                aoff[p][k] = live ? min(max((int)hrec[p][k] - sx_lo, 0), kZero) : kZero;
+                wt[p][k] = live ? __uint_as_float(hrec[p][kPackable ? MAXTH + k : 0]) : 0.0f;
             }
         }
     } else {
 #pragma unroll
         for (int p = 0; p < PXL; p++) {
-            col_live[p] = tcol + p * cstep <= fp.tx1;
-            const int hline = tcol + p * cstep - fp.tx0;
+            col_live[p] = tcol + p * cstep <= tx1;
+            const int hline = tcol + p * cstep - tx0;
             const int hn = col_live[p] ? min(fp.h.ntaps[hline], MAXTH) : 0;
 #pragma unroll
             for (int k = 0; k < MAXTH; k++) {
@@ -139,16 +158,19 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(cvk_fir2d_params fp, int rows
     { float acc = 0.0f; _Pragma("unroll") for (int p = 0; p < PXL; p++) { _Pragma("unroll") for (int k = 0; k < MAXTH; k++) acc += wt[p][k] + (float)aoff[p][k]; } asm volatile("" :: "v"(acc)); }
 #endif
     CVS_VH_CLOCK(1);                                                     // the tap lists have landed
-    const bool all_live = fp.tx0 + ((int)blockIdx.x + 1) * kStrip - 1 <= fp.tx1;      // (uniform) every lane's columns exist
+    if (nframes > 1 && !(chk_n == nframes && chk_x == tx1 && chk_y == ty1 && chk_p == fp.source.pitch)) return;
+    const void *const src_data = nframes > 1 ? zsrc : one_src;
+    void *const dst_data = nframes > 1 ? ztgt : one_tgt;
+    const bool all_live = tx0 + ((int)blockIdx.x + 1) * kStrip - 1 <= tx1;      // (uniform) every lane's columns exist
 
     constexpr uint32_t tpx = out_half ? 8 : 16;
     char *optr = reinterpret_cast<char *>(dst_data) + ((size_t)(tcol - fp.target.fx0)) * tpx
-               + (size_t)(fp.ty0 + ia - fp.target.fy0) * (size_t)fp.target.pitch * tpx;
+               + (size_t)(ty0 + ia - fp.target.fy0) * (size_t)fp.target.pitch * tpx;
     const size_t trow = (size_t)fp.target.pitch * tpx;
 
     // one record per line (cvk_fir_axis.lrec): count, first source row, weights -- one scalar load, requested a line ahead
     constexpr int LR = CVK_FIR_LREC;
-    konst lrec = as_konst(fp.v.lrec) + (size_t)ia * LR;
+    konst lrec = as_konst(vlrec) + (size_t)ia * LR;
     struct Line { int n, first; float w[W]; };
     auto load_line = [&]() __attribute__((always_inline)) {              // the record `lrec` points at; then on to the next
         Line l;
@@ -331,7 +353,8 @@ int launch(const cvk_fir2d_params &fp, int line0, int cus, hipStream_t s) {
     if (r > 256) r = 256;
     if (r > rows) r = rows;
     dim3 grid((unsigned)strips, (unsigned)((rows + r - 1) / r), (unsigned)frames);
-    hipLaunchKernelGGL((k_fir_vh<W, MAXTH, NQ, INH, PXL>), grid, dim3(kLanes), 0, s, fp, r, line0);
+    const uint32_t *hpack = (MAXTH == 2 || MAXTH == 4) && fp.h.pack != nullptr && fp.h.pack_width == MAXTH ? fp.h.pack : nullptr;
+    hipLaunchKernelGGL((k_fir_vh<W, MAXTH, NQ, INH, PXL>), grid, dim3(kLanes), 0, s, hpack, fp.h.foot, fp.v.lrec, r, line0, fp.tx0, fp.tx1, fp.ty0, fp.ty1, fp);
     return (int)hipGetLastError();
 }
 
