@@ -47,6 +47,8 @@ extern "C" __attribute__((visibility("default"))) int cvk_fir_vh_clock_buffer(vo
 namespace {
 
 using cvs::f32x2;
+typedef uint32_t nt_u4 __attribute__((ext_vector_type(4)));
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
 
 constexpr int kLanes = 64;       // one wave per workgroup; a lane owns one or two target columns
 constexpr int kPF = 3;           // source rows requested ahead of the window
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(const uint32_t *hpack, const 
 #pragma unroll
                 for (int p = 0; p < PXL; p++) { const uint2 v = narrow4(hlo[p], hhi[p]); h[p][0] = v.x; h[p][1] = v.y; }
                 if constexpr (PXL == 2) {
-                    if (all_live || col_live[1]) *reinterpret_cast<uint4 *>(optr) = make_uint4(h[0][0], h[0][1], h[1][0], h[1][1]);
+                    if (all_live || col_live[1]) __builtin_nontemporal_store(nt_u4{ h[0][0], h[0][1], h[1][0], h[1][1] }, reinterpret_cast<nt_u4 *>(optr));      // (streamed: nothing reads the target back)
                     else if (col_live[0]) *reinterpret_cast<uint2 *>(optr) = make_uint2(h[0][0], h[0][1]);
                 } else {
                     if (all_live || col_live[0]) *reinterpret_cast<uint2 *>(optr) = make_uint2(h[0][0], h[0][1]);
@@ -303,7 +305,12 @@ __global__ __launch_bounds__(kLanes) void k_fir_vh(const uint32_t *hpack, const 
             } else {
 #pragma unroll
                 for (int p = 0; p < PXL; p++)
-                    if (all_live || col_live[p]) *reinterpret_cast<float4 *>(optr + 16 * kLanes * p) = make_float4(hlo[p].x, hlo[p].y, hhi[p].x, hhi[p].y);
+                    if (all_live || col_live[p]) {
+                        // (streamed where the target is the large frame -- the two-columns-per-lane instances: 3..9 % on floats; on the
+                        // reducing instances it cost 10 % at 0.75x: profiles/r04/vh_streamed_stores_ab.txt)
+                        if constexpr (PXL == 2) __builtin_nontemporal_store(nt_f4{ hlo[p].x, hlo[p].y, hhi[p].x, hhi[p].y }, reinterpret_cast<nt_f4 *>(optr + 16 * kLanes * p));
+                        else *reinterpret_cast<float4 *>(optr + 16 * kLanes * p) = make_float4(hlo[p].x, hlo[p].y, hhi[p].x, hhi[p].y);
+                    }
             }
             optr += trow;
 #ifdef CVS_VH_PROBES

@@ -387,12 +387,18 @@ __global__ __launch_bounds__(kThreads) void k_fir_tile_vh(const uint32_t *hpack,
         char *optr = obase + (size_t)line * trow;
         if constexpr (out_half) {
             const uint4 h = narrow8(hlo[0], hhi[0], hlo[1], hhi[1]);
-            if (all_live || col_live[1]) *reinterpret_cast<uint4 *>(optr) = h;
+            if (all_live || col_live[1]) {                               // (streamed: nothing reads the target back)
+                typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(u32x4_t{ h.x, h.y, h.z, h.w }, reinterpret_cast<u32x4_t *>(optr));
+            }
             else if (col_live[0]) *reinterpret_cast<uint2 *>(optr) = make_uint2(h.x, h.y);
         } else {
 #pragma unroll
             for (int p = 0; p < 2; p++)
-                if (all_live || col_live[p]) *reinterpret_cast<float4 *>(optr + 16 * 64 * p) = make_float4(hlo[p].x, hlo[p].y, hhi[p].x, hhi[p].y);
+                if (all_live || col_live[p]) {
+                    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(f32x4_t{ hlo[p].x, hlo[p].y, hhi[p].x, hhi[p].y }, reinterpret_cast<f32x4_t *>(optr + 16 * 64 * p));
+                }
         }
         if (line == wave) CVS_TVH_CLOCK(5);                              // the wave's first line: stores issued
     }
