@@ -174,21 +174,28 @@ def run_extras(lib, dist, rank, world, stream, ring, my_frames, matrix, seconds)
     # ---------------------------------------------------------------- the reference's own scaler, 1080p -> 4K (A9; no BASELINE config)
     from canvas_amd.abi import v2f
     small_w, small_h = w // 2, h // 2
+    # 96 sources (1.6 GB: the SOURCES alone must not fit the 256 MiB Infinity Cache -- the kernels' stores are non-temporal and
+    # leave it to what is read) into 16 targets (1.06 GB); every source that lands in target 0 is the generator's frame
     srcs = []
-    for i, donor in enumerate(sources):
+    nsrc = 6 * len(sources)
+    for i in range(nsrc):
         d = DeviceFrame((0, 0, small_w - 1, small_h - 1), np.uint16)
         if i == 0:
             d.upload(synth.layer_pixels(small_w, small_h, 1, g0))
+        elif i % len(sources) == 0:
+            _lib.check(lib.cvs_memcpy_d2d(d.ptr, srcs[0].ptr, d.nbytes, stream), "d2d")
         else:                                                                      # a quarter of a 4K frame's pixels: same distribution
-            _lib.check(lib.cvs_memcpy_d2d(d.ptr, donor.ptr, d.nbytes, stream), "d2d")
+            donor = sources[i % len(sources)]
+            off = (i // len(sources)) % 4 * d.nbytes
+            _lib.check(lib.cvs_memcpy_d2d(d.ptr, donor.ptr + off, d.nbytes, stream), "d2d")
         srcs.append(d)
-    bigs = [DeviceFrame((0, 0, w - 1, h - 1), np.uint16) for _ in srcs]              # 16 x (17 + 66) MB rotate
+    bigs = [DeviceFrame((0, 0, w - 1, h - 1), np.uint16) for _ in sources]           # 96 x 17 MB read, 16 x 66 MB written, rotating
 
     streams_s = [stream, lib.cvs_stream_create()]               # two frames in flight (the reference's pull queue has two workers)
 
     def pass_s():
-        for i, (src, dst) in enumerate(zip(srcs, bigs)):
-            _lib.check(lib.cvs_scale_bilinear_f16_dev(dst.ref(), v2f(0, 0), src.ref(), v2f(0, 0), v2f(2.0, 2.0), streams_s[i % 2]), "scaler")
+        for i, src in enumerate(srcs):
+            _lib.check(lib.cvs_scale_bilinear_f16_dev(bigs[i % len(bigs)].ref(), v2f(0, 0), src.ref(), v2f(0, 0), v2f(2.0, 2.0), streams_s[i % 2]), "scaler")
 
     n, dt = _timed_passes(lib, _lib, streams_s, pass_s, seconds / 2)
     lib.cvs_stream_sync(streams_s[1])
