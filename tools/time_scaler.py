@@ -1,7 +1,7 @@
 """The reference's own scaler (video_scale_bilinear_f32 and its f16 twin) at the factors the editor uses, per call:
 ms, TB/s of the bytes under the window the call reports (a reduction produces part of the target only, as the reference
-does), and which kernel took it (cvs_fir_last_kernel).  Sources rotate over enough frames to
-stay out of the Infinity Cache.   usage: python3 tools/time_scaler.py [--reps 40] [--only NAME] [--strips]"""
+does), and which kernel took it (cvs_fir_last_kernel).  Sources rotate over 1.6 GB (the scaler kernels'
+stores are non-temporal: the targets do not sweep the Infinity Cache, so the sources must not fit it on their own).   usage: python3 tools/time_scaler.py [--reps 40] [--only NAME] [--strips]"""
 import argparse
 import ctypes as C
 import os
@@ -58,8 +58,7 @@ def main():
         tw, th = int(w * fac[0]), int(h * fac[1])
         for fmt in ("f16", "f32"):
             bpp = 8 if fmt == "f16" else 16
-            nsrc = max(2, int(600e6 // (w * h * bpp)) + 1)
-            nsrc = min(nsrc, 24)
+            nsrc = min(max(2, int(1.6e9 // (w * h * bpp)) + 1), 100)     # the sources alone exceed the 256 MiB Infinity Cache several times over
             host = synth.layer_frame(w, h, 1, 0)
             srcs = []
             for k in range(nsrc):
